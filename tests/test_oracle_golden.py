@@ -1,0 +1,139 @@
+"""CPU: the oracle/ restatement reproduces every committed golden vector.
+
+The goldens were produced from the imported reference by tests/golden/make_golden.py
+(eager `attn_ref` + autograd, `RelativePositionalEncoding`, the eager LayerNorm / CE modules, and the
+reference's Triton kernels run under the Triton CPU interpreter)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_io import load, load_attn, ATTN_CASES, TRITON_CASES
+
+
+def md(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+def test_bucket_known_answers():
+    # SURVEY 8(a8) known answers (probed from reference positional_encoding.py:25-71)
+    d = np.arange(-200, 200, 25)
+    assert oracle.relative_position_bucket(d, True, 32, 128).tolist() == \
+        [15, 15, 15, 15, 15, 14, 13, 11, 0, 27, 29, 30, 31, 31, 31, 31]
+    assert oracle.relative_position_bucket(d, False, 32, 128).tolist() == \
+        [31, 31, 31, 31, 30, 27, 24, 19, 0, 0, 0, 0, 0, 0, 0, 0]
+
+
+def test_bucket_golden():
+    z = load("rpe_buckets")
+    deltas = z["deltas"]
+    n = 0
+    for key, val in z.items():
+        if key.startswith("bucket_"):
+            _, bidir, nb, mdist = key.split("_")
+            mine = oracle.relative_position_bucket(deltas, bool(int(bidir)), int(nb), int(mdist))
+            assert np.array_equal(mine.astype(np.int32), val), key
+            n += 1
+    assert n == 8
+
+
+@pytest.mark.parametrize("bidir,M,N", [(1, 256, 256), (1, 96, 160), (0, 128, 128)])
+def test_bias1d_golden(bidir, M, N):
+    z = load("rpe_buckets")
+    table = torch.from_numpy(z[f"table_{bidir}_{M}_{N}"])
+    b1 = oracle.bias1d_from_table(table, M, N, bool(bidir), 32, 128)
+    assert torch.equal(b1, torch.from_numpy(z[f"bias1d_{bidir}_{M}_{N}"]))
+    dense = oracle.compute_bias(table, M, N, bool(bidir), 32, 128)
+    assert torch.equal(dense[0, :, 0, :], torch.from_numpy(z[f"bias_{bidir}_{M}_{N}_row0"]))
+    assert torch.equal(dense[0, :, M - 1, :], torch.from_numpy(z[f"bias_{bidir}_{M}_{N}_rowlast"]))
+    assert torch.equal(oracle.toeplitz_from_bias1d(b1, M, N), dense)
+    # scatter of diagonal sums == autograd through the dense bias
+    g = torch.Generator().manual_seed(5)
+    dbias = torch.randn(1, table.shape[1], M, N, generator=g)
+    tl = table.clone().requires_grad_()
+    oracle.compute_bias(tl, M, N, bool(bidir), 32, 128).backward(dbias)
+    d1 = torch.zeros(table.shape[1], M + N - 1)
+    idx = (torch.arange(N)[None, :] - torch.arange(M)[:, None]) + (M - 1)
+    d1.index_add_(1, idx.reshape(-1), dbias[0].reshape(table.shape[1], -1))
+    tg = oracle.table_grad_from_dbias1d(d1, M, N, bool(bidir), 32, 128)
+    assert md(tg, tl.grad) < 1e-3
+
+
+def test_attn_cfg1_golden():
+    c = load_attn("attn_cfg1_fp32")
+    o, L = oracle.attn_fwd_oracle(c["q"], c["k"], c["v"], c["bias"], c["sm_scale"], c["causal"])
+    assert md(o, c["o"]) < 1e-6 and md(L, c["L"]) < 1e-6
+    o2 = oracle.attn_ref(c["q"], c["k"], c["v"], c["bias"], c["sm_scale"], causal=c["causal"], upcast=True)
+    assert md(o2, c["o"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", ATTN_CASES)
+def test_attn_golden(name):
+    c = load_attn(name)
+    q, k, v, b, do = c["q"], c["k"], c["v"], c["bias"], c["do"]
+    o, L = oracle.attn_fwd_oracle(q, k, v, b, c["sm_scale"], c["causal"])
+    assert md(o, c["o"]) < 1e-6 and (L - c["L"]).nan_to_num(0, 0, 0).abs().max() < 1e-6
+    dq, dk, dv, ds, dbias = oracle.attn_bwd_oracle(q, k, v, b, o, L, do, c["sm_scale"], c["causal"])
+    tol = 4e-4  # fp32 summation order vs autograd
+    assert md(dq, c["dq"]) < tol and md(dk, c["dk"]) < tol and md(dv, c["dv"]) < tol
+    if b is not None:
+        assert dbias.shape == b.shape
+        assert md(dbias, c["dbias"]) < 4 * tol
+    # row sums of dS vanish (softmax Jacobian) -- property used by the kernels' tests at full size
+    assert ds.sum(-1).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("name", TRITON_CASES)
+def test_oracle_vs_reference_triton_kernels(name):
+    """The oracle agrees with the reference's own Triton kernels (interpreter, fp16) within fp16 rounding."""
+    c = load_attn(name)
+    q, k, v, b, do = c["q"], c["k"], c["v"], c["bias"], c["do"]
+    o, L = oracle.attn_fwd_oracle(q, k, v, b, c["sm_scale"], c["causal"])
+    dq, dk, dv, _, dbias = oracle.attn_bwd_oracle(q, k, v, b, o, L, do, c["sm_scale"], c["causal"])
+    for mine, key in ((o, "o_triton"), (dq, "dq_triton"), (dk, "dk_triton"), (dv, "dv_triton"), (dbias, "dbias_triton")):
+        assert md(mine, c[key]) < 2e-3 * max(1.0, mine.abs().max().item()), key
+    assert md(L, c["L_triton"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rmsnorm_golden(tag):
+    z = load("rmsnorm")
+    x, w, dy = (torch.from_numpy(z[f"{n}_{tag}"]) for n in ("x", "w", "dy"))
+    y, rstd = oracle.rmsnorm_fwd_oracle(x, w, 1e-6)
+    dx, dw = oracle.rmsnorm_bwd_oracle(dy, x, w, rstd)
+    assert md(y, torch.from_numpy(z[f"y_{tag}"])) < 1e-5
+    assert md(rstd, torch.from_numpy(z[f"rstd_{tag}"])) < 1e-5
+    assert md(dx, torch.from_numpy(z[f"dx_{tag}"])) < 1e-5
+    assert md(dw, torch.from_numpy(z[f"dw_{tag}"])) < 1e-4
+    assert md(oracle.rmsnorm_eager(x, w, 1e-6), torch.from_numpy(z[f"y_eager_{tag}"])) == 0.0
+    assert md(dx, torch.from_numpy(z[f"dx_eager_{tag}"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_ce_golden(tag):
+    z = load("cross_entropy")
+    logits = torch.from_numpy(z[f"logits_{tag}"])
+    labels = torch.from_numpy(z[f"labels_{tag}"])
+    dloss = torch.from_numpy(z[f"dloss_{tag}"])
+    smooth, zl = (float(x) for x in z[f"cfg_{tag}"])
+    loss, zz, lse = oracle.ce_fwd_oracle(logits, labels, smooth, 1.0, zl, -100)
+    dl = oracle.ce_bwd_oracle(dloss, logits, lse, labels, smooth, 1.0, zl, -100)
+    s = max(1.0, 50 * zl)
+    assert md(loss, torch.from_numpy(z[f"loss_{tag}"])) < 2e-4 * s
+    assert md(zz, torch.from_numpy(z[f"z_{tag}"])) < 2e-4 * s
+    assert md(lse, torch.from_numpy(z[f"lse_{tag}"])) < 1e-5
+    assert md(dl, torch.from_numpy(z[f"dlogits_{tag}"])) < 1e-5 * s
+    assert loss[1] == 0 and zz[1] == 0 and dl[1].abs().max() == 0  # ignore_index rows
+
+
+def test_varlen_oracle_matches_dense():
+    g = torch.Generator().manual_seed(0)
+    H, D = 2, 64
+    cu_q, cu_k = [0, 5, 5, 17], [0, 9, 12, 40]
+    q = torch.randn(cu_q[-1], H, D, generator=g)
+    k = torch.randn(cu_k[-1], H, D, generator=g)
+    v = torch.randn(cu_k[-1], H, D, generator=g)
+    out = oracle.attn_varlen_oracle(q, k, v, cu_q, cu_k, 0.125)
+    o0, _ = oracle.attn_fwd_oracle(q[0:5].permute(1, 0, 2)[None], k[0:9].permute(1, 0, 2)[None],
+                                   v[0:9].permute(1, 0, 2)[None], None, 0.125)
+    assert md(out[0:5], o0[0].permute(1, 0, 2)) == 0
