@@ -1,0 +1,111 @@
+"""ctypes binding of libfat5.so (the C ABI declared in include/fat5.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the
+ops raises -- a GPU box must never silently run something else.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfat5.so")
+
+FAT5_F32, FAT5_F16, FAT5_BF16 = 0, 1, 2
+BIAS_NONE, BIAS_DENSE, BIAS_RPE1D = 0, 1, 2
+MAX_RPE_RADIUS = 2048
+
+_DT = {torch.float32: FAT5_F32, torch.float16: FAT5_F16, torch.bfloat16: FAT5_BF16}
+
+c_i64x3 = ctypes.c_int64 * 3
+
+
+class AttnParams(ctypes.Structure):
+    """Mirror of `fat5_attn_params` (include/fat5.h) -- field order must match exactly."""
+    _fields_ = [
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("M", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("causal", ctypes.c_int32),
+        ("bias_mode", ctypes.c_int32), ("sm_scale", ctypes.c_float), ("rpe_radius", ctypes.c_int32),
+        ("q", ctypes.c_void_p), ("k", ctypes.c_void_p), ("v", ctypes.c_void_p), ("o", ctypes.c_void_p),
+        ("lse", ctypes.c_void_p),
+        ("q_stride", c_i64x3), ("k_stride", c_i64x3), ("v_stride", c_i64x3), ("o_stride", c_i64x3),
+        ("bias", ctypes.c_void_p), ("bias_stride", c_i64x3), ("rpe1d", ctypes.c_void_p),
+        ("cu_seqlens_q", ctypes.c_void_p), ("cu_seqlens_k", ctypes.c_void_p),
+        ("total_q", ctypes.c_int32), ("total_k", ctypes.c_int32),
+        ("dout", ctypes.c_void_p), ("dq", ctypes.c_void_p), ("dk", ctypes.c_void_p), ("dv", ctypes.c_void_p),
+        ("do_stride", c_i64x3), ("dq_stride", c_i64x3), ("dk_stride", c_i64x3), ("dv_stride", c_i64x3),
+        ("dbias", ctypes.c_void_p), ("dbias_batch", ctypes.c_int32), ("dbias_heads", ctypes.c_int32),
+        ("drpe1d", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+EXPORTS = (
+    "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd",
+    "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_ce_fwd", "fat5_ce_bwd",
+)
+
+_lib = None
+
+
+def load():
+    """Load libfat5.so once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python flasht5_amd/build.py` (hipcc, gfx950). "
+            "flasht5_amd has no non-HIP fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.fat5_version.restype = ctypes.c_int
+    lib.fat5_last_error.restype = ctypes.c_char_p
+    lib.fat5_attn_fwd.restype = ctypes.c_int
+    lib.fat5_attn_fwd.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_void_p]
+    lib.fat5_attn_bwd.restype = ctypes.c_int
+    lib.fat5_attn_bwd.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_void_p]
+    lib.fat5_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.fat5_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(AttnParams)]
+    i64, f32, vp, i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+    lib.fat5_rmsnorm_fwd.restype = ctypes.c_int
+    lib.fat5_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, i32, vp]
+    lib.fat5_rmsnorm_bwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.fat5_rmsnorm_bwd_workspace_bytes.argtypes = [i64, i64]
+    lib.fat5_rmsnorm_bwd.restype = ctypes.c_int
+    lib.fat5_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.fat5_ce_fwd.restype = ctypes.c_int
+    lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
+    lib.fat5_ce_bwd.restype = ctypes.c_int
+    lib.fat5_ce_bwd.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, f32, f32, i64, i32, vp]
+    lib.fat5_sizeof_attn_params.restype = ctypes.c_size_t
+    if lib.fat5_sizeof_attn_params() != ctypes.sizeof(AttnParams):
+        raise ImportError(f"fat5_attn_params layout mismatch: library {lib.fat5_sizeof_attn_params()} B, "
+                          f"binding {ctypes.sizeof(AttnParams)} B")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fat5_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (fat5 status {rc}): {msg}")
+
+
+def dtype_code(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}") from None
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def strides3(t):
+    """(b, h, s) element strides of a 4-D (B,H,S,D) tensor as a ctypes array."""
+    return c_i64x3(t.stride(0), t.stride(1), t.stride(2))
+
+
+def kernel_ready(t):
+    """The kernels need last-dim stride 1, 16-byte aligned base and strides that are multiples of 8."""
+    return (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % 8 == 0 for s in t.stride()[:-1]))

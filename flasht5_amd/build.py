@@ -1,0 +1,69 @@
+"""Build libfat5.so (gfx950) in-tree with hipcc.  `python flasht5_amd/build.py [--force]` (run as a script: importing the package needs the library).
+
+The built library lives at flasht5_amd/lib/libfat5.so (git-ignored, travels to the GPU box).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libfat5.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-Wno-unused-value", "-I", INCLUDE]
+
+# (source, object name, extra defines)
+UNITS = [("fat5_api.hip", "fat5_api.o", [])]
+for d in (32, 64, 128):
+    UNITS.append(("attn_fwd_inst.hip", f"attn_fwd_d{d}.o", [f"-DFAT5_INST_D={d}"]))
+    UNITS.append(("attn_bwd_inst.hip", f"attn_bwd_d{d}.o", [f"-DFAT5_INST_D={d}"]))
+
+
+def _deps_mtime():
+    m = 0.0
+    for root in (CSRC, INCLUDE):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".hip")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(unit):
+    src, obj, defs = unit
+    cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", os.path.join(OBJ, obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {obj}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build_lib(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    newest = _deps_mtime()
+    todo = [u for u in UNITS
+            if force or not os.path.exists(os.path.join(OBJ, u[1])) or os.path.getmtime(os.path.join(OBJ, u[1])) < newest]
+    if todo:
+        if verbose:
+            print(f"[fat5 build] compiling {len(todo)} unit(s) for gfx950 ...", flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
+            for obj in ex.map(_compile, todo):
+                if verbose:
+                    print(f"[fat5 build]   {obj}", flush=True)
+    objs = [os.path.join(OBJ, u[1]) for u in UNITS]
+    if todo or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[fat5 build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)

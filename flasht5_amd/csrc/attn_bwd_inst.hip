@@ -1,0 +1,65 @@
+// Instantiations of the backward kernels for one head_dim (compile with -DFAT5_INST_D=32|64|128).
+#include "attn_bwd.h"
+#include "attn_launch.h"
+
+#ifndef FAT5_INST_D
+#error "FAT5_INST_D must be defined"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+namespace fat5 {
+
+template <typename K>
+static hipError_t set_smem(K kern, size_t smem) {
+  if (smem > 48 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  return hipSuccess;
+}
+
+template <int D, bool BF16, int BIAS, int NW>
+static hipError_t launch_q(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = BwdQCfg<D, NW>::smem(a.R, BIAS);
+  auto kern = attn_bwd_q_kernel<D, BF16, BIAS, NW>;
+  hipError_t e = set_smem(kern, smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  return hipGetLastError();
+}
+template <int D, bool BF16, int BIAS, int NW>
+static hipError_t launch_kv(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = BwdKVCfg<D, NW>::smem(a.R, BIAS);
+  auto kern = attn_bwd_kv_kernel<D, BF16, BIAS, NW>;
+  hipError_t e = set_smem(kern, smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  return hipGetLastError();
+}
+
+#define DISPATCH(FN, a, bf16, bias, nw, grid, s)                                                     \
+  do {                                                                                               \
+    if (bf16) {                                                                                      \
+      if (bias == FAT5_BIAS_NONE) return nw == 2 ? FN<FAT5_INST_D, true, 0, 2>(a, grid, s) : FN<FAT5_INST_D, true, 0, 4>(a, grid, s); \
+      if (bias == FAT5_BIAS_DENSE) return nw == 2 ? FN<FAT5_INST_D, true, 1, 2>(a, grid, s) : FN<FAT5_INST_D, true, 1, 4>(a, grid, s); \
+      return nw == 2 ? FN<FAT5_INST_D, true, 2, 2>(a, grid, s) : FN<FAT5_INST_D, true, 2, 4>(a, grid, s); \
+    } else {                                                                                         \
+      if (bias == FAT5_BIAS_NONE) return nw == 2 ? FN<FAT5_INST_D, false, 0, 2>(a, grid, s) : FN<FAT5_INST_D, false, 0, 4>(a, grid, s); \
+      if (bias == FAT5_BIAS_DENSE) return nw == 2 ? FN<FAT5_INST_D, false, 1, 2>(a, grid, s) : FN<FAT5_INST_D, false, 1, 4>(a, grid, s); \
+      return nw == 2 ? FN<FAT5_INST_D, false, 2, 2>(a, grid, s) : FN<FAT5_INST_D, false, 2, 4>(a, grid, s); \
+    }                                                                                                \
+  } while (0)
+
+hipError_t CAT(launch_bwd_q_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  DISPATCH(launch_q, a, bf16, bias, nw, grid, s);
+}
+hipError_t CAT(launch_bwd_kv_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  DISPATCH(launch_kv, a, bf16, bias, nw, grid, s);
+}
+size_t CAT(smem_bwd_q_d, FAT5_INST_D)(int nw, int R, int bias) {
+  return nw == 2 ? BwdQCfg<FAT5_INST_D, 2>::smem(R, bias) : BwdQCfg<FAT5_INST_D, 4>::smem(R, bias);
+}
+size_t CAT(smem_bwd_kv_d, FAT5_INST_D)(int nw, int R, int bias) {
+  return nw == 2 ? BwdKVCfg<FAT5_INST_D, 2>::smem(R, bias) : BwdKVCfg<FAT5_INST_D, 4>::smem(R, bias);
+}
+
+}  // namespace fat5

@@ -1,0 +1,45 @@
+// Instantiations of the forward kernel for one head_dim (compile with -DFAT5_INST_D=32|64|128).
+#include "attn_fwd.h"
+#include "attn_launch.h"
+
+#ifndef FAT5_INST_D
+#error "FAT5_INST_D must be defined"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+namespace fat5 {
+
+template <int D, bool BF16, int BIAS, int NW>
+static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
+  auto kern = attn_fwd_kernel<D, BF16, BIAS, NW>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  return hipGetLastError();
+}
+
+template <int D, bool BF16, int BIAS>
+static hipError_t launch_nw(const AttnArgs& a, int nw, int grid, hipStream_t s) {
+  return nw == 2 ? launch_one<D, BF16, BIAS, 2>(a, grid, s) : launch_one<D, BF16, BIAS, 4>(a, grid, s);
+}
+template <int D, bool BF16>
+static hipError_t launch_bias(const AttnArgs& a, int bias, int nw, int grid, hipStream_t s) {
+  switch (bias) {
+    case FAT5_BIAS_NONE: return launch_nw<D, BF16, FAT5_BIAS_NONE>(a, nw, grid, s);
+    case FAT5_BIAS_DENSE: return launch_nw<D, BF16, FAT5_BIAS_DENSE>(a, nw, grid, s);
+    default: return launch_nw<D, BF16, FAT5_BIAS_RPE1D>(a, nw, grid, s);
+  }
+}
+
+hipError_t CAT(launch_fwd_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  return bf16 ? launch_bias<FAT5_INST_D, true>(a, bias, nw, grid, s) : launch_bias<FAT5_INST_D, false>(a, bias, nw, grid, s);
+}
+size_t CAT(smem_fwd_d, FAT5_INST_D)(int nw, int R, int bias) {
+  return nw == 2 ? FwdCfg<FAT5_INST_D, 2>::smem(R, bias) : FwdCfg<FAT5_INST_D, 4>::smem(R, bias);
+}
+
+}  // namespace fat5

@@ -1,0 +1,19 @@
+// Host-visible launchers of the templated attention kernels (one translation unit per head_dim).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "attn_common.h"
+
+namespace fat5 {
+// each returns hipError_t of the launch; nw in {2,4}
+#define FAT5_DECL_LAUNCH(D)                                                                           \
+  hipError_t launch_fwd_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
+  hipError_t launch_bwd_q_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
+  hipError_t launch_bwd_kv_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
+  size_t smem_fwd_d##D(int nw, int R, int bias);                                                      \
+  size_t smem_bwd_q_d##D(int nw, int R, int bias);                                                    \
+  size_t smem_bwd_kv_d##D(int nw, int R, int bias);
+FAT5_DECL_LAUNCH(32)
+FAT5_DECL_LAUNCH(64)
+FAT5_DECL_LAUNCH(128)
+#undef FAT5_DECL_LAUNCH
+}  // namespace fat5

@@ -1,0 +1,390 @@
+// libfat5.so -- C ABI over the gfx950 kernels (see include/fat5.h for the contract).
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/fat5.h"
+#include "attn_common.h"
+#include "attn_launch.h"
+#include "reduce_kernels.h"
+#include "rowwise_kernels.h"
+
+using namespace fat5;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(FAT5_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+struct BwdLayout {
+  size_t delta_off, ds_off, drpe_off, total;
+  bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
+  int n_nblk;
+  int nw_q, nw_kv;
+};
+
+int pick_nw(long ctas_at_nw4, const char* env) {
+  const int forced = env_int(env, 0);
+  if (forced == 2 || forced == 4) return forced;
+  // below ~1.5 workgroups per CU a 4-wave tile leaves CUs idle: halve the tile
+  return ctas_at_nw4 < 384 ? 2 : 4;
+}
+
+int check_common(const fat5_attn_params* p) {
+  if (!p) return fail(FAT5_EINVAL, "params is NULL");
+  if (p->D != 32 && p->D != 64 && p->D != 128) return fail(FAT5_EINVAL, "head_dim %d unsupported (32, 64, 128; pad 16 to 32)", p->D);
+  if (p->dtype != FAT5_F16 && p->dtype != FAT5_BF16) return fail(FAT5_EINVAL, "dtype %d unsupported (f16, bf16)", p->dtype);
+  if (p->B <= 0 || p->H <= 0 || p->M <= 0 || p->N <= 0) return fail(FAT5_EINVAL, "empty problem B=%d H=%d M=%d N=%d", p->B, p->H, p->M, p->N);
+  if (p->bias_mode < 0 || p->bias_mode > 2) return fail(FAT5_EINVAL, "bias_mode %d", p->bias_mode);
+  if (p->bias_mode == FAT5_BIAS_DENSE && !p->bias) return fail(FAT5_EINVAL, "dense bias mode without bias pointer");
+  if (p->bias_mode == FAT5_BIAS_RPE1D) {
+    if (!p->rpe1d) return fail(FAT5_EINVAL, "rpe1d mode without table");
+    if (p->rpe_radius < 1 || p->rpe_radius > 2048) return fail(FAT5_EINVAL, "rpe_radius %d out of range [1, 2048]", p->rpe_radius);
+    if (p->cu_seqlens_q) return fail(FAT5_EINVAL, "rpe1d + varlen unsupported");
+  }
+  return FAT5_OK;
+}
+
+bool strides_ok(const void* ptr, const int64_t* s) {
+  return aligned16(ptr) && (s[0] % 8 == 0) && (s[1] % 8 == 0) && (s[2] % 8 == 0);
+}
+
+void fill_common(const fat5_attn_params* p, AttnArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.q = (const uint16_t*)p->q; a.k = (const uint16_t*)p->k; a.v = (const uint16_t*)p->v;
+  a.o = (uint16_t*)p->o; a.lse = p->lse;
+  for (int i = 0; i < 3; ++i) {
+    a.qs[i] = p->q_stride[i]; a.ks[i] = p->k_stride[i]; a.vs[i] = p->v_stride[i]; a.os[i] = p->o_stride[i];
+    a.bs[i] = p->bias_stride[i];
+  }
+  a.B = p->B; a.H = p->H; a.M = p->M; a.N = p->N;
+  a.causal = p->causal; a.scale = p->sm_scale; a.R = p->rpe_radius;
+  a.bias = (const uint16_t*)p->bias; a.rpe1d = p->rpe1d;
+  a.cu_q = p->cu_seqlens_q; a.cu_k = p->cu_seqlens_k;
+  a.total_q = p->total_q; a.total_k = p->total_k;
+  if (p->bias_mode == FAT5_BIAS_DENSE) {
+    a.bias_vec4 = ((reinterpret_cast<uintptr_t>(p->bias) & 7) == 0) && (p->bias_stride[0] % 4 == 0) &&
+                  (p->bias_stride[1] % 4 == 0) && (p->bias_stride[2] % 4 == 0);
+  }
+}
+
+typedef hipError_t (*launch_fn)(const AttnArgs&, int, int, int, int, hipStream_t);
+
+template <int V>
+using IC = std::integral_constant<int, V>;
+template <typename F>
+void dispatch_dtype(int dt, F&& f) {
+  switch (dt) {
+    case FAT5_F32: f(IC<FAT5_F32>{}); break;
+    case FAT5_F16: f(IC<FAT5_F16>{}); break;
+    default: f(IC<FAT5_BF16>{}); break;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fat5_version(void) { return FAT5_VERSION; }
+const char* fat5_last_error(void) { return g_err; }
+size_t fat5_sizeof_attn_params(void) { return sizeof(fat5_attn_params); }
+
+int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
+  int rc = check_common(p);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!p->q || !p->k || !p->v || !p->o || !p->lse) return fail(FAT5_EINVAL, "fwd: null tensor pointer");
+  if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||
+      !strides_ok(p->o, p->o_stride))
+    return fail(FAT5_EINVAL, "fwd: q/k/v/o must be 16-byte aligned with strides that are multiples of 8 elements");
+  if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
+  if (p->cu_seqlens_q && p->bias_mode != FAT5_BIAS_NONE) return fail(FAT5_EINVAL, "varlen supports bias_mode none only");
+
+  AttnArgs a;
+  fill_common(p, a);
+  const long bh = (long)p->B * p->H;
+  const int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW");
+  a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
+  const long grid = bh * a.n_mblk;
+  if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
+  launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
+  hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
+  if (e != hipSuccess) return hip_fail(e, "attn_fwd launch");
+  return FAT5_OK;
+}
+
+static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
+  const long bh = (long)p->B * p->H;
+  L.nw_q = pick_nw(bh * ((p->M + 127) / 128), "FAT5_BWDQ_NW");
+  L.nw_kv = pick_nw(bh * ((p->N + 127) / 128), "FAT5_BWDKV_NW");
+  L.n_nblk = (p->N + 32 * L.nw_kv - 1) / (32 * L.nw_kv);
+  size_t off = 0;
+  L.delta_off = off;
+  off = align_up(off + (size_t)bh * p->M * sizeof(float), 256);
+  L.ds_staged = false;
+  L.ds_off = off;
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
+    const bool reduced = (p->dbias_batch != p->B) || (p->dbias_heads != p->H);
+    if (reduced) {
+      L.ds_staged = true;
+      off = align_up(off + (size_t)bh * p->M * p->N * 2, 256);
+    }
+  }
+  L.drpe_off = off;
+  if (p->bias_mode == FAT5_BIAS_RPE1D && p->drpe1d)
+    off = align_up(off + (size_t)bh * L.n_nblk * (2 * p->rpe_radius + 1) * sizeof(float), 256);
+  L.total = off;
+  return FAT5_OK;
+}
+
+size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
+  if (check_common(p)) return 0;
+  BwdLayout L;
+  bwd_layout(p, L);
+  return L.total;
+}
+
+int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) {
+  int rc = check_common(p);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (p->cu_seqlens_q) return fail(FAT5_EINVAL, "bwd: varlen not supported yet");
+  if (!p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv)
+    return fail(FAT5_EINVAL, "bwd: null tensor pointer");
+  if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||
+      !strides_ok(p->o, p->o_stride) || !strides_ok(p->dout, p->do_stride) || !strides_ok(p->dq, p->dq_stride) ||
+      !strides_ok(p->dk, p->dk_stride) || !strides_ok(p->dv, p->dv_stride))
+    return fail(FAT5_EINVAL, "bwd: tensors must be 16-byte aligned with strides that are multiples of 8 elements");
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
+    if (!((p->dbias_batch == 1 || p->dbias_batch == p->B) && (p->dbias_heads == 1 || p->dbias_heads == p->H)))
+      return fail(FAT5_EINVAL, "bwd: dbias batch/heads (%d,%d) must be 1 or (B,H)", p->dbias_batch, p->dbias_heads);
+    if (!aligned16(p->dbias)) return fail(FAT5_EINVAL, "bwd: dbias must be 16-byte aligned");
+  }
+  BwdLayout L;
+  bwd_layout(p, L);
+  if (L.total > 0 && (!p->workspace || p->workspace_bytes < L.total))
+    return fail(FAT5_EWORKSPACE, "bwd: workspace of %zu bytes required, got %zu", L.total, p->workspace_bytes);
+  if ((reinterpret_cast<uintptr_t>(p->workspace) & 255) != 0) return fail(FAT5_EINVAL, "bwd: workspace must be 256-byte aligned");
+  char* ws = (char*)p->workspace;
+
+  AttnArgs a;
+  fill_common(p, a);
+  a.dout = (const uint16_t*)p->dout; a.dq = (uint16_t*)p->dq; a.dk = (uint16_t*)p->dk; a.dv = (uint16_t*)p->dv;
+  for (int i = 0; i < 3; ++i) {
+    a.dos[i] = p->do_stride[i]; a.dqs[i] = p->dq_stride[i]; a.dks[i] = p->dk_stride[i]; a.dvs[i] = p->dv_stride[i];
+  }
+  a.delta = (float*)(ws + L.delta_off);
+  const int64_t MN = (int64_t)p->M * p->N;
+  const long bh = (long)p->B * p->H;
+  const bool bf16 = p->dtype == FAT5_BF16;
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
+    if (L.ds_staged) {
+      a.ds_out = (uint16_t*)(ws + L.ds_off);
+    } else {
+      a.ds_out = (uint16_t*)p->dbias;
+    }
+    a.dss[0] = (int64_t)p->H * MN; a.dss[1] = MN; a.dss[2] = p->N;
+    if (p->causal) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
+      hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
+      if (e != hipSuccess) return hip_fail(e, "memset ds");
+    }
+  }
+  if (p->bias_mode == FAT5_BIAS_RPE1D && p->drpe1d) a.drpe_part = (float*)(ws + L.drpe_off);
+
+  // 1) dQ (+ delta)
+  a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
+  a.n_nblk = L.n_nblk;
+  {
+    launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
+    hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)(bh * a.n_mblk), stream);
+    if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
+  }
+  // 2) dK, dV, dBias
+  {
+    launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
+    hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)(bh * a.n_nblk), stream);
+    if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
+  }
+  // 3) reductions over the broadcast dims
+  if (L.ds_staged) {
+    const int64_t chunks = (MN + 7) / 8 * p->dbias_batch * p->dbias_heads;
+    const int grid = (int)((chunks + 255) / 256);
+    if (bf16)
+      hipLaunchKernelGGL(dbias_reduce_kernel<true>, dim3(grid), dim3(256), 0, stream, a.ds_out, (uint16_t*)p->dbias, p->B,
+                         p->H, p->dbias_batch, p->dbias_heads, MN);
+    else
+      hipLaunchKernelGGL(dbias_reduce_kernel<false>, dim3(grid), dim3(256), 0, stream, a.ds_out, (uint16_t*)p->dbias, p->B,
+                         p->H, p->dbias_batch, p->dbias_heads, MN);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "dbias_reduce launch");
+  }
+  if (a.drpe_part) {
+    const int n1 = 2 * p->rpe_radius + 1;
+    const int grid = (p->H * n1 + 255) / 256;
+    hipLaunchKernelGGL(drpe_reduce_kernel, dim3(grid), dim3(256), 0, stream, a.drpe_part, p->drpe1d, p->B, p->H, a.n_nblk, n1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
+  }
+  return FAT5_OK;
+}
+
+// ============================================================================================
+// RMSNorm
+// ============================================================================================
+#define RMS_DISPATCH(...)                                  \
+  dispatch_dtype(x_dtype, [&](auto xt_) {                  \
+    dispatch_dtype(w_dtype, [&](auto wt_) {                \
+      constexpr int XDT = decltype(xt_)::value;            \
+      constexpr int WDT = decltype(wt_)::value;            \
+      __VA_ARGS__                                          \
+    });                                                    \
+  });
+
+static int dtype_ok(int d) { return d == FAT5_F32 || d == FAT5_F16 || d == FAT5_BF16; }
+static int vec_of(int d) { return d == FAT5_F32 ? 4 : 8; }
+
+int fat5_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t n, int64_t xs,
+                     int64_t ys, float eps, int x_dtype, int w_dtype, void* stream_) {
+  if (!x || !w || !y || !rstd) return fail(FAT5_EINVAL, "rmsnorm_fwd: null pointer");
+  if (!dtype_ok(x_dtype) || !dtype_ok(w_dtype)) return fail(FAT5_EINVAL, "rmsnorm_fwd: bad dtype");
+  if (rows <= 0 || n <= 0 || n > (1 << 24)) return fail(FAT5_EINVAL, "rmsnorm_fwd: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int vx = vec_of(x_dtype);
+  const bool vecok = (n % vx == 0) && (xs % vx == 0) && (ys % vx == 0) && aligned16(x) && aligned16(y) && aligned16(w) &&
+                     (n % 8 == 0);
+  const int grid = (int)((rows + 3) / 4);
+  RMS_DISPATCH({
+    if (vecok)
+      hipLaunchKernelGGL((rmsnorm_fwd_kernel<XDT, WDT, true>), dim3(grid), dim3(256), 0, stream, x, w, y, rstd, rows, (int)n, xs, ys, eps);
+    else
+      hipLaunchKernelGGL((rmsnorm_fwd_kernel<XDT, WDT, false>), dim3(grid), dim3(256), 0, stream, x, w, y, rstd, rows, (int)n, xs, ys, eps);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rmsnorm_fwd launch");
+  return FAT5_OK;
+}
+
+static int rms_bwd_blocks(int64_t rows) {
+  int64_t b = (rows + 7) / 8;
+  return (int)(b < 256 ? b : 256);
+}
+size_t fat5_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t n) {
+  return (size_t)rms_bwd_blocks(rows) * (size_t)n * sizeof(float);
+}
+
+int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw, int64_t rows,
+                     int64_t n, int64_t dys, int64_t xs, int64_t dxs, int x_dtype, int w_dtype, void* workspace,
+                     size_t workspace_bytes, void* stream_) {
+  if (!dy || !x || !w || !rstd || !dx || !dw) return fail(FAT5_EINVAL, "rmsnorm_bwd: null pointer");
+  if (!dtype_ok(x_dtype) || !dtype_ok(w_dtype)) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad dtype");
+  if (rows <= 0 || n <= 0) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad shape");
+  const int vx = vec_of(x_dtype);
+  if ((n % 8) || (xs % vx) || (dys % vx) || (dxs % vx) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(w))
+    return fail(FAT5_EINVAL, "rmsnorm_bwd: n must be a multiple of 8 and rows 16-byte aligned");
+  if (n > 16 * 64 * vx) return fail(FAT5_EINVAL, "rmsnorm_bwd: n = %lld exceeds %d", (long long)n, 16 * 64 * vx);
+  const size_t need = fat5_rmsnorm_bwd_workspace_bytes(rows, n);
+  if (!workspace || workspace_bytes < need) return fail(FAT5_EWORKSPACE, "rmsnorm_bwd: workspace of %zu bytes required", need);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int blocks = rms_bwd_blocks(rows);
+  const int nch = (int)((n + 64 * vx - 1) / (64 * vx));
+  const size_t smem = (size_t)n * sizeof(float);
+  float* part = (float*)workspace;
+#define RMS_BWD_LAUNCH(NCH) \
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<XDT, WDT, NCH>), dim3(blocks), dim3(512), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs)
+  RMS_DISPATCH({
+    if (nch <= 2) RMS_BWD_LAUNCH(2);
+    else if (nch <= 4) RMS_BWD_LAUNCH(4);
+    else if (nch <= 8) RMS_BWD_LAUNCH(8);
+    else RMS_BWD_LAUNCH(16);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rmsnorm_bwd launch");
+  const int g2 = (int)((n + 255) / 256);
+  switch (w_dtype) {
+    case FAT5_F32: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F32>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
+    case FAT5_F16: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F16>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
+    default: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_BF16>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rmsnorm_dw_reduce launch");
+  return FAT5_OK;
+}
+
+// ============================================================================================
+// Cross-entropy
+// ============================================================================================
+#define CE_DISPATCH(...)                         \
+  dispatch_dtype(dtype, [&](auto dt_) {            \
+    constexpr int DT = decltype(dt_)::value;       \
+    __VA_ARGS__                                    \
+  });
+
+int fat5_ce_fwd(const void* logits, const int64_t* labels, float* losses, float* z_losses, float* lse, int64_t rows,
+                int64_t n_cols, int64_t row_stride, float smoothing, float logit_scale, float lse_square_scale,
+                int64_t ignore_index, int use_precomputed_lse, int dtype, void* stream_) {
+  if (!logits || !labels || !losses || !z_losses || !lse) return fail(FAT5_EINVAL, "ce_fwd: null pointer");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "ce_fwd: bad dtype");
+  if (rows <= 0 || n_cols <= 0 || n_cols > 0x7fffffffLL || rows > 0x7fffffffLL) return fail(FAT5_EINVAL, "ce_fwd: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int v = vec_of(dtype);
+  const bool vecok = (n_cols % v == 0) && (row_stride % v == 0) && aligned16(logits);
+  CE_DISPATCH({
+    if (vecok)
+      hipLaunchKernelGGL((ce_fwd_kernel<DT, true>), dim3((int)rows), dim3(256), 0, stream, logits, labels, losses, z_losses, lse,
+                         (int)n_cols, row_stride, smoothing, logit_scale, lse_square_scale, ignore_index, use_precomputed_lse);
+    else
+      hipLaunchKernelGGL((ce_fwd_kernel<DT, false>), dim3((int)rows), dim3(256), 0, stream, logits, labels, losses, z_losses, lse,
+                         (int)n_cols, row_stride, smoothing, logit_scale, lse_square_scale, ignore_index, use_precomputed_lse);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "ce_fwd launch");
+  return FAT5_OK;
+}
+
+int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, const float* lse, const int64_t* labels,
+                void* dlogits, int64_t rows, int64_t n_cols, int64_t row_stride, int64_t drow_stride, float smoothing,
+                float logit_scale, float lse_square_scale, int64_t ignore_index, int dtype, void* stream_) {
+  if (!dlosses || !logits || !lse || !labels || !dlogits) return fail(FAT5_EINVAL, "ce_bwd: null pointer");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "ce_bwd: bad dtype");
+  if (rows <= 0 || n_cols <= 0 || n_cols > 0x7fffffffLL || rows > 0x7fffffffLL) return fail(FAT5_EINVAL, "ce_bwd: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int v = vec_of(dtype);
+  const bool vecok = (n_cols % v == 0) && (row_stride % v == 0) && (drow_stride % v == 0) && aligned16(logits) && aligned16(dlogits);
+  const int per_block = 256 * v;
+  dim3 grid((unsigned)rows, (unsigned)((n_cols + per_block - 1) / per_block));
+  if (grid.y > 65535) return fail(FAT5_EINVAL, "ce_bwd: too many columns");
+  CE_DISPATCH({
+    if (vecok)
+      hipLaunchKernelGGL((ce_bwd_kernel<DT, true>), grid, dim3(256), 0, stream, dlosses, dloss_stride, logits, lse, labels, dlogits,
+                         (int)n_cols, row_stride, drow_stride, smoothing, logit_scale, lse_square_scale, ignore_index);
+    else
+      hipLaunchKernelGGL((ce_bwd_kernel<DT, false>), grid, dim3(256), 0, stream, dlosses, dloss_stride, logits, lse, labels, dlogits,
+                         (int)n_cols, row_stride, drow_stride, smoothing, logit_scale, lse_square_scale, ignore_index);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "ce_bwd launch");
+  return FAT5_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// Bandwidth-bound row-wise ops for gfx950: T5 RMSNorm and cross-entropy (+ label smoothing, z-loss).
+// No MFMA: coalesced 16-byte HBM accesses, wave-shuffle / LDS reductions, fp32 math.
+//
+// Replaces the reference Triton kernels
+//   _rmsnorm_fwd_kernel / _rmsnorm_bwd_kernel        (src/model/ops/rms_norm.py:25-131)
+//   cross_entropy_fwd_kernel / cross_entropy_bwd_kernel (src/model/ops/cross_entropy_loss.py:35-162)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "attn_common.h"
+
+namespace fat5 {
+
+// element traits: 16-byte vectors of VEC elements <-> fp32
+template <int DT>
+struct Elem;
+template <>
+struct Elem<FAT5_F32> {
+  typedef float T;
+  static constexpr int VEC = 4;
+  static FAT5_DEV void load(const T* p, float (&f)[VEC]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static FAT5_DEV void store(T* p, const float (&f)[VEC]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+  static FAT5_DEV float ld1(const T* p) { return *p; }
+  static FAT5_DEV void st1(T* p, float f) { *p = f; }
+};
+template <int DT>
+struct Elem16 {
+  typedef uint16_t T;
+  static constexpr bool BF = (DT == FAT5_BF16);
+  static constexpr int VEC = 8;
+  static FAT5_DEV void load(const T* p, float (&f)[VEC]) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = cvt_lo<BF>(v[j]);
+      f[2 * j + 1] = cvt_hi<BF>(v[j]);
+    }
+  }
+  static FAT5_DEV void store(T* p, const float (&f)[VEC]) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack2<BF>(f[2 * j], f[2 * j + 1]);
+    *reinterpret_cast<u32x4*>(p) = v;
+  }
+  static FAT5_DEV float ld1(const T* p) { return cvt16<BF>(*p); }
+  static FAT5_DEV void st1(T* p, float f) { *p = to16<BF>(f); }
+};
+template <>
+struct Elem<FAT5_F16> : Elem16<FAT5_F16> {};
+template <>
+struct Elem<FAT5_BF16> : Elem16<FAT5_BF16> {};
+
+FAT5_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+FAT5_DEV float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// load VEC weights starting at column c (w may have a different dtype than x)
+template <int WDT, int VEC>
+FAT5_DEV void load_w(const void* w, int64_t c, float (&f)[VEC]) {
+  typedef Elem<WDT> W;
+  const typename W::T* wp = reinterpret_cast<const typename W::T*>(w) + c;
+  if constexpr (W::VEC == VEC) {
+    W::load(wp, f);
+  } else if constexpr (W::VEC * 2 == VEC) {  // fp32 weights, 16-bit activations
+    float a[W::VEC], b[W::VEC];
+    W::load(wp, a);
+    W::load(wp + W::VEC, b);
+#pragma unroll
+    for (int j = 0; j < W::VEC; ++j) { f[j] = a[j]; f[W::VEC + j] = b[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = W::ld1(wp + j);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm forward: one wave per row, 16-byte accesses; x is re-read from L1 in the second pass.
+// ---------------------------------------------------------------------------------------------
+template <int XDT, int WDT, bool VECOK>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_,
+                                                          void* __restrict__ y_, float* __restrict__ rstd,
+                                                          int64_t rows, int n, int64_t xs, int64_t ys, float eps) {
+  typedef Elem<XDT> X;
+  constexpr int VEC = X::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+  typename X::T* y = reinterpret_cast<typename X::T*>(y_) + row * ys;
+  float ss = 0.f;
+  if constexpr (VECOK) {
+    for (int c = lane * VEC; c < n; c += 64 * VEC) {
+      float f[VEC];
+      X::load(x + c, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      const float f = X::ld1(x + c);
+      ss = fmaf(f, f, ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)n + eps);  // rms_norm.py:49-50
+  if (lane == 0) rstd[row] = r;
+  if constexpr (VECOK) {
+    for (int c = lane * VEC; c < n; c += 64 * VEC) {
+      float f[VEC], wv[VEC];
+      X::load(x + c, f);
+      load_w<WDT, VEC>(w_, c, wv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = f[j] * r * wv[j];  // x_hat * w (:59-60)
+      X::store(y + c, f);
+    }
+  } else {
+    typedef Elem<WDT> W;
+    const typename W::T* w = reinterpret_cast<const typename W::T*>(w_);
+    for (int c = lane; c < n; c += 64) X::st1(y + c, X::ld1(x + c) * r * W::ld1(w + c));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm backward: persistent waves over strided rows; dw accumulated per lane in registers,
+// reduced across the workgroup's waves through LDS, one fp32 partial row per workgroup.
+//   NCH = max 16-byte chunks per lane (n <= NCH * 64 * VEC)
+// ---------------------------------------------------------------------------------------------
+template <int XDT, int WDT, int NCH>
+__global__ __launch_bounds__(512) void rmsnorm_bwd_kernel(const void* __restrict__ dy_, const void* __restrict__ x_,
+                                                          const void* __restrict__ w_, const float* __restrict__ rstd,
+                                                          void* __restrict__ dx_, float* __restrict__ dw_part,
+                                                          int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs) {
+  typedef Elem<XDT> X;
+  constexpr int VEC = X::VEC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sdw = reinterpret_cast<float*>(smem);  // [n]
+  const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int64_t wave_id = (int64_t)blockIdx.x * nwave + wv_;
+  const int64_t nwaves = (int64_t)gridDim.x * nwave;
+  float dw[NCH][VEC], wreg[NCH][VEC];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dw[i][j] = 0.f; wreg[i][j] = 0.f; }
+    if (c < n) load_w<WDT, VEC>(w_, c, wreg[i]);
+  }
+  const float inv_n = 1.0f / (float)n;
+  for (int64_t row = wave_id; row < rows; row += nwaves) {
+    const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+    const typename X::T* dy = reinterpret_cast<const typename X::T*>(dy_) + row * dys;
+    typename X::T* dx = reinterpret_cast<typename X::T*>(dx_) + row * dxs;
+    const float r = rstd[row];
+    float xh[NCH][VEC], wdy[NCH][VEC];
+    float c1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < n) {
+        float xf[VEC], dyf[VEC];
+        X::load(x + c, xf);
+        X::load(dy + c, dyf);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          xh[i][j] = xf[j] * r;                       // xhat (rms_norm.py:113)
+          wdy[i][j] = wreg[i][j] * dyf[j];            // :117
+          dw[i][j] = fmaf(dyf[j], xh[i][j], dw[i][j]);  // :119
+          c1 = fmaf(xh[i][j], wdy[i][j], c1);
+        }
+      }
+    }
+    c1 = wave_sum(c1) * inv_n;  // :121
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * VEC;
+      if (c < n) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = (wdy[i][j] - xh[i][j] * c1) * r;  // :122
+        X::store(dx + c, o);
+      }
+    }
+  }
+  // workgroup reduction of dw in wave order (deterministic)
+  for (int wsel = 0; wsel < nwave; ++wsel) {
+    if (wv_ == wsel) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) sdw[c + j] = (wsel == 0 ? 0.f : sdw[c + j]) + dw[i][j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = dw_part + (int64_t)blockIdx.x * n;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) out[c] = sdw[c];
+}
+
+// dw[c] = sum_p part[p][c]  -> weight dtype (rms_norm.py:234)
+template <int WDT>
+__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ part, void* __restrict__ dw_,
+                                                                int nparts, int n) {
+  typedef Elem<WDT> W;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * n + c];
+  W::st1(reinterpret_cast<typename W::T*>(dw_) + c, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-entropy forward: one 256-thread workgroup per row, online max / sum-exp per thread over
+// 16-byte chunks, then a workgroup combine.
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool VECOK>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const void* __restrict__ logits_, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ losses, float* __restrict__ z_losses,
+                                                     float* __restrict__ lse_, int n_cols, int64_t row_stride,
+                                                     float smoothing, float logit_scale, float lse_square_scale,
+                                                     int64_t ignore_index, int use_precomputed_lse) {
+  typedef Elem<DT> X;
+  constexpr int VEC = X::VEC;
+  __shared__ float sm[4], sl[4], ssum[4];
+  const int64_t row = blockIdx.x;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(logits_) + row * row_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wv_ = tid >> 6;
+  const bool has_smooth = smoothing > 0.f;
+  float lse;
+  float sum_logits = 0.f;
+  if (!use_precomputed_lse) {
+    float m = -INFINITY, l = 0.f;
+    if constexpr (VECOK) {
+      for (int c = tid * VEC; c < n_cols; c += 256 * VEC) {
+        float f[VEC];
+        X::load(x + c, f);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          f[j] *= logit_scale;
+          cm = fmaxf(cm, f[j]);
+          sum_logits += f[j];
+        }
+        const float mn = fmaxf(m, cm);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc += fast_exp2((f[j] - mn) * kLog2e);
+        l = l * fast_exp2((m - mn) * kLog2e) + acc;
+        m = mn;
+      }
+    } else {
+      for (int c = tid; c < n_cols; c += 256) {
+        const float f = X::ld1(x + c) * logit_scale;
+        sum_logits += f;
+        const float mn = fmaxf(m, f);
+        l = l * fast_exp2((m - mn) * kLog2e) + fast_exp2((f - mn) * kLog2e);
+        m = mn;
+      }
+    }
+    // combine (m, l) across the wave, then across the 4 waves
+    const float wm = wave_max(m);
+    l = (m == -INFINITY) ? 0.f : l * fast_exp2((m - wm) * kLog2e);
+    l = wave_sum(l);
+    sum_logits = wave_sum(sum_logits);
+    if (lane == 0) { sm[wv_] = wm; sl[wv_] = l; ssum[wv_] = sum_logits; }
+    __syncthreads();
+    const float gm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float gl = 0.f;
+    sum_logits = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gl += (sm[i] == -INFINITY) ? 0.f : sl[i] * fast_exp2((sm[i] - gm) * kLog2e);
+      sum_logits += ssum[i];
+    }
+    lse = logf(gl) + gm;  // cross_entropy_loss.py:78
+    if (tid == 0) lse_[row] = lse;
+  } else {
+    lse = lse_[row];
+  }
+  if (tid == 0) {
+    const int64_t label = labels[row];
+    float loss = 0.f, z = 0.f;
+    if (label != ignore_index) {  // :83-106 (single rank: class_start_idx = 0, total_classes = n_cols)
+      if (label >= 0 && label < n_cols) {
+        const float ll = X::ld1(x + label) * logit_scale;
+        loss = has_smooth ? (lse - smoothing * sum_logits / (float)n_cols - (1.f - smoothing) * ll) : (lse - ll);
+      } else {
+        loss = has_smooth ? smoothing * (lse - sum_logits / (float)n_cols) : 0.f;
+      }
+      z = lse_square_scale * lse * lse;
+      loss += z;
+    }
+    losses[row] = loss;
+    z_losses[row] = z;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-entropy backward: elementwise over (row, 2048-column block); may run in place.
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool VECOK>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ dlosses, int64_t dloss_stride,
+                                                     const void* logits_, const float* __restrict__ lse_,
+                                                     const int64_t* __restrict__ labels, void* dlogits_, int n_cols,
+                                                     int64_t row_stride, int64_t drow_stride, float smoothing,
+                                                     float logit_scale, float lse_square_scale, int64_t ignore_index) {
+  typedef Elem<DT> X;
+  constexpr int VEC = X::VEC;
+  const int64_t row = blockIdx.x;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(logits_) + row * row_stride;
+  typename X::T* dx = reinterpret_cast<typename X::T*>(dlogits_) + row * drow_stride;
+  const int64_t label = labels[row];
+  const float dloss = (label != ignore_index) ? dlosses[row * dloss_stride] : 0.f;  // :145-148
+  const float lse = lse_[row];
+  const float g = dloss * logit_scale;
+  const float zf = 1.f + 2.f * lse_square_scale * lse;  // probs += 2*zs*lse*probs (:153-154)
+  const bool has_smooth = smoothing > 0.f;
+  const float sp = 1.f - smoothing, sn = smoothing / (float)n_cols;
+  const float nl = -lse * kLog2e, ls2 = logit_scale * kLog2e;
+  const int c0 = blockIdx.y * (256 * VEC);
+  if constexpr (VECOK) {
+    const int c = c0 + threadIdx.x * VEC;
+    if (c < n_cols) {
+      float f[VEC];
+      X::load(x + c, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float p = fast_exp2(fmaf(f[j], ls2, nl)) * zf;
+        if (has_smooth) p = ((c + j == label) ? p - sp : p) - sn;  // :156-159
+        else p = (c + j == label) ? p - 1.f : p;                   // :161
+        f[j] = g * p;
+      }
+      X::store(dx + c, f);
+    }
+  } else {
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j * 256 + threadIdx.x;
+      if (c < n_cols) {
+        float p = fast_exp2(fmaf(X::ld1(x + c), ls2, nl)) * zf;
+        if (has_smooth) p = ((c == label) ? p - sp : p) - sn;
+        else p = (c == label) ? p - 1.f : p;
+        X::st1(dx + c, g * p);
+      }
+    }
+  }
+}
+
+}  // namespace fat5

@@ -1,0 +1,267 @@
+"""FlashAttention-2 with an additive (T5 relative-position) bias on MI355X.
+
+Host-side mirror of the reference operator file src/model/ops/flash_attention_v2_bias.py: the same
+public callable `flash_attention_v2_bias(q, k, v, bias, causal=False, sm_scale=None)` backed by the same
+`torch.autograd.Function` signature (`FlashAttentionAdditiveBias`, reference :228-271) and a pair of
+custom ops with fake impls (reference :27-89, :91-226) -- but the kernels are hand-written gfx950 HIP
+behind the C ABI of libfat5.so instead of Triton.
+
+Extra, linear-memory entry point: `flash_attention_v2_rpe(q, k, v, rpe_table, ...)` takes the
+`(num_buckets, H)` T5 table itself (what the reference's external `fa2_rpe` backend takes,
+modeling_flash_t5.py:275-279); neither the `(1,H,M,N)` bias nor its gradient is ever materialised.
+"""
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from . import positional_encoding as _pe
+
+__all__ = ["flash_attention_v2_bias", "FlashAttentionAdditiveBias", "flash_attention_v2_rpe",
+           "FlashAttentionRPE", "flash_attn_varlen_fwd"]
+
+
+def _prep(t):
+    return t if _lib.kernel_ready(t) else t.contiguous()
+
+
+def _bias_strides(bias, B, H):
+    # broadcast (1|B, 1|H, M, N) via zero strides (reference :45-52)
+    sb = bias.stride(0) if bias.shape[0] == B and B != 1 else (0 if bias.shape[0] == 1 else bias.stride(0))
+    sh = bias.stride(1) if bias.shape[1] == H and H != 1 else (0 if bias.shape[1] == 1 else bias.stride(1))
+    if bias.shape[0] == 1:
+        sb = 0
+    if bias.shape[1] == 1:
+        sh = 0
+    return _lib.c_i64x3(sb, sh, bias.stride(2))
+
+
+def _base_params(q, k, v, causal, sm_scale):
+    B, H, M, D = q.shape
+    N = k.shape[2]
+    p = _lib.AttnParams()
+    p.B, p.H, p.M, p.N, p.D = B, H, M, N, D
+    p.dtype = _lib.dtype_code(q.dtype)
+    p.causal = int(bool(causal))
+    p.sm_scale = float(sm_scale)
+    p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    p.q_stride, p.k_stride, p.v_stride = _lib.strides3(q), _lib.strides3(k), _lib.strides3(v)
+    return p
+
+
+def _check_inputs(q, k, v):
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flasht5_amd attention needs tensors on the HIP device (no CPU fallback)")
+    if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError("q, k, v must share dtype float16 or bfloat16")
+    if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+        raise ValueError("q, k, v must be (B, H, S, D)")
+
+
+def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
+    _check_inputs(q, k, v)
+    q, k, v = _prep(q), _prep(k), _prep(v)
+    B, H, M, D = q.shape
+    o = torch.empty_like(q)  # reference :58
+    if not _lib.kernel_ready(o):
+        o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    L = torch.empty((B, H, M), device=q.device, dtype=torch.float32)  # reference :59
+    p = _base_params(q, k, v, causal, sm_scale)
+    p.o, p.lse, p.o_stride = o.data_ptr(), L.data_ptr(), _lib.strides3(o)
+    if bias is not None:
+        if bias.dtype != q.dtype:
+            raise TypeError("bias must have the dtype of q")
+        if bias.stride(-1) != 1:
+            bias = bias.contiguous()
+        p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
+    elif rpe1d is not None:
+        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd")
+    return o, L
+
+
+def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbias):
+    q, k, v, o, do = _prep(q), _prep(k), _prep(v), _prep(o), _prep(do)
+    B, H, M, D = q.shape
+    N = k.shape[2]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)  # reference :140-141,:191
+    if not _lib.kernel_ready(dq):
+        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    if not _lib.kernel_ready(dk):
+        dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    if not _lib.kernel_ready(dv):
+        dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    p = _base_params(q, k, v, causal, sm_scale)
+    p.o, p.lse, p.o_stride = o.data_ptr(), L.data_ptr(), _lib.strides3(o)
+    p.dout, p.dq, p.dk, p.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    p.do_stride, p.dq_stride, p.dk_stride, p.dv_stride = (_lib.strides3(t) for t in (do, dq, dk, dv))
+    dbias = None
+    if bias is not None:
+        if bias.stride(-1) != 1:
+            bias = bias.contiguous()
+        p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
+        if need_dbias:
+            dbias = torch.empty(bias.shape, dtype=bias.dtype, device=bias.device)  # shape/dtype of bias (:149,:224)
+            p.dbias, p.dbias_batch, p.dbias_heads = dbias.data_ptr(), bias.shape[0], bias.shape[1]
+    elif rpe1d is not None:
+        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
+        if need_dbias:
+            dbias = torch.empty_like(rpe1d)
+            p.drpe1d = dbias.data_ptr()
+    lib = _lib.load()
+    nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd")
+    return dq, dk, dv, dbias
+
+
+# ------------------------------------------------------------------------------------------------
+# custom ops (own namespace; optionals declared `Tensor?` -- SURVEY Q8) with fake impls so that
+# FakeTensor / torch.compile tracing works like for the reference's flasht5::* ops.
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op("fat5::flash_attn_v2_fwd", mutates_args=(), device_types="cuda")
+def flash_attn_v2_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch.Tensor],
+                      causal: bool, sm_scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _attn_fwd(q, k, v, bias, None, 0, causal, sm_scale)
+
+
+@torch.library.register_fake("fat5::flash_attn_v2_fwd")
+def _flash_attn_v2_fwd_fake(q, k, v, bias, causal, sm_scale):
+    B, H, M, D = q.shape
+    return torch.empty_like(q), torch.empty((B, H, M), dtype=torch.float32, device=q.device)
+
+
+@torch.library.custom_op("fat5::flash_attn_v2_bwd", mutates_args=(), device_types="cuda")
+def flash_attn_v2_bwd(o: torch.Tensor, do: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                      bias: Optional[torch.Tensor], L: torch.Tensor, causal: bool, sm_scale: float
+                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    dq, dk, dv, ds = _attn_bwd(o, do, q, k, v, bias, None, 0, L, causal, sm_scale, bias is not None)
+    if ds is None:
+        ds = torch.empty(0, dtype=q.dtype, device=q.device)
+    return dq, dk, dv, ds
+
+
+@torch.library.register_fake("fat5::flash_attn_v2_bwd")
+def _flash_attn_v2_bwd_fake(o, do, q, k, v, bias, L, causal, sm_scale):
+    ds = torch.empty_like(bias) if bias is not None else torch.empty(0, dtype=q.dtype, device=q.device)
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), ds
+
+
+class FlashAttentionAdditiveBias(torch.autograd.Function):
+    """Same contract as the reference class (flash_attention_v2_bias.py:228-271)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, causal, sm_scale):
+        Dq, Dk, Dv = q.shape[-1], k.shape[-1], v.shape[-1]
+        assert Dq == Dk == Dv
+        assert Dk in {16, 32, 64, 128}
+        if sm_scale is None:
+            sm_scale = 1.0 / math.sqrt(Dq)
+        pad16 = Dk == 16
+        if pad16:  # the kernels' smallest head_dim is 32: zero-pad (scores and outputs unchanged)
+            q, k, v = (torch.nn.functional.pad(t, (0, 16)) for t in (q, k, v))
+        o, L = torch.ops.fat5.flash_attn_v2_fwd(q, k, v, bias, bool(causal), float(sm_scale))
+        ctx.save_for_backward(q, k, v, bias, o, L)
+        ctx.sm_scale = sm_scale
+        ctx.causal = causal
+        ctx.pad16 = pad16
+        return o[..., :16] if pad16 else o
+
+    @staticmethod
+    def backward(ctx, do, *ignored):
+        q, k, v, bias, o, L = ctx.saved_tensors
+        if ctx.pad16:
+            do = torch.nn.functional.pad(do, (0, 16))
+        dq, dk, dv, ds = torch.ops.fat5.flash_attn_v2_bwd(o, do, q, k, v, bias, L, bool(ctx.causal), float(ctx.sm_scale))
+        if ctx.pad16:
+            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
+        return dq, dk, dv, (ds if bias is not None else None), None, None, None, None
+
+
+def flash_attention_v2_bias(q, k, v, bias, causal=False, sm_scale=None):
+    """FlashAttention-2 forward/backward with additive bias (reference :274-288).
+
+    q: (B, H, M, D); k, v: (B, H, N, D) (strided views are fine); bias: (B|1, H|1, M, N) or None.
+    Differentiable in q, k, v and bias.  Returns o: (B, H, M, D)."""
+    return FlashAttentionAdditiveBias.apply(q, k, v, bias, causal, sm_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# linear-memory T5 RPE mode
+# ------------------------------------------------------------------------------------------------
+class FlashAttentionRPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale):
+        D = q.shape[-1]
+        assert D in {32, 64, 128}
+        if sm_scale is None:
+            sm_scale = 1.0 / math.sqrt(D)
+        R = _pe.rpe_radius(max_distance)
+        if R > _lib.MAX_RPE_RADIUS:
+            raise ValueError(f"max_distance {max_distance} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
+        if rpe_table.shape != (num_buckets, q.shape[1]):
+            raise ValueError("rpe_table must be (num_buckets, n_heads)")
+        idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, q.device)
+        rpe1d = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
+        o, L = _attn_fwd(q, k, v, None, rpe1d, R, causal, sm_scale)
+        ctx.save_for_backward(q, k, v, o, L, rpe1d, idx)
+        ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, L, rpe1d, idx = ctx.saved_tensors
+        R, causal, sm_scale, num_buckets, tdtype = ctx.meta
+        need = ctx.needs_input_grad[3]
+        dq, dk, dv, drpe1d = _attn_bwd(o, do, q, k, v, None, rpe1d, R, L, causal, sm_scale, need)
+        dtable = None
+        if need:  # scatter the (H, 2R+1) diagonal sums into the (num_buckets, H) table
+            dtable = torch.zeros(num_buckets, q.shape[1], dtype=torch.float32, device=q.device)
+            dtable.index_add_(0, idx, drpe1d.transpose(0, 1))
+            dtable = dtable.to(tdtype)
+        return dq, dk, dv, dtable, None, None, None, None, None
+
+
+def flash_attention_v2_rpe(q, k, v, rpe_table, bidirectional=True, num_buckets=32, max_distance=128,
+                           causal=False, sm_scale=None):
+    """Attention with the T5 relative-position bias generated in-kernel from the `(num_buckets, H)` table
+    (`RelativePositionalEncoding.relative_attention_bias.weight` of the reference).  Equivalent to
+    `flash_attention_v2_bias(q, k, v, compute_bias(table, M, N), ...)` with O(S) memory; differentiable in
+    q, k, v and the table."""
+    return FlashAttentionRPE.apply(q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# packed var-len forward (config 4: decoder cross-attention over cu_seqlens; forward only for now)
+# ------------------------------------------------------------------------------------------------
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None):
+    """q: (total_q, H, D); k, v: (total_k, H, D); cu_seqlens_*: int32 (nseq+1,) on device.
+    Returns o (total_q, H, D) and lse (H, total_q)."""
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise TypeError("q must be float16 or bfloat16")
+    q, k, v = (t if (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0)
+               else t.contiguous() for t in (q, k, v))
+    Tq, H, D = q.shape
+    Tk = k.shape[0]
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nseq = cu_seqlens_q.numel() - 1
+    o = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
+    p = _lib.AttnParams()
+    p.B, p.H, p.M, p.N, p.D = nseq, H, int(max_seqlen_q), int(max_seqlen_k), D
+    p.dtype, p.causal, p.sm_scale = _lib.dtype_code(q.dtype), int(bool(causal)), float(sm_scale)
+    p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+        setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
+    cq = cu_seqlens_q.to(torch.int32).contiguous()
+    ck = cu_seqlens_k.to(torch.int32).contiguous()
+    p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cq.data_ptr(), ck.data_ptr(), Tq, Tk
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
+    return o, lse

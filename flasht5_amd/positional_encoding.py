@@ -1,0 +1,70 @@
+"""T5 relative-position bias producers for the attention path.
+
+Mirrors `RelativePositionalEncoding` of the reference (src/utils/positional_encoding.py:11-110):
+same bucket formula, same dense `(1, H, M, N)` bias -- plus the linear-memory form consumed by the
+RPE mode of the kernels: the Toeplitz generator `rpe1d[h, clamp(n - m, -R, R) + R]`.
+"""
+import math
+from functools import lru_cache
+
+import torch
+
+
+def relative_position_bucket(relative_position, bidirectional=True, num_buckets=32, max_distance=128):
+    """Same arithmetic as the reference `_relative_position_bucket` (positional_encoding.py:25-71):
+    fp32 log ratio, truncation toward zero, clamp to the last bucket."""
+    relative_buckets = torch.zeros_like(relative_position)
+    if bidirectional:
+        num_buckets //= 2
+        relative_buckets = relative_buckets + (relative_position > 0).to(torch.long) * num_buckets
+        relative_position = torch.abs(relative_position)
+    else:
+        relative_position = -torch.min(relative_position, torch.zeros_like(relative_position))
+    max_exact = num_buckets // 2
+    is_small = relative_position < max_exact
+    safe = torch.clamp(relative_position, min=1).float()  # log(0) lanes are masked by is_small
+    large = max_exact + (
+        torch.log(safe / max_exact) / torch.log(torch.tensor(max_distance / max_exact)) * (num_buckets - max_exact)
+    ).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return relative_buckets + torch.where(is_small, relative_position, large)
+
+
+def compute_bias(table, query_length, key_length, bidirectional=True, num_buckets=32, max_distance=128):
+    """Dense bias `(1, H, M, N)` from the `(num_buckets, H)` table (positional_encoding.py:73-102)."""
+    device = table.device
+    ctx = torch.arange(query_length, dtype=torch.long, device=device)[:, None]
+    mem = torch.arange(key_length, dtype=torch.long, device=device)[None, :]
+    bucket = relative_position_bucket(mem - ctx, bidirectional, num_buckets, max_distance)
+    return table[bucket].permute(2, 0, 1).unsqueeze(0)
+
+
+@lru_cache(maxsize=64)
+def _bucket_index_cpu(radius, bidirectional, num_buckets, max_distance):
+    delta = torch.arange(-radius, radius + 1, dtype=torch.long)
+    return relative_position_bucket(delta, bidirectional, num_buckets, max_distance)
+
+
+_IDX_CACHE = {}
+
+
+def bucket_index(radius, bidirectional, num_buckets, max_distance, device):
+    """bucket id of every clamped relative position delta in [-R, R]; cached per device."""
+    key = (radius, bool(bidirectional), num_buckets, max_distance, str(device))
+    idx = _IDX_CACHE.get(key)
+    if idx is None:
+        idx = _bucket_index_cpu(radius, bool(bidirectional), num_buckets, max_distance).to(device)
+        _IDX_CACHE[key] = idx
+    return idx
+
+
+def rpe_radius(max_distance):
+    """Beyond |n - m| >= max_distance every relative position falls in the last bucket of its side."""
+    return int(max_distance)
+
+
+def rpe1d_from_table(table, bidirectional=True, num_buckets=32, max_distance=128):
+    """(num_buckets, H) table -> (H, 2R+1) fp32 generator with R = max_distance."""
+    R = rpe_radius(max_distance)
+    idx = bucket_index(R, bidirectional, num_buckets, max_distance, table.device)
+    return table.index_select(0, idx).transpose(0, 1).float().contiguous()

@@ -1,0 +1,145 @@
+/*
+ * fat5.h -- C ABI of libfat5.so: MI355X-native (gfx950) FlashAttention-2 with an additive
+ * T5 relative-position bias (forward + backward), T5 RMSNorm and cross-entropy + z-loss.
+ *
+ * Every entry point replaces one `flasht5::*` custom op of the reference (catie-aq/flashT5);
+ * the reference interface each one stands in for is cited next to it (paths relative to the
+ * reference tree).  The reference has no native code: its FFI for this path is the Python
+ * `torch.library.custom_op` layer, so the binding a maintainer would add is a ctypes stub
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / HIP C++ types (hipStream_t is passed as void*).
+ *  - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or
+ *    frees device memory and keeps no mutable global state.  All launches are asynchronous on
+ *    the given stream; the library never synchronises.
+ *  - return value: FAT5_OK (0) or a negative error; the message of the last error on the
+ *    calling thread is available from fat5_last_error().  Nothing throws across the ABI.
+ *  - strides are in ELEMENTS.  The innermost (head_dim / feature / vocab) stride must be 1.
+ */
+#ifndef FAT5_H
+#define FAT5_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAT5_VERSION 100 /* 0.1.0 */
+
+enum fat5_status {
+  FAT5_OK = 0,
+  FAT5_EINVAL = -1, /* unsupported head_dim / dtype / stride / alignment / shape */
+  FAT5_EHIP = -2,   /* a HIP runtime call failed (text in fat5_last_error) */
+  FAT5_EWORKSPACE = -3 /* workspace missing or too small */
+};
+
+enum fat5_dtype { FAT5_F16 = 1, FAT5_BF16 = 2, FAT5_F32 = 0 };
+
+enum fat5_bias_mode {
+  FAT5_BIAS_NONE = 0,  /* bias=None (reference HAS_BIAS=False, e.g. T5 cross-attention) */
+  FAT5_BIAS_DENSE = 1, /* additive bias (B|1, H|1, M, N), same dtype as q (reference path) */
+  FAT5_BIAS_RPE1D = 2  /* Toeplitz bias given by its clamped generator (H, 2R+1) fp32:
+                          bias[h][m][n] = rpe1d[h][clamp(n - m, -R, R) + R]  (linear memory) */
+};
+
+/*
+ * Attention problem descriptor, shared by forward and backward.
+ *
+ * Replaces: flasht5::flash_attn_v2_fwd  (src/model/ops/flash_attention_v2_bias.py:27-80)
+ *           flasht5::flash_attn_v2_bwd  (src/model/ops/flash_attention_v2_bias.py:91-217)
+ * Semantics: o = softmax(q k^T * sm_scale + bias [+ bottom-right causal mask]) v;
+ *            lse = natural-log LSE per row, fp32, (B,H,M) contiguous (:476,:59);
+ *            fully masked rows (causal and M > N) give o = 0, lse = -inf (:470-473).
+ *            dbias is the gradient of the UNSCALED additive term (dS), reduced over every
+ *            broadcast dimension of bias (mathematically correct also for (1,1,M,N): SURVEY Q4).
+ */
+typedef struct fat5_attn_params {
+  /* ---- problem ---- */
+  int32_t B, H, M, N, D; /* D in {32, 64, 128} (16: pad to 32 in the caller) */
+  int32_t dtype;         /* FAT5_F16 | FAT5_BF16 : dtype of q,k,v,o,do,dq,dk,dv and of dense bias */
+  int32_t causal;        /* bottom-right aligned: key n visible to query m iff m + (N-M) >= n */
+  int32_t bias_mode;     /* enum fat5_bias_mode */
+  float sm_scale;
+  int32_t rpe_radius;    /* R for FAT5_BIAS_RPE1D */
+  /* ---- forward tensors ---- */
+  const void* q; /* (B,H,M,D) strides q_stride[b,h,m] */
+  const void* k; /* (B,H,N,D) */
+  const void* v; /* (B,H,N,D) */
+  void* o;       /* (B,H,M,D) */
+  float* lse;    /* (B,H,M) contiguous fp32 */
+  int64_t q_stride[3], k_stride[3], v_stride[3], o_stride[3];
+  const void* bias;        /* DENSE: (Bb,Hb,M,N), Bb in {1,B}, Hb in {1,H}; n-stride 1 */
+  int64_t bias_stride[3];  /* [b,h,m]; 0 for a broadcast dimension */
+  const float* rpe1d;      /* RPE1D: (H, 2R+1) fp32 contiguous */
+  /* ---- packed var-len (optional; reference has none -- SURVEY 8(f) n2) ----
+   * when cu_seqlens_q != NULL: B = number of sequences, q/o are (total_q, H, D) addressed as
+   * base + (cu_seqlens_q[b] + m) * stride[2] + h * stride[1] (stride[0] ignored), k/v likewise
+   * with cu_seqlens_k; M/N are the MAXIMUM lengths; lse is (H, total_q). */
+  const int32_t* cu_seqlens_q;
+  const int32_t* cu_seqlens_k;
+  int32_t total_q, total_k;
+  /* ---- backward tensors (ignored by fat5_attn_fwd) ---- */
+  const void* dout; /* (B,H,M,D) */
+  void* dq;         /* (B,H,M,D) */
+  void* dk;         /* (B,H,N,D) */
+  void* dv;         /* (B,H,N,D) */
+  int64_t do_stride[3], dq_stride[3], dk_stride[3], dv_stride[3];
+  void* dbias;              /* DENSE: same shape/dtype as bias, contiguous; may be NULL */
+  int32_t dbias_batch, dbias_heads; /* Bb, Hb of bias/dbias */
+  float* drpe1d;            /* RPE1D: (H, 2R+1) fp32, overwritten; may be NULL */
+  void* workspace;          /* size from fat5_attn_bwd_workspace_bytes(); 256-B aligned */
+  size_t workspace_bytes;
+} fat5_attn_params;
+
+int fat5_version(void);
+const char* fat5_last_error(void);
+/* sizeof(fat5_attn_params) as compiled into the library (bindings check their mirror against it). */
+size_t fat5_sizeof_attn_params(void);
+
+/* forward: writes o, lse. */
+int fat5_attn_fwd(const fat5_attn_params* p, void* hip_stream);
+/* bytes of scratch the backward needs for this problem (delta, dS staging, partial sums). */
+size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p);
+/* backward: reads q,k,v,o,lse,dout(,bias|rpe1d); writes dq,dk,dv(,dbias|drpe1d). */
+int fat5_attn_bwd(const fat5_attn_params* p, void* hip_stream);
+
+/*
+ * T5 RMSNorm.  Replaces flasht5::rmsnorm_triton_fwd / _bwd (src/model/ops/rms_norm.py:134-236).
+ *   y = x * rsqrt(mean(x^2) + eps) * w   (fp32 math, y in x's dtype);  rstd (rows,) fp32.
+ *   dx = (w*dy - xhat*mean(xhat*w*dy)) * rstd;  dw = sum_rows(dy * xhat)  (fp32 partials, cast to w dtype)
+ * x_dtype / w_dtype in {FAT5_F32, FAT5_F16, FAT5_BF16}; dy has x's dtype.
+ */
+int fat5_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t n,
+                     int64_t x_row_stride, int64_t y_row_stride, float eps, int x_dtype, int w_dtype,
+                     void* hip_stream);
+size_t fat5_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t n);
+int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw,
+                     int64_t rows, int64_t n, int64_t dy_row_stride, int64_t x_row_stride,
+                     int64_t dx_row_stride, int x_dtype, int w_dtype, void* workspace,
+                     size_t workspace_bytes, void* hip_stream);
+
+/*
+ * Cross-entropy + label smoothing + z-loss.  Replaces flasht5::cross_entropy_triton_fwd / _bwd
+ * (src/model/ops/cross_entropy_loss.py:164-274), single-rank path (SPLIT = False).
+ *   lse = log sum exp(logits*logit_scale);  loss = lse - logit[label]  (smoothed variant :90-95)
+ *   z_loss = lse_square_scale * lse^2 (added to loss); rows with label == ignore_index give 0.
+ *   dlogits = dloss*logit_scale*(softmax*(1 + 2*lse_square_scale*lse) - onehot/smoothing terms);
+ *   dlogits may alias logits (in-place backward, :247).
+ * labels are int64.
+ */
+int fat5_ce_fwd(const void* logits, const int64_t* labels, float* losses, float* z_losses, float* lse,
+                int64_t rows, int64_t n_cols, int64_t row_stride, float smoothing, float logit_scale,
+                float lse_square_scale, int64_t ignore_index, int use_precomputed_lse, int dtype,
+                void* hip_stream);
+int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, const float* lse,
+                const int64_t* labels, void* dlogits, int64_t rows, int64_t n_cols,
+                int64_t row_stride, int64_t dlogits_row_stride, float smoothing, float logit_scale,
+                float lse_square_scale, int64_t ignore_index, int dtype, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAT5_H */

@@ -1,0 +1,154 @@
+"""Developer sweep on the GPU box: correctness table + timings for the attention kernels.
+
+    python tools/devcheck.py [--quick] [--no-time]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+import oracle  # noqa: E402
+from attn_helpers import make_inputs, oracle_all, run_dense, errors, maxdiff  # noqa: E402
+import flasht5_amd  # noqa: E402
+from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe  # noqa: E402
+from flasht5_amd import positional_encoding as pe  # noqa: E402
+
+
+def fmt(d):
+    return " ".join(f"{k}={v:.2e}" for k, v in d.items())
+
+
+def check_dense(B, H, M, N, D, dtype, bias_kind, causal, scale=1.0, strided=False):
+    q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, bias_kind, seed=M * 7 + N, strided=strided)
+    ref = oracle_all(q, k, v, b, do, scale, causal)
+    try:
+        got = run_dense(q, k, v, b, do, scale, causal)
+    except Exception as e:  # noqa: BLE001
+        print(f"  dense B{B} H{H} M{M} N{N} D{D} {str(dtype)[6:]} bias={bias_kind} causal={int(causal)}: EXC {e}")
+        return
+    e = errors(got, ref)
+    nan = any(not torch.isfinite(t.float()).all().item() for t in got.values())
+    rel = {key: val / max(1.0, ref[key].abs().max().item()) for key, val in e.items()}
+    flag = "OK " if max(rel.values()) < 1.2e-2 and not nan else "BAD"
+    print(f"  {flag} dense B{B} H{H} M{M} N{N} D{D} {str(dtype)[6:]} bias={bias_kind} c={int(causal)} st={int(strided)}: {fmt(e)}{' NAN' if nan else ''}")
+
+
+def check_rpe(B, H, M, N, D, dtype, causal, bidir=True, scale=1.0, max_distance=128):
+    q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=M + 3 * N)
+    g = torch.Generator().manual_seed(5)
+    table = (torch.randn(32, H, generator=g) * 0.5).cuda()
+    bias = pe.compute_bias(table, M, N, bidir, 32, max_distance).contiguous()  # fp32 (1,H,M,N)
+    ref = oracle_all(q, k, v, bias, do, scale, causal)
+    # table gradient through the dense oracle path
+    tl = table.clone().requires_grad_()
+    pe.compute_bias(tl, M, N, bidir, 32, max_distance).backward(ref["db"])
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    tb = table.clone().requires_grad_()
+    try:
+        o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, max_distance, causal, scale)
+        grads = torch.autograd.grad(o, leaves + [tb], do)
+    except Exception as e:  # noqa: BLE001
+        print(f"  rpe B{B} H{H} M{M} N{N} D{D}: EXC {e}")
+        return
+    e = {"o": maxdiff(o, ref["o"]), "dq": maxdiff(grads[0], ref["dq"]), "dk": maxdiff(grads[1], ref["dk"]),
+         "dv": maxdiff(grads[2], ref["dv"]), "dtab": maxdiff(grads[3], tl.grad)}
+    scl = {"o": ref["o"], "dq": ref["dq"], "dk": ref["dk"], "dv": ref["dv"], "dtab": tl.grad}
+    rel = {key: val / max(1.0, scl[key].abs().max().item()) for key, val in e.items()}
+    flag = "OK " if max(rel.values()) < 1.2e-2 else "BAD"
+    print(f"  {flag} rpe   B{B} H{H} M{M} N{N} D{D} {str(dtype)[6:]} c={int(causal)} bidir={int(bidir)}: {fmt(e)} (|dtab|max {tl.grad.abs().max().item():.1f})")
+
+
+def time_fn(fn, warmup=5, iters=20):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters  # ms
+
+
+def timing(B, H, S, D, mode, dtype=torch.bfloat16, causal=False):
+    from flasht5_amd import flash_attention_v2_bias as fa
+    from flasht5_amd.flash_attention_v2_bias import _attn_fwd, _attn_bwd
+    q, k, v, _, do = make_inputs(B, H, S, S, D, dtype, None, seed=1, strided=True)
+    scale = 0.125
+    table = (torch.randn(32, H) * 0.5).cuda()
+    bias = rpe1d = None
+    R = 0
+    if mode == "dense":
+        bias = pe.compute_bias(table, S, S).to(dtype).contiguous()
+    elif mode == "rpe":
+        rpe1d = pe.rpe1d_from_table(table)
+        R = 128
+    o, L = _attn_fwd(q, k, v, bias, rpe1d, R, causal, scale)
+    t_f = time_fn(lambda: _attn_fwd(q, k, v, bias, rpe1d, R, causal, scale))
+    t_b = time_fn(lambda: _attn_bwd(o, do, q, k, v, bias, rpe1d, R, L, causal, scale, mode != "none"))
+    fl = 4.0 * B * H * S * S * D / (2 if causal else 1)
+    print(f"  time B{B} H{H} S{S} D{D} {mode:5s} c={int(causal)}: fwd {t_f*1e3:8.1f} us = {fl/t_f/1e9:7.1f} TF/s | "
+          f"bwd {t_b*1e3:8.1f} us = {2.5*fl/t_b/1e9:7.1f} TF/s | fwd+bwd {3.5*fl/(t_f+t_b)/1e9:7.1f} TF/s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--no-time", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    print("device:", torch.cuda.get_device_name(0), "fat5", flasht5_amd.__version__, flush=True)
+    bf, fp = torch.bfloat16, torch.float16
+    if not args.no_check:
+        print("== correctness (max abs err vs fp32 oracle) ==")
+        check_dense(1, 1, 32, 64, 64, bf, None, False)
+        check_dense(1, 1, 64, 64, 64, bf, None, False)
+        check_dense(1, 2, 128, 128, 64, bf, None, False)
+        check_dense(2, 2, 128, 128, 64, bf, "1h", False)
+        check_dense(2, 2, 128, 164, 64, bf, "1h", False)
+        check_dense(2, 2, 128, 164, 64, fp, "bh", True)
+        check_dense(2, 2, 96, 64, 64, bf, "bh", True)
+        check_dense(2, 3, 64, 96, 64, bf, "11", False)
+        check_dense(2, 3, 100, 77, 64, bf, "b1", False)
+        check_dense(1, 2, 80, 80, 64, bf, None, True, scale=0.125)
+        check_dense(2, 4, 256, 300, 64, bf, "1h", True, strided=True)
+        check_dense(1, 2, 64, 100, 128, bf, "1h", False)
+        check_dense(1, 2, 72, 72, 32, fp, "1h", True)
+        check_dense(1, 2, 72, 72, 16, fp, "1h", True)
+        if not args.quick:
+            check_dense(2, 4, 512, 612, 128, bf, "bh", True)
+            check_dense(2, 4, 1024, 1045, 64, bf, "bh", False)
+            check_dense(2, 4, 1024, 1045, 64, fp, "11", True)
+            check_dense(4, 12, 512, 512, 64, bf, "1h", False, strided=True)
+        check_rpe(1, 2, 128, 128, 64, bf, False)
+        check_rpe(2, 2, 256, 256, 64, bf, False)
+        check_rpe(2, 2, 96, 160, 64, bf, False)
+        check_rpe(2, 2, 128, 128, 64, bf, True, bidir=False)
+        check_rpe(1, 2, 512, 512, 64, bf, False)
+        check_rpe(2, 2, 300, 200, 64, fp, False, max_distance=64)
+        if not args.quick:
+            check_rpe(4, 12, 512, 512, 64, bf, False)
+            check_rpe(1, 4, 2048, 2048, 64, bf, False)
+    if not args.no_time:
+        print("== timing ==")
+        for S in (512, 2048, 8192):
+            for mode in ("none", "rpe", "dense"):
+                if mode == "dense" and S == 8192 and args.quick:
+                    continue
+                timing(4, 12, S, 64, mode)
+        timing(4, 12, 2048, 64, "rpe", causal=True)
+        timing(16, 12, 1024, 64, "dense", causal=True)
+        timing(4, 12, 2048, 128, "none")
+
+
+if __name__ == "__main__":
+    main()
