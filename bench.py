@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Headline benchmark: FA2 + T5-bias forward+backward TFLOP/s (bf16, d_head = 64).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--seq 512] [--mode rpe|dense|none]
+
+A step = one forward + one backward of the attention hot path over one synthetic batch
+(B,H,S,D) = (4,12,S,64), bias = 32-bucket T5 relative-position bias, inputs resident in HBM, every kernel
+launched through the C ABI of libfat5.so and replayed from a HIP graph.  At N > 1 every rank owns its own
+batch (weak scaling, data parallel) and the step ends with ONE all-reduce (RCCL) of the bias-table gradient.
+Prints ONE JSON line on rank 0 (see the repo task contract); extra keys: by_seq, kernels, roofline, cpu_baseline.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+B, H, D = 4, 12, 64
+NUM_BUCKETS, MAX_DISTANCE = 32, 128
+
+
+def fwd_flops(S, causal=False):
+    return 4.0 * B * H * S * S * D / (2 if causal else 1)  # reference benchmarks/bench_fa2_bias.py:10-13
+
+
+def make_plan(S, mode, device, seed):
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    g = torch.Generator().manual_seed(seed)
+    # the model's real layout: (B,S,H,D) storage viewed as (B,H,S,D)
+    mk = lambda: torch.randn(B, S, H, D, generator=g).to(torch.bfloat16).to(device).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v, do = mk(), mk(), mk(), mk()
+    table = (torch.randn(NUM_BUCKETS, H, generator=g) * 0.5).to(device)
+    kw = {}
+    if mode == "rpe":
+        kw = dict(rpe1d=pe.rpe1d_from_table(table, True, NUM_BUCKETS, MAX_DISTANCE), radius=MAX_DISTANCE)
+    elif mode == "dense":
+        kw = dict(bias=pe.compute_bias(table, S, S, True, NUM_BUCKETS, MAX_DISTANCE).to(torch.bfloat16).contiguous())
+    plan = AttentionPlan(q, k, v, do, causal=False, sm_scale=0.125, **kw)
+    idx = pe.bucket_index(MAX_DISTANCE, True, NUM_BUCKETS, MAX_DISTANCE, device)
+    return plan, table, idx
+
+
+def event_time(fn, iters, warmup=3):
+    """average ms per call of fn(), measured with HIP events on the current stream"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def kernel_breakdown(plan, S, iters):
+    """per-kernel average duration (us) with HIP events around each C-ABI stage"""
+    t_fwd = event_time(plan.forward, iters) * 1e3
+    plan.forward()
+    t_dq = event_time(lambda: plan.backward(1), iters) * 1e3
+    t_dkv = event_time(lambda: plan.backward(2), iters) * 1e3
+    t_red = event_time(lambda: plan.backward(4), iters) * 1e3
+    f = fwd_flops(S)
+    # algorithmic flops per launch: fwd 2 GEMMs; dk/dv kernel 4 GEMMs (S, dP, dV, dK);
+    # dq kernel 1 GEMM (its recomputation of S and dP is not counted)
+    return {
+        "attn_fwd": {"us": t_fwd, "tflops": f / t_fwd / 1e6, "alg_flops": f},
+        "attn_bwd_dq": {"us": t_dq, "tflops": 0.5 * f / t_dq / 1e6, "alg_flops": 0.5 * f},
+        "attn_bwd_dkdv": {"us": t_dkv, "tflops": 2.0 * f / t_dkv / 1e6, "alg_flops": 2.0 * f},
+        "bias_grad_reduce": {"us": t_red},
+    }
+
+
+def cpu_baseline(S=512, reps=3):
+    """The reference's eager attention (oracle restatement of src/utils/attn_ref.py) forward+backward on the
+    host cores, fp32, full cfg2 batch, min of `reps` runs."""
+    import oracle
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(B, H, S, D, requires_grad=True) for _ in range(3))
+    bias = torch.randn(1, H, S, S, requires_grad=True)
+    do = torch.randn(B, H, S, D)
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        o = oracle.attn_ref(q, k, v, bias, 0.125, causal=False, upcast=True)
+        torch.autograd.grad(o, (q, k, v, bias), do)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": 3.5 * fwd_flops(S) / best / 1e12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"eager fp32 attention fwd+bwd (oracle.attn_ref + autograd), full (4,12,{S},64) batch with dense "
+                      f"(1,12,{S},{S}) bias, min of {reps} runs, {best*1e3:.1f} ms"}
+
+
+def load_traffic(kernel_key, S, mode):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(f"{kernel_key}:S{S}:{mode}")
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--mode", default="rpe", choices=["rpe", "dense", "none"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import flasht5_amd  # noqa: F401  raises if libfat5.so is missing
+    S, mode = args.seq, args.mode
+    plan, table, idx = make_plan(S, mode, device, seed=rank)
+    dtable = torch.zeros(NUM_BUCKETS, H, dtype=torch.float32, device=device)
+
+    def step_local():
+        plan.forward()
+        plan.backward()
+        if mode == "rpe":  # scatter the (H, 2R+1) diagonal sums into the (32, H) table gradient
+            dtable.zero_()
+            dtable.index_add_(0, idx, plan.dbias.transpose(0, 1))
+
+    # ---- capture the local part of a step in a HIP graph (launch-bound at S = 512) ----
+    for _ in range(3):
+        step_local()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step_local()
+            with torch.cuda.graph(graph, stream=side):
+                step_local()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step_local()
+        if world > 1 and mode != "none":
+            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI
+            dist.all_reduce(dtable if mode == "rpe" else plan.dbias, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    flops_step = 3.5 * fwd_flops(S) * world
+    value = flops_step / (ms_per_step * 1e-3) / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "FA2+T5-bias fwd+bwd TFLOP/s (bf16, d_head=64)", "value": round(value, 2), "unit": "TFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"encoder self-attn fwd+bwd, (B,H,S,d)=({B},{H},{S},{D}) per GPU, non-causal, "
+                                   f"32-bucket T5 RPE bias ({mode} mode), sm_scale 0.125, (B,S,H,D)-strided inputs",
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}", "bias_mode": mode,
+                       "launch": "hipGraph replay" if graph is not None else "eager C-ABI calls"},
+            "frac_of_peak": round(value / (PEAK_BF16_TFLOPS * world), 4),
+        }
+        if not args.no_extras:
+            iters = max(10, min(args.steps, 50))
+            kern = kernel_breakdown(plan, S, iters)
+            dom = max(("attn_fwd", "attn_bwd_dq", "attn_bwd_dkdv"), key=lambda n: kern[n]["us"])
+            out["kernels"] = {n: {k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in d.items()} for n, d in kern.items()}
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(kern[dom]["tflops"], 2),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_BF16_TFLOPS, 4),
+                               "avg_launch_us": round(kern[dom]["us"], 3), "traffic": load_traffic(dom, S, mode)}
+            by_seq = {}
+            for s2 in (512, 2048, 8192):
+                p2 = plan if s2 == S else make_plan(s2, mode, device, seed=rank)[0]
+                it = 50 if s2 <= 2048 else 10
+                tf = event_time(p2.forward, it)
+                p2.forward()
+                tb = event_time(p2.backward, it)
+                f = fwd_flops(s2)
+                by_seq[str(s2)] = {"fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "fwd_tflops": round(f / tf / 1e9, 1),
+                                   "bwd_tflops": round(2.5 * f / tb / 1e9, 1),
+                                   "fwd_bwd_tflops": round(3.5 * f / (tf + tb) / 1e9, 1),
+                                   "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4)}
+                del p2
+            out["by_seq"] = by_seq
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(512)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,9 +11,12 @@
 namespace fat5 {
 
 template <typename K>
-static hipError_t set_smem(K kern, size_t smem) {
-  if (smem > 48 * 1024)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+static hipError_t set_smem(K kern, size_t smem, size_t& configured) {
+  if (smem > 48 * 1024 && smem > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    configured = smem;  // per instantiation; benign race (idempotent call)
+  }
   return hipSuccess;
 }
 
@@ -21,7 +24,8 @@ template <int D, bool BF16, int BIAS, int NW>
 static hipError_t launch_q(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = BwdQCfg<D, NW>::smem(a.R, BIAS);
   auto kern = attn_bwd_q_kernel<D, BF16, BIAS, NW>;
-  hipError_t e = set_smem(kern, smem);
+  static size_t configured = 0;
+  hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
   return hipGetLastError();
@@ -30,7 +34,8 @@ template <int D, bool BF16, int BIAS, int NW>
 static hipError_t launch_kv(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = BwdKVCfg<D, NW>::smem(a.R, BIAS);
   auto kern = attn_bwd_kv_kernel<D, BF16, BIAS, NW>;
-  hipError_t e = set_smem(kern, smem);
+  static size_t configured = 0;
+  hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
   return hipGetLastError();

@@ -14,9 +14,11 @@ template <int D, bool BF16, int BIAS, int NW>
 static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
   auto kern = attn_fwd_kernel<D, BF16, BIAS, NW>;
-  if (smem > 48 * 1024) {
+  static size_t configured = 0;  // per instantiation; benign race (idempotent call)
+  if (smem > 48 * 1024 && smem > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
+    configured = smem;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
   return hipGetLastError();

@@ -165,7 +165,9 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
   return L.total;
 }
 
-int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) {
+int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) { return fat5_attn_bwd_stages(p, FAT5_BWD_ALL, stream_); }
+
+int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   int rc = check_common(p);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -205,7 +207,7 @@ int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) {
       a.ds_out = (uint16_t*)p->dbias;
     }
     a.dss[0] = (int64_t)p->H * MN; a.dss[1] = MN; a.dss[2] = p->N;
-    if (p->causal) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
+    if (p->causal && (stages & FAT5_BWD_DKDV)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
       hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
       if (e != hipSuccess) return hip_fail(e, "memset ds");
     }
@@ -215,19 +217,19 @@ int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) {
   // 1) dQ (+ delta)
   a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
   a.n_nblk = L.n_nblk;
-  {
+  if (stages & FAT5_BWD_DQ) {
     launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
     hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)(bh * a.n_mblk), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
   }
   // 2) dK, dV, dBias
-  {
+  if (stages & FAT5_BWD_DKDV) {
     launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
     hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)(bh * a.n_nblk), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
   }
   // 3) reductions over the broadcast dims
-  if (L.ds_staged) {
+  if (L.ds_staged && (stages & FAT5_BWD_REDUCE)) {
     const int64_t chunks = (MN + 7) / 8 * p->dbias_batch * p->dbias_heads;
     const int grid = (int)((chunks + 255) / 256);
     if (bf16)
@@ -239,7 +241,7 @@ int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "dbias_reduce launch");
   }
-  if (a.drpe_part) {
+  if (a.drpe_part && (stages & FAT5_BWD_REDUCE)) {
     const int n1 = 2 * p->rpe_radius + 1;
     const int grid = (p->H * n1 + 255) / 256;
     hipLaunchKernelGGL(drpe_reduce_kernel, dim3(grid), dim3(256), 0, stream, a.drpe_part, p->drpe1d, p->B, p->H, a.n_nblk, n1);
@@ -300,9 +302,9 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
   if (!dtype_ok(x_dtype) || !dtype_ok(w_dtype)) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad dtype");
   if (rows <= 0 || n <= 0) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad shape");
   const int vx = vec_of(x_dtype);
-  if ((n % 8) || (xs % vx) || (dys % vx) || (dxs % vx) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(w))
-    return fail(FAT5_EINVAL, "rmsnorm_bwd: n must be a multiple of 8 and rows 16-byte aligned");
-  if (n > 16 * 64 * vx) return fail(FAT5_EINVAL, "rmsnorm_bwd: n = %lld exceeds %d", (long long)n, 16 * 64 * vx);
+  const bool vecok = !((n % 8) || (xs % vx) || (dys % vx) || (dxs % vx) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) ||
+                       !aligned16(w)) && (n <= 16 * 64 * vx);
+  if (n > 16384) return fail(FAT5_EINVAL, "rmsnorm_bwd: n = %lld exceeds 16384", (long long)n);
   const size_t need = fat5_rmsnorm_bwd_workspace_bytes(rows, n);
   if (!workspace || workspace_bytes < need) return fail(FAT5_EWORKSPACE, "rmsnorm_bwd: workspace of %zu bytes required", need);
   hipStream_t stream = (hipStream_t)stream_;
@@ -313,7 +315,11 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
 #define RMS_BWD_LAUNCH(NCH) \
   hipLaunchKernelGGL((rmsnorm_bwd_kernel<XDT, WDT, NCH>), dim3(blocks), dim3(512), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs)
   RMS_DISPATCH({
-    if (nch <= 2) RMS_BWD_LAUNCH(2);
+    if (!vecok) {
+      auto kern = rmsnorm_bwd_scalar_kernel<XDT, WDT>;
+      if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs);
+    } else if (nch <= 2) RMS_BWD_LAUNCH(2);
     else if (nch <= 4) RMS_BWD_LAUNCH(4);
     else if (nch <= 8) RMS_BWD_LAUNCH(8);
     else RMS_BWD_LAUNCH(16);

@@ -211,6 +211,42 @@ __global__ __launch_bounds__(512) void rmsnorm_bwd_kernel(const void* __restrict
   for (int c = threadIdx.x; c < n; c += blockDim.x) out[c] = sdw[c];
 }
 
+// Generic fallback (n or strides not 16-byte friendly): scalar accesses, dw accumulated with LDS atomics.
+template <int XDT, int WDT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_scalar_kernel(const void* __restrict__ dy_, const void* __restrict__ x_,
+                                                                 const void* __restrict__ w_, const float* __restrict__ rstd,
+                                                                 void* __restrict__ dx_, float* __restrict__ dw_part,
+                                                                 int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs) {
+  typedef Elem<XDT> X;
+  typedef Elem<WDT> W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sdw = reinterpret_cast<float*>(smem);
+  for (int c = threadIdx.x; c < n; c += blockDim.x) sdw[c] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+  const int64_t wave_id = (int64_t)blockIdx.x * nwave + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nwave;
+  const typename W::T* w = reinterpret_cast<const typename W::T*>(w_);
+  const float inv_n = 1.0f / (float)n;
+  for (int64_t row = wave_id; row < rows; row += nwaves) {
+    const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+    const typename X::T* dy = reinterpret_cast<const typename X::T*>(dy_) + row * dys;
+    typename X::T* dx = reinterpret_cast<typename X::T*>(dx_) + row * dxs;
+    const float r = rstd[row];
+    float c1 = 0.f;
+    for (int c = lane; c < n; c += 64) c1 = fmaf(X::ld1(x + c) * r, W::ld1(w + c) * X::ld1(dy + c), c1);
+    c1 = wave_sum(c1) * inv_n;
+    for (int c = lane; c < n; c += 64) {
+      const float xh = X::ld1(x + c) * r, dyf = X::ld1(dy + c);
+      X::st1(dx + c, (W::ld1(w + c) * dyf - xh * c1) * r);
+      atomicAdd(&sdw[c], dyf * xh);
+    }
+  }
+  __syncthreads();
+  float* out = dw_part + (int64_t)blockIdx.x * n;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) out[c] = sdw[c];
+}
+
 // dw[c] = sum_p part[p][c]  -> weight dtype (rms_norm.py:234)
 template <int WDT>
 __global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ part, void* __restrict__ dw_,

@@ -265,3 +265,54 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max
     with torch.cuda.device(q.device):
         _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
     return o, lse
+
+
+# ------------------------------------------------------------------------------------------------
+# pre-planned fwd+bwd (fixed buffers, prebuilt C descriptors): what a training loop / hipGraph replays
+# ------------------------------------------------------------------------------------------------
+class AttentionPlan:
+    """Fixed-shape forward+backward with all buffers preallocated and the `fat5_attn_params` descriptors
+    built once: each call is one C-ABI call (fwd) or one per stage (bwd) -- capturable in a HIP graph.
+
+    mode: "none" | "dense" (bias tensor) | "rpe" (rpe1d (H, 2R+1) fp32 + radius)."""
+
+    def __init__(self, q, k, v, do, *, bias=None, rpe1d=None, radius=0, causal=False, sm_scale=None, need_dbias=True):
+        _check_inputs(q, k, v)
+        self.q, self.k, self.v, self.do = _prep(q), _prep(k), _prep(v), _prep(do)
+        B, H, M, D = q.shape
+        self.shape = (B, H, M, k.shape[2], D)
+        sm_scale = (1.0 / math.sqrt(D)) if sm_scale is None else sm_scale
+        dev = q.device
+        self.o = torch.empty_like(self.q)
+        self.lse = torch.empty((B, H, M), dtype=torch.float32, device=dev)
+        self.dq, self.dk, self.dv = torch.empty_like(self.q), torch.empty_like(self.k), torch.empty_like(self.v)
+        self.bias, self.rpe1d, self.dbias = bias, rpe1d, None
+        p = _base_params(self.q, self.k, self.v, causal, sm_scale)
+        p.o, p.lse, p.o_stride = self.o.data_ptr(), self.lse.data_ptr(), _lib.strides3(self.o)
+        p.dout, p.dq, p.dk, p.dv = self.do.data_ptr(), self.dq.data_ptr(), self.dk.data_ptr(), self.dv.data_ptr()
+        p.do_stride, p.dq_stride, p.dk_stride, p.dv_stride = (_lib.strides3(t) for t in (self.do, self.dq, self.dk, self.dv))
+        if bias is not None:
+            p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
+            if need_dbias:
+                self.dbias = torch.empty_like(bias)
+                p.dbias, p.dbias_batch, p.dbias_heads = self.dbias.data_ptr(), bias.shape[0], bias.shape[1]
+        elif rpe1d is not None:
+            p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
+            if need_dbias:
+                self.dbias = torch.empty_like(rpe1d)
+                p.drpe1d = self.dbias.data_ptr()
+        self.lib = _lib.load()
+        nbytes = self.lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
+        self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        p.workspace, p.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.p = p
+        self.device = dev
+
+    def forward(self):
+        _lib.check(self.lib.fat5_attn_fwd(ctypes.byref(self.p), _lib.stream_ptr(self.device)), "fat5_attn_fwd")
+        return self.o
+
+    def backward(self, stages=7):
+        _lib.check(self.lib.fat5_attn_bwd_stages(ctypes.byref(self.p), int(stages), _lib.stream_ptr(self.device)),
+                   "fat5_attn_bwd")
+        return self.dq, self.dk, self.dv, self.dbias

@@ -105,6 +105,11 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* hip_stream);
 size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p);
 /* backward: reads q,k,v,o,lse,dout(,bias|rpe1d); writes dq,dk,dv(,dbias|drpe1d). */
 int fat5_attn_bwd(const fat5_attn_params* p, void* hip_stream);
+/* the same backward, one stage at a time (profiling / stream overlap).  Order matters:
+ * FAT5_BWD_DQ (writes delta + dq) must precede FAT5_BWD_DKDV (reads delta; writes dk, dv, dS / partial
+ * diagonal sums), which must precede FAT5_BWD_REDUCE (dbias / drpe1d).  fat5_attn_bwd == FAT5_BWD_ALL. */
+enum fat5_bwd_stage { FAT5_BWD_DQ = 1, FAT5_BWD_DKDV = 2, FAT5_BWD_REDUCE = 4, FAT5_BWD_ALL = 7 };
+int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* hip_stream);
 
 /*
  * T5 RMSNorm.  Replaces flasht5::rmsnorm_triton_fwd / _bwd (src/model/ops/rms_norm.py:134-236).

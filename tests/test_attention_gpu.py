@@ -1,0 +1,276 @@
+"""GPU parity tests of the attention hot path: HIP kernels (through the C ABI / ctypes / autograd.Function)
+vs the CPU oracle, the committed golden fixtures, and the reference's own acceptance rule.
+
+Tolerances
+  * reference rule (tests/fa2_triton/test_fa2_bias.py:26-28,64-67): err <= 2 * err(eager low precision) + 1e-5
+  * fixed bound: err <= (1e-3 + u * half-ulp(dtype)) * max(1, max|ref|) -- 1e-3 is the north-star atol on the
+    arithmetic; the half-ulp term (2^-8 bf16, 2^-11 fp16 of max|ref|) is the unavoidable rounding of the OUTPUT
+    tensor (u = 1 forward; u = 3 gradients: their MFMA operands P and dS are rounded once more and delta is formed from
+    the stored, rounded o -- all exactly as in the reference kernels).
+"""
+import math
+
+import pytest
+import torch
+
+import oracle
+from attn_helpers import make_inputs, oracle_all, run_dense, errors, maxdiff, eager_lowprec_errors
+from golden_io import load_attn, ATTN_CASES, TRITON_CASES
+
+pytestmark = pytest.mark.gpu
+
+HALF_ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}  # worst case (value just above a power of two)
+
+
+def bound(ref_t, dtype, atol=1e-3, ulps=1.0):
+    return (atol + ulps * HALF_ULP[dtype]) * max(1.0, ref_t.float().abs().max().item())
+
+
+def gbound(ref_t, dtype):
+    """gradients: P and dS enter the dV/dK/dQ contractions rounded to the input dtype (exactly like the
+    reference kernels, flash_attention_v2_bias.py:702,:720-722) -> one more rounding than the forward."""
+    return bound(ref_t, dtype, ulps=3.0)
+
+
+def to_dev(c):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+
+
+@pytest.mark.parametrize("name", ATTN_CASES)
+def test_golden_fixture(name):
+    c = to_dev(load_attn(name))
+    got = run_dense(c["q"], c["k"], c["v"], c["bias"], c["do"], c["sm_scale"], c["causal"])
+    dt = c["dtype"]
+    lp = c["eager_lp_err"].tolist()  # [o, dq, dk, dv, dbias] of the reference's eager low-precision path
+    for i, key in enumerate(("o", "dq", "dk", "dv")):
+        e = maxdiff(got[key], c[key])
+        assert e <= (bound(c[key], dt) if key == "o" else gbound(c[key], dt)), (key, e)
+        if lp[i] > 0:
+            assert e <= 2 * lp[i] + 1e-5 + HALF_ULP[dt] * c[key].abs().max().item(), (key, e, lp[i])
+    if c["bias"] is not None:
+        e = maxdiff(got["db"], c["dbias"])
+        # dS is rounded to the bias dtype BEFORE the batch/head sum, like the reference (:720,:214): one extra
+        # half-ulp per summed term
+        nsum = (c["B"] if c["bias"].shape[0] == 1 else 1) * (c["H"] if c["bias"].shape[1] == 1 else 1)
+        assert e <= gbound(c["dbias"], dt) * (1 + nsum), ("db", e)
+
+
+def test_cfg1_fwd_numerics():
+    """config 1: t5-small encoder self-attn fwd (2,8,128,64); fp32 eager reference vs the bf16 kernel."""
+    c = to_dev(load_attn("attn_cfg1_fp32"))
+    from flasht5_amd import flash_attention_v2_bias
+    o = flash_attention_v2_bias(c["q"].bfloat16(), c["k"].bfloat16(), c["v"].bfloat16(), c["bias"].bfloat16(),
+                                False, c["sm_scale"])
+    assert maxdiff(o, c["o"]) <= bound(c["o"], torch.bfloat16)
+
+
+@pytest.mark.parametrize("name", TRITON_CASES)
+def test_vs_reference_triton_kernels(name):
+    """Same inputs as the reference's Triton kernels (run under the interpreter, fp16): outputs agree within
+    the two kernels' combined rounding (each is within ~half an output ulp + 1e-3 of fp32 truth)."""
+    c = to_dev(load_attn(name))
+    got = run_dense(c["q"], c["k"], c["v"], c["bias"], c["do"], c["sm_scale"], c["causal"])
+    for key, tk in (("o", "o_triton"), ("dq", "dq_triton"), ("dk", "dk_triton"), ("dv", "dv_triton"), ("db", "dbias_triton")):
+        e = maxdiff(got[key], c[tk])
+        scale = max(1.0, c[tk].float().abs().max().item())
+        nsum = c["B"] if (key == "db" and c["bias"].shape[0] == 1) else 1
+        assert e <= 2 * (1e-3 + HALF_ULP[torch.float16]) * scale * nsum, (key, e)
+
+
+@pytest.mark.parametrize("B,H,M,N,D", [(2, 4, 512, 612, 128), (2, 4, 1024, 1045, 64)])
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reference_shapes_fwd_bwd(B, H, M, N, D, causal, dtype):
+    """The reference's own test shapes (test_fa2_bias.py:10-13): M != N, N not divisible by any tile."""
+    q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, "bh", seed=3)
+    ref = oracle_all(q, k, v, b, do, 1.0, causal)
+    lp = eager_lowprec_errors(q, k, v, b, do, 1.0, causal, ref)
+    got = run_dense(q, k, v, b, do, 1.0, causal)
+    for key in ("o", "dq", "dk", "dv", "db"):
+        e = maxdiff(got[key], ref[key])
+        assert e <= 2 * lp[key] + 1e-5 + HALF_ULP[dtype] * ref[key].abs().max().item(), (key, e, lp[key])
+        assert e <= (bound(ref[key], dtype) if key == "o" else gbound(ref[key], dtype)), (key, e)
+
+
+@pytest.mark.parametrize("kind", ["11", "b1", "1h"])
+def test_broadcast_bias_gradient(kind):
+    """(1,1,M,N) / (B,1,M,N) / (1,H,M,N): dbias is the mathematically correct sum (the reference races on
+    head-broadcast biases -- SURVEY Q4)."""
+    q, k, v, b, do = make_inputs(2, 3, 100, 77, 64, torch.bfloat16, kind, seed=11)
+    ref = oracle_all(q, k, v, b, do, 1.0, False)
+    got = run_dense(q, k, v, b, do, 1.0, False)
+    assert got["db"].shape == b.shape and got["db"].dtype == b.dtype
+    nsum = (2 if b.shape[0] == 1 else 1) * (3 if b.shape[1] == 1 else 1)
+    assert maxdiff(got["db"], ref["db"]) <= gbound(ref["db"], torch.bfloat16) * (1 + nsum)
+
+
+def test_strided_inputs_and_layout():
+    """(B,S,H,D)-backed permuted views: outputs keep the input layout."""
+    q, k, v, b, do = make_inputs(2, 4, 200, 264, 64, torch.bfloat16, "1h", seed=5, strided=True)
+    from flasht5_amd import flash_attention_v2_bias
+    o = flash_attention_v2_bias(q, k, v, b, False, 0.125)
+    assert o.stride() == q.stride()
+    ref = oracle_all(q, k, v, b, do, 0.125, False)
+    got = run_dense(q, k, v, b, do, 0.125, False)
+    for key in ("o", "dq", "dk", "dv", "db"):
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16) * (3 if key == "db" else 1), key
+
+
+def test_causal_m_larger_than_n_empty_rows():
+    """causal with M > N: the first M-N rows see no key -> o = 0, finite gradients (reference :470-473)."""
+    q, k, v, b, do = make_inputs(1, 2, 96, 64, 64, torch.bfloat16, "1h", seed=9)
+    from flasht5_amd.flash_attention_v2_bias import _attn_fwd
+    o, L = _attn_fwd(q, k, v, b, None, 0, True, 1.0)
+    assert torch.all(o[:, :, :32] == 0) and torch.all(torch.isinf(L[:, :, :32])) and torch.all(L[:, :, :32] < 0)
+    got = run_dense(q, k, v, b, do, 1.0, True)
+    ref = oracle_all(q, k, v, b, do, 1.0, True)
+    for key in ("o", "dq", "dk", "dv", "db"):
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16) * (3 if key == "db" else 1), key
+
+
+@pytest.mark.parametrize("D", [16, 32, 128])
+def test_head_dims(D):
+    q, k, v, b, do = make_inputs(1, 2, 72, 100, D, torch.float16, "1h", seed=D)
+    ref = oracle_all(q, k, v, b, do, 1.0 / math.sqrt(D), True)
+    got = run_dense(q, k, v, b, do, 1.0 / math.sqrt(D), True)
+    for key in ("o", "dq", "dk", "dv", "db"):
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.float16), key
+
+
+def test_default_scale_and_none_bias():
+    q, k, v, _, do = make_inputs(2, 2, 128, 128, 64, torch.bfloat16, None, seed=2)
+    got = run_dense(q, k, v, None, do, None, False)
+    ref = oracle_all(q, k, v, None, do, 1.0 / 8.0, False)
+    for key in ("o", "dq", "dk", "dv"):
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16), key
+
+
+def test_deterministic():
+    """two runs are bit-identical (no atomics on dQ/dK/dV/dense dBias) -- would have caught the reference's Q4 race."""
+    q, k, v, b, do = make_inputs(2, 3, 256, 300, 64, torch.bfloat16, "11", seed=1)
+    a = run_dense(q, k, v, b, do, 1.0, True)
+    c = run_dense(q, k, v, b, do, 1.0, True)
+    for key in a:
+        assert torch.equal(a[key], c[key]), key
+
+
+# ---- linear-memory RPE mode ----------------------------------------------------------------------------------
+def _rpe_case(B, H, M, N, dtype, causal, bidir, max_distance=128, seed=0):
+    q, k, v, _, do = make_inputs(B, H, M, N, 64, dtype, None, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    table = torch.randn(32, H, generator=g) * 0.5
+    bias = oracle.compute_bias(table, M, N, bidir, 32, max_distance).contiguous().cuda()
+    return q, k, v, do, table, bias
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,bidir,md", [
+    (2, 2, 256, 256, False, True, 128), (2, 2, 96, 160, False, True, 128), (2, 2, 128, 128, True, False, 128),
+    (1, 2, 512, 512, False, True, 128), (2, 2, 300, 200, False, True, 64), (1, 2, 520, 333, True, True, 32)])
+def test_rpe_mode_matches_dense_oracle(B, H, M, N, causal, bidir, md):
+    from flasht5_amd import flash_attention_v2_rpe
+    dtype = torch.bfloat16
+    q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, bidir, md, seed=M + N)
+    ref = oracle_all(q, k, v, bias, do, 1.0, causal)  # fp32 bias: the RPE mode never rounds it
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    tb = table.cuda().requires_grad_()
+    o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, 1.0)
+    dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+    # table-gradient truth: the oracle's dS with delta = rowsum(o * do) formed from the STORED (rounded) o, which is
+    # what FA2 backward defines (reference _bwd_preprocess reads the bf16 o, :516-556); with the unrounded o the
+    # per-row offsets of ~2^-9 |o||do| sqrt(D) pile up over the B*M rows of a bucket.
+    _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, bias, o.detach(), ref["L"], do, 1.0, causal)
+    tl = table.clone().requires_grad_()
+    oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db_alg.cpu())
+    for got, key in ((o, "o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert maxdiff(got, ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), key
+    assert maxdiff(dt.cpu(), tl.grad) <= 5e-3 * max(1.0, tl.grad.abs().max().item()) + 2e-2
+
+
+def test_rpe_equals_dense_kernel_full_cfg2():
+    """config 2 at full size: the RPE-mode kernels and the dense-bias kernels agree (same table)."""
+    from flasht5_amd import flash_attention_v2_rpe, flash_attention_v2_bias, compute_bias
+    q, k, v, _, do = make_inputs(4, 12, 512, 512, 64, torch.bfloat16, None, seed=42, strided=True)
+    table = (torch.randn(32, 12, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    bias = compute_bias(table, 512, 512).contiguous()  # fp32 values
+    o1 = flash_attention_v2_rpe(q, k, v, table, True, 32, 128, False, 0.125)
+    o2 = flash_attention_v2_bias(q, k, v, bias.bfloat16(), False, 0.125)
+    # the dense path rounds the bias to bf16 (like the reference, positional_encoding.py:108)
+    assert maxdiff(o1, o2) <= 3e-2
+    ref, _ = oracle.attn_fwd_oracle(q, k, v, bias, 0.125, False)
+    assert maxdiff(o1, ref) <= bound(ref, torch.bfloat16)
+
+
+# ---- full-size, size-independent properties (config 3: S = 8192) ---------------------------------------------
+def test_cfg3_properties_s8192():
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    B, H, S, D = 4, 12, 8192, 64
+    q, k, v, _, do = make_inputs(B, H, S, S, D, torch.bfloat16, None, seed=8, strided=True)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(2)) * 0.5).cuda()
+    rpe1d = pe.rpe1d_from_table(table)
+    plan = AttentionPlan(q, k, v, do, rpe1d=rpe1d, radius=128, sm_scale=0.125)
+    o = plan.forward().clone()
+    dq, dk, dv, d1 = (t.clone() for t in plan.backward())
+    torch.cuda.synchronize()
+    for t in (o, dq, dk, dv, d1):
+        assert torch.isfinite(t.float()).all()
+    # (1) a (b,h) slice against the fp32 oracle run on the device (full S x S scores for 2 heads)
+    bias = pe.compute_bias(table[:, :2], S, S).contiguous()
+    sl = slice(0, 1), slice(0, 2)
+    qs, ks, vs, dos = (t[sl[0], sl[1]] for t in (q, k, v, do))
+    ref_o, ref_L = oracle.attn_fwd_oracle(qs, ks, vs, bias, 0.125, False)
+    assert maxdiff(o[sl[0], sl[1]], ref_o) <= bound(ref_o, torch.bfloat16)
+    assert maxdiff(plan.lse[sl[0], sl[1]], ref_L) <= 1e-3
+    rdq, rdk, rdv, rds, _ = oracle.attn_bwd_oracle(qs, ks, vs, bias, ref_o, ref_L, dos, 0.125, False)
+    assert maxdiff(dq[sl[0], sl[1]], rdq) <= gbound(rdq, torch.bfloat16)
+    assert maxdiff(dk[sl[0], sl[1]], rdk) <= gbound(rdk, torch.bfloat16)
+    assert maxdiff(dv[sl[0], sl[1]], rdv) <= gbound(rdv, torch.bfloat16)
+    # (2) softmax Jacobian: every row of dS sums to zero => the diagonal sums of each head sum to ~0
+    tot = d1.sum(-1).abs().max().item()
+    assert tot <= 1e-3 * d1.abs().sum(-1).max().item() + 1e-2, tot
+    # (3) linearity in V and dO: o(2v) = 2 o(v) exactly in bf16 (power of two); dq(2 do) = 2 dq
+    plan2 = AttentionPlan(q, k, (v * 2).contiguous(), (do * 2).contiguous(), rpe1d=rpe1d, radius=128, sm_scale=0.125)
+    o2 = plan2.forward()
+    assert torch.equal(o2, o * 2)
+    # (4) key permutation invariance without bias: shuffling (k, v) rows jointly leaves o unchanged up to rounding
+    plan3 = AttentionPlan(q[:1], k[:1], v[:1], do[:1], sm_scale=0.125)
+    o3 = plan3.forward().clone()
+    perm = torch.randperm(S, device="cuda")
+    plan4 = AttentionPlan(q[:1], k[:1][:, :, perm].contiguous(), v[:1][:, :, perm].contiguous(), do[:1], sm_scale=0.125)
+    o4 = plan4.forward()
+    assert maxdiff(o3, o4) <= 2 * HALF_ULP[torch.bfloat16] * max(1.0, o3.float().abs().max().item()) + 1e-3
+
+
+def test_varlen_cross_attention_cfg4():
+    """config 4: packed decoder cross-attention, q_len 256 / kv_len 4096 class, via cu_seqlens."""
+    from flasht5_amd import flash_attn_varlen_fwd
+    H, D = 12, 64
+    cu_q = [0, 256, 512, 704, 768]
+    cu_k = [0, 4096, 7168, 11264, 12288]
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(cu_q[-1], H, D, generator=g).bfloat16().cuda()
+    k = torch.randn(cu_k[-1], H, D, generator=g).bfloat16().cuda()
+    v = torch.randn(cu_k[-1], H, D, generator=g).bfloat16().cuda()
+    o, lse = flash_attn_varlen_fwd(q, k, v, torch.tensor(cu_q, dtype=torch.int32).cuda(),
+                                   torch.tensor(cu_k, dtype=torch.int32).cuda(), 256, 4096, False, 0.125)
+    ref = oracle.attn_varlen_oracle(q, k, v, cu_q, cu_k, 0.125).to(q.device)
+    assert maxdiff(o, ref) <= bound(ref, torch.bfloat16)
+    # ragged edge cases: an empty query sequence, an empty key sequence, length-1 sequences
+    cu_q2, cu_k2 = [0, 5, 5, 6, 70], [0, 9, 12, 12, 141]
+    q2, k2, v2 = q[:70].contiguous(), k[:141].contiguous(), v[:141].contiguous()
+    o2, _ = flash_attn_varlen_fwd(q2, k2, v2, torch.tensor(cu_q2, dtype=torch.int32).cuda(),
+                                  torch.tensor(cu_k2, dtype=torch.int32).cuda(), 64, 129, False, 0.125)
+    ref2 = oracle.attn_varlen_oracle(q2, k2, v2, cu_q2, cu_k2, 0.125).to(q.device)
+    assert maxdiff(o2, ref2) <= bound(ref2, torch.bfloat16)
+
+
+def test_bad_arguments_raise():
+    from flasht5_amd import flash_attention_v2_bias
+    q, k, v, b, _ = make_inputs(1, 1, 32, 32, 64, torch.bfloat16, "1h")
+    with pytest.raises(AssertionError):
+        flash_attention_v2_bias(q[..., :48], k[..., :48], v[..., :48], None)  # head_dim 48 (reference asserts too)
+    with pytest.raises(TypeError):
+        flash_attention_v2_bias(q.float(), k.float(), v.float(), None)
+    with pytest.raises(RuntimeError):
+        flash_attention_v2_bias(q.cpu(), k.cpu(), v.cpu(), None)  # no CPU fallback

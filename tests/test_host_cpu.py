@@ -1,0 +1,92 @@
+"""CPU tests: the C-ABI library loads and exports every declared symbol, rejects bad descriptors without touching a
+GPU, the host-side bias producers match the oracle / goldens, and the unit sharding logic is sound."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_io import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from flasht5_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("fat5_build", os.path.join(ROOT, "flasht5_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_lib()
+    return _lib.load()
+
+
+def test_exports_match_header(lib):
+    from flasht5_amd import _lib
+    header = open(os.path.join(ROOT, "include", "fat5.h")).read()
+    declared = set(re.findall(r"\b(fat5_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fat5_attn_params"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fat5_version() == 100
+    assert lib.fat5_sizeof_attn_params() == ctypes.sizeof(_lib.AttnParams)
+
+
+def test_bad_descriptors_are_rejected_without_gpu(lib):
+    from flasht5_amd import _lib
+    p = _lib.AttnParams()
+    p.B, p.H, p.M, p.N, p.D = 1, 1, 16, 16, 48
+    p.dtype = _lib.FAT5_BF16
+    assert lib.fat5_attn_fwd(ctypes.byref(p), None) == -1
+    assert b"head_dim 48" in lib.fat5_last_error()
+    p.D, p.dtype = 64, _lib.FAT5_F32
+    assert lib.fat5_attn_fwd(ctypes.byref(p), None) == -1
+    p.dtype = _lib.FAT5_BF16
+    assert lib.fat5_attn_fwd(ctypes.byref(p), None) == -1 and b"null" in lib.fat5_last_error()
+    p.bias_mode = _lib.BIAS_RPE1D
+    assert lib.fat5_attn_fwd(ctypes.byref(p), None) == -1 and b"rpe1d" in lib.fat5_last_error()
+    assert lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p)) == 0
+    p.bias_mode = _lib.BIAS_NONE
+    p.B, p.H, p.M, p.N = 4, 12, 512, 512
+    assert lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p)) >= 4 * 12 * 512 * 4
+    assert lib.fat5_rmsnorm_fwd(None, None, None, None, 4, 8, 8, 8, 1e-6, 0, 0, None) == -1
+    assert lib.fat5_ce_fwd(None, None, None, None, None, 4, 8, 8, 0.0, 1.0, 0.0, -100, 0, 0, None) == -1
+
+
+def test_host_bucket_and_bias_match_oracle():
+    from flasht5_amd import positional_encoding as pe
+    z = load("rpe_buckets")
+    deltas = torch.from_numpy(z["deltas"])
+    for key, val in z.items():
+        if key.startswith("bucket_"):
+            _, bidir, nb, mdist = key.split("_")
+            got = pe.relative_position_bucket(deltas, bool(int(bidir)), int(nb), int(mdist))
+            assert np.array_equal(got.numpy().astype(np.int32), val), key
+    table = torch.from_numpy(z["table_1_256_256"])
+    assert torch.equal(pe.compute_bias(table, 256, 256), oracle.compute_bias(table, 256, 256))
+    # the clamped generator reproduces the dense bias everywhere
+    for bidir, M, N in ((True, 256, 256), (True, 96, 300), (False, 128, 128)):
+        r1 = pe.rpe1d_from_table(table, bidir, 32, 128)
+        R = pe.rpe_radius(128)
+        idx = torch.clamp(torch.arange(N)[None, :] - torch.arange(M)[:, None], -R, R) + R
+        assert torch.equal(r1[:, idx].unsqueeze(0), oracle.compute_bias(table, M, N, bidir, 32, 128).float())
+
+
+def test_shard_units_partition():
+    from flasht5_amd.sharding import shard_units, heads_needing_reduction
+    for B, H in ((4, 12), (3, 5), (1, 7)):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for r in range(world):
+                seen += shard_units(B, H, world, r)
+            assert sorted(seen) == sorted((b, h) for b in range(B) for h in range(H))
+            sizes = [len(shard_units(B, H, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert heads_needing_reduction(4, 12, 4) == []           # 3 whole heads per rank: no communication
+    assert heads_needing_reduction(4, 12, 8) == [1, 4, 7, 10]   # 1.5 heads per rank: every third head is split
