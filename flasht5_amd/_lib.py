@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfat5.so")
+# FAT5_LIB_VARIANT selects a developer A/B build (lib/libfat5_<name>.so); unset = the product library
+_VAR = os.environ.get("FAT5_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libfat5" + ("_" + _VAR if _VAR else "") + ".so")
 
 FAT5_F32, FAT5_F16, FAT5_BF16 = 0, 1, 2
 BIAS_NONE, BIAS_DENSE, BIAS_RPE1D = 0, 1, 2

@@ -9,13 +9,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(HERE, "lib", "libfat5.so")
+# developer A/B builds: FAT5_VARIANT=name FAT5_EXTRA_FLAGS="-DX=1" python flasht5_amd/build.py  -> lib/libfat5_name.so
+VARIANT = os.environ.get("FAT5_VARIANT", "")
+OBJ = os.path.join(HERE, "lib", "obj" + ("_" + VARIANT if VARIANT else ""))
+LIB = os.path.join(HERE, "lib", "libfat5" + ("_" + VARIANT if VARIANT else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-Wno-unused-value", "-I", INCLUDE]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has a unified register file); without it every
+# softmax / rescale operand costs a v_accvgpr_read/_write (25 % of the forward loop's VALU issue slots).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         "-Wno-unused-value", "-I", INCLUDE] + os.environ.get("FAT5_EXTRA_FLAGS", "").split()
 
 # (source, object name, extra defines)
 UNITS = [("fat5_api.hip", "fat5_api.o", [])]

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 #define FAT5_DEV __device__ __forceinline__
 
@@ -94,8 +95,13 @@ FAT5_DEV float xchg32(float v) {  // value held by the partner lane (lane ^ 32)
 // ------------------------------------------------------------------------------------------
 template <int D>
 FAT5_DEV constexpr int swz(int row) {
+  // One XOR pattern serves both read shapes of a row-major image:
+  //  * ds_read_b128 fragment reads (16 rows that differ mod 16, same chunk)  -> 16 distinct 16-byte slots
+  //  * ds_read_b64_tr_b16 transposed reads (rows 4a..4a+3, 64 contiguous bytes each) -> 4 distinct 64-byte
+  //    quarters of the 256-byte bank row
   constexpr int C = D / 8;
-  if constexpr (C >= 16) return row & (C - 1) & 15;
+  if constexpr (C == 16) return ((row & 3) << 2) | ((row >> 2) & 3);
+  else if constexpr (C == 8) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
   else return (row * C / 16) & (C - 1);
 }
 template <int D>
@@ -224,6 +230,121 @@ struct PairStage {
   }
 };
 
+// Buffer resource over rows [0, nrows) of one (b,h) slice: bytes past the last row's D elements are out of range
+// (hardware returns 0).  Inputs are made provably wave-uniform so no waterfall loop is generated around the loads.
+FAT5_DEV __amdgpu_buffer_rsrc_t make_rows_rsrc(const uint16_t* base, int64_t row_stride, int nrows, int D) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const int64_t bytes = nrows > 0 ? ((int64_t)(nrows - 1) * row_stride + D) * 2 : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// Row staging for row-major images only (one 16-byte chunk of one row per work item).
+template <int D, int ROWS, int NT>
+struct RowStage {
+  static constexpr int C = D / 8;
+  static constexpr int ITEMS = ROWS * C;
+  static constexpr int PER = (ITEMS + NT - 1) / NT;
+  u32x4 r[PER];
+  FAT5_DEV void load(const uint16_t* base, int64_t row_stride, int row0, int limit, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = tid + NT * i;
+      const int c = id % C, row = row0 + id / C;
+      const bool in = (ITEMS % NT == 0) || (id < ITEMS);
+      r[i] = gload16(base + (int64_t)row * row_stride + c * 8, in && row < limit);
+    }
+  }
+  // rows >= limit read row limit-1 again (finite data; callers mask those rows' contributions exactly)
+  FAT5_DEV void load_clamped(const uint16_t* base, int64_t row_stride, int row0, int limit, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = tid + NT * i;
+      if ((ITEMS % NT != 0) && id >= ITEMS) continue;
+      const int row = min(row0 + id / C, limit - 1);
+      r[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * row_stride + (id % C) * 8);
+    }
+  }
+  // Buffer-descriptor path (the one the kernels use): voffset = this thread's constant byte offset inside a
+  // tile, soffset = wave-uniform byte offset of the tile.  No per-load VALU address math, no temporaries that the
+  // compiler could alias with MFMA operands, and rows past the descriptor's end read as ZERO in hardware.
+  FAT5_DEV void load_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_byte_off, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if ((ITEMS % NT != 0) && tid + NT * i >= ITEMS) continue;
+      r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] * 2u, tile_byte_off, 0));
+    }
+  }
+  // unguarded variant for full tiles: `tile` = wave-uniform pointer to the tile's first row (SGPR base),
+  // goff[i] = this thread's constant element offset inside a tile -> global_load with saddr + 32-bit voffset
+  uint32_t goff[PER];
+  int loff[PER];
+  FAT5_DEV void init(int64_t row_stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = tid + NT * i;
+      goff[i] = (uint32_t)((id / C) * row_stride + (id % C) * 8);
+      loff[i] = rm_off<D>(id / C, id % C);
+    }
+  }
+  FAT5_DEV void load_full(const uint16_t* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if ((ITEMS % NT != 0) && tid + NT * i >= ITEMS) continue;
+      r[i] = *reinterpret_cast<const u32x4*>(tile + goff[i]);
+    }
+  }
+  FAT5_DEV void store_rm(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if ((ITEMS % NT != 0) && tid + NT * i >= ITEMS) continue;
+      *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
+    }
+  }
+};
+
+// Per-lane LDS byte offsets of the fragment reads, hoisted out of the tile loops.  With the swizzle of
+// swz<D>() the XOR term of a fragment address depends on the lane only (not on the 32-row block / 16-row
+// step), so a handful of VGPRs + immediate offsets address every read of a tile.
+template <int D>
+struct FragAddr {
+  static constexpr int KK = D / 16, DB = D / 32;
+  int rm[KK];      // ds_read_b128: row (lane&31) of a 32-row block, chunk 2kk+hi
+  int tr[2][DB];   // ds_read_b64_tr_b16: rows 8*j2 + 4*hi + e, d-block db
+  FAT5_DEV void init(int lane) {
+    const int lq = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) rm[kk] = rm_off<D>(lq, 2 * kk + hi);
+    const int i = lane & 15, e = i >> 2, c = i & 3, g = (lane >> 4) & 1;
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int row = 8 * j2 + 4 * hi + e;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+        tr[j2][db] = row * (2 * D) + (((4 * db + 2 * g + (c >> 1)) ^ swz<D>(row)) << 4) + 8 * (c & 1);
+    }
+  }
+};
+// row-major fragment (A or B operand, contraction over the row's elements): 32-row block `blk`
+template <int D>
+FAT5_DEV u32x4 ld_rm(const char* img, const FragAddr<D>& fa, int blk, int kk) {
+  return *reinterpret_cast<const u32x4*>(img + fa.rm[kk] + blk * (32 * 2 * D));
+}
+// transposed fragment (contraction over rows): rows 32*blk + 16*t + {8*j2 + 4*hi + (j&3)}, d-block db
+template <int D>
+FAT5_DEV u32x4 ld_tr(const char* img, const FragAddr<D>& fa, int blk, int t, int db) {
+  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+  const char* p0 = img + fa.tr[0][db] + (32 * blk + 16 * t) * (2 * D);
+  const char* p1 = img + fa.tr[1][db] + (32 * blk + 16 * t) * (2 * D);
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0);
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1);
+  const u32x2 a2 = __builtin_bit_cast(u32x2, a), b2 = __builtin_bit_cast(u32x2, b);
+  u32x4 r = {a2[0], a2[1], b2[0], b2[1]};
+  return r;
+}
+
 // fragment reads -----------------------------------------------------------------------------
 // row-major image: rows on lanes (lq), 16-bit k-slots 16*kk + 8*hi + j
 template <int D>
@@ -238,6 +359,26 @@ FAT5_DEV u32x4 frag_tr(const char* lds, int d, int base) {
   const u32x2 a = *reinterpret_cast<const u32x2*>(p);
   const u32x2 b = *reinterpret_cast<const u32x2*>(p + 16);
   u32x4 r = {a[0], a[1], b[0], b[1]};
+  return r;
+}
+
+// Transposed fragment straight from a ROW-MAJOR image with ds_read_b64_tr_b16 (no transposed copy):
+// returns, for lane (d = 32*db + (lane&31), hi), the 8 k-slots j <-> rows  rbase + (j&3) + 8*(j>>2)
+// where rbase must be a multiple of 4 and already include the lane's 4*hi.
+// tr16_b64 semantics (probed on gfx950, tools/probe_layout.hip): inside each 16-lane group, lane 4e+c supplies
+// the address of row e, 8-byte piece c; lane i receives, for e = 0..3, the 16-bit element i of row e's 32 bytes.
+template <int D>
+FAT5_DEV u32x4 frag_tr_rm(const char* lds, int rbase, int db, int lane) {
+  const int i = lane & 15, e = i >> 2, c = i & 3, g = (lane >> 4) & 1;
+  const int chunk = 4 * db + 2 * g + (c >> 1);
+  const int r0 = rbase + e, r1 = r0 + 8;
+  const char* p0 = lds + r0 * (2 * D) + ((chunk ^ swz<D>(r0)) << 4) + 8 * (c & 1);
+  const char* p1 = lds + r1 * (2 * D) + ((chunk ^ swz<D>(r1)) << 4) + 8 * (c & 1);
+  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0);
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1);
+  const u32x2 a2 = __builtin_bit_cast(u32x2, a), b2 = __builtin_bit_cast(u32x2, b);
+  u32x4 r = {a2[0], a2[1], b2[0], b2[1]};
   return r;
 }
 

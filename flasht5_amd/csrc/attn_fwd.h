@@ -4,14 +4,18 @@
 //
 // Work decomposition: one workgroup = NW waves = one (b, h, 32*NW query rows) tile; a wave owns 32
 // query rows for the whole K/V sweep.  Per 64-key K/V tile:
-//   S^T[key][q]  = K . Q^T        v_mfma_f32_32x32x16 (A = K fragment from the row-major swizzled
-//                                  LDS image, B = Q fragment kept in registers)
+//   S^T[key][q]  = K . Q^T        v_mfma_f32_32x32x16 (A = K fragment, ds_read_b128 from the row-major
+//                                  swizzled LDS image; B = Q fragment kept in registers)
 //   online softmax in registers   lane (q = lane&31, hi = lane>>5) holds 16 of the 32 keys of each
-//                                  32-key block of its row: row max / row sum are 15 in-lane ops
-//                                  plus ONE exchange with lane^32
-//   O^T[d][q]   += V^T . P^T      A = V^T fragment from the transposed LDS image, B = P^T straight
-//                                  from the S^T accumulator registers (the MFMA k-slot <-> key
-//                                  mapping is chosen so that no cross-lane shuffle is needed)
+//                                  32-key block of its row: row max / row sum are in-lane ops plus ONE
+//                                  exchange with lane^32.  exp2 domain, sm_scale*log2e and tile-constant
+//                                  bias folded into the exponent FMA; the O/l rescale is skipped while no
+//                                  row maximum of the wave grows by more than DEFER_THR (exact: the same
+//                                  stale maximum is used for P, l and the final normalisation).
+//   O^T[d][q]   += V^T . P^T      A = V^T fragment read TRANSPOSED from the row-major V image with
+//                                  ds_read_b64_tr_b16, B = P^T straight from the S^T accumulator
+//                                  registers (the MFMA k-slot <-> key mapping is chosen so that no
+//                                  cross-lane shuffle is needed)
 // K/V tiles are prefetched global->registers one tile ahead and written to the other LDS buffer
 // after the compute of the current tile (one barrier per tile).
 #pragma once
@@ -19,13 +23,17 @@
 
 namespace fat5 {
 
+#ifndef FAT5_DEFER_THR
+#define FAT5_DEFER_THR 6.0f  // log2 units: P <= 2^6 while the running max is stale
+#endif
+
 template <int D, int NW>
 struct FwdCfg {
   static constexpr int BM = 32 * NW;
   static constexpr int BN = 64;
   static constexpr int NT = 64 * NW;
   static constexpr int KBYTES = rm_bytes<D, BN>();
-  static constexpr int VBYTES = tr_bytes<D, BN>();
+  static constexpr int VBYTES = rm_bytes<D, BN>();
   static constexpr int STAGE = KBYTES + VBYTES;
   static size_t smem(int R, int bias_mode) {
     return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0);
@@ -53,8 +61,49 @@ FAT5_DEV void load_bias_block(const uint16_t* brow, int nb, int hi, int N, bool 
   }
 }
 
+#ifndef FAT5_ASM_MAX3
+#define FAT5_ASM_MAX3 0  // 1 is UNSAFE: hipcc pads no MFMA->VALU wait states in front of inline asm
+#endif
+FAT5_DEV float max3f(float a, float b, float c) {
+#if FAT5_ASM_MAX3
+  // single instruction, no canonicalising v_max inserted by the compiler in front of it
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return fmaxf(fmaxf(a, b), c);
+#endif
+}
+FAT5_DEV float max16(const f32x16& s) {
+  const float a = max3f(s[0], s[1], s[2]), b = max3f(s[3], s[4], s[5]), c = max3f(s[6], s[7], s[8]);
+  const float d = max3f(s[9], s[10], s[11]), e = max3f(s[12], s[13], s[14]);
+  return max3f(max3f(a, b, c), max3f(d, e, s[15]), s[15]);
+}
+FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
+  float t[11];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    t[2 * i] = max3f(x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+    t[2 * i + 1] = max3f(y[3 * i], y[3 * i + 1], y[3 * i + 2]);
+  }
+  t[10] = max3f(x[15], y[15], t[0]);
+  const float u0 = max3f(t[1], t[2], t[3]), u1 = max3f(t[4], t[5], t[6]), u2 = max3f(t[7], t[8], t[9]);
+  return max3f(max3f(u0, u1, u2), t[10], t[10]);
+}
+
+#ifndef FAT5_PSUM_MFMA
+#define FAT5_PSUM_MFMA 1  // row sums of P on the matrix pipe (A = ones) instead of 32 VALU adds per tile
+#endif
+
+#ifndef FAT5_ABLATE
+#define FAT5_ABLATE 0  // developer ablations (bitmask): 1 no exp, 2 no max, 4 no staging/barrier, 8 no PV, 16 no QK
+#endif
+#ifndef FAT5_FWD_MINW
+#define FAT5_FWD_MINW 2  // waves per SIMD the register allocator must leave room for
+#endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_FWD_MINW)))
+void attn_fwd_kernel(const AttnArgs a) {
   using Cfg = FwdCfg<D, NW>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -104,137 +153,254 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     const int n1 = 2 * a.R + 1;
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i];
+    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;  // log2 units
   }
   const uint16_t* brow = nullptr;
   if constexpr (BIAS == FAT5_BIAS_DENSE)
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
+
+  FragAddr<D> fa;
+  fa.init(l);
 
   f32x16 oacc[DB];
 #pragma unroll
   for (int i = 0; i < DB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;  // running row max, log2 units
+#if FAT5_PSUM_MFMA
+  f32x16 lacc;              // every register = running row sum of (rounded) P for this lane's query
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  const uint32_t one2 = pack2<BF16>(1.f, 1.f);
+  const u32x4 ones = {one2, one2, one2, one2};
+#else
+  float l_run = 0.f;        // per-lane partial row sum
+#endif
 
-  PairStage<D, BN, NT> kst, vst;
+  RowStage<D, BN, NT> kst, vst;
+  kst.init(a.ks[2], tid);
+  vst.init(a.vs[2], tid);
+  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
+  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
+  const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   if (nt > 0) {
-    kst.load(kb_, a.ks[2], 0, N, tid);
-    vst.load(vb, a.vs[2], 0, N, tid);
+    kst.load_buf(krs, 0, tid);
+    vst.load_buf(vrs, 0, tid);
     kst.store_rm(smem, tid);
-    vst.store_tr(smem + Cfg::KBYTES, tid);
+    vst.store_rm(smem + Cfg::KBYTES, tid);
   }
   __syncthreads();
 
-  const float scale = a.scale;
-  for (int t = 0; t < nt; ++t) {
+  // Touch the Q fragments here: their global loads are otherwise still "pending" in the compiler's waitcnt model at
+  // the loop header, and every QK^T MFMA inside the loop then waits on vmcnt, i.e. on the K/V PREFETCH of its own tile.
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(qf[kk]));
+  const float c2 = a.scale * kLog2e;  // scores -> log2 units
+  const bool fold_ok = c2 > 0.f;      // max(s*c) = c*max(s) only for c > 0
+  float cst_neg = 0.f, cst_pos = 0.f;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    cst_neg = sT[0];
+    cst_pos = sT[2 * a.R];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // One K/V tile.  FAST: no key of the tile is masked for any row of the workgroup and the bias is one
+  // constant `cst` (none, or an all-far RPE tile): raw scores stay in registers, scale and constant are folded
+  // into the exponent FMA.  Otherwise the generic body handles masks / per-element bias per 32-key block.
+  auto tile = [&]<bool FAST, int BUF>(int t, float cst) {
     const int n0 = t * BN;
-    const char* sK = smem + (t & 1) * Cfg::STAGE;
+    const char* sK = smem + BUF * Cfg::STAGE;
     const char* sV = sK + Cfg::KBYTES;
     const bool more = (t + 1 < nt);
-    if (more) {
-      kst.load(kb_, a.ks[2], n0 + BN, N, tid);
-      vst.load(vb, a.vs[2], n0 + BN, N, tid);
+    // prefetch of the next tile through the buffer descriptors (zero-filled past row N-1 by the hardware)
+    if (!(FAT5_ABLATE & 4) && more) {
+      kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
+      vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
     }
-
-    // ---- S^T = K Q^T for the two 32-key blocks --------------------------------------------
-    f32x16 s[2];
+    // ---- S^T = K Q^T for both 32-key blocks first: all K fragments in flight, two independent MFMA chains
+    //      (the second block's MFMAs run under the first block's softmax VALU work) ----
+    f32x16 sblk[2];
+    {
+      u32x4 kf[2][KK];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        for (int kk = 0; kk < KK; ++kk) kf[kb][kk] = ld_rm<D>(sK, fa, kb, kk);
+      __builtin_amdgcn_sched_barrier(0);  // all K-fragment reads in flight before the first MFMA
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
-        s[kb] = mfma32<BF16>(frag_rm<D>(sK, 32 * kb + lq, kk, hi), qf[kk], s[kb]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          if (FAT5_ABLATE & 16) { sblk[kb] = zero16; sblk[kb][0] = __uint_as_float(qf[kk][0] & 0x3f800000u); continue; }
+          sblk[kb] = mfma32<BF16>(kf[kb][kk], qf[kk], kk == 0 ? zero16 : sblk[kb]);
+        }
     }
-
-    // ---- y = s*scale + bias (natural-log units), masks -------------------------------------
+    // ---- per block: online softmax -> O^T += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int nb = n0 + 32 * kb;
-      if constexpr (BIAS == FAT5_BIAS_DENSE) {
-        float bv[16];
-        load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
+      f32x16& s = sblk[kb];
+      u32x4 vfr[2][DB];  // V^T fragments of this block: issued now, consumed after the softmax
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = fmaf(s[kb][r], scale, bv[r]);
-      } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        const int R = a.R;
-        const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;  // wave-uniform
-        if (dmax <= -R || dmin >= R) {
-          const float c = (dmax <= -R) ? sT[0] : sT[2 * R];
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[kb][r] = fmaf(s[kb][r], scale, c);
+        for (int db = 0; db < DB; ++db) vfr[t2][db] = ld_tr<D>(sV, fa, kb, t2, db);
+      __builtin_amdgcn_sched_barrier(0);
+
+      float mul, add, mcand;
+      if constexpr (FAST) {
+        mul = c2;
+        add = cst;
+        mcand = (FAT5_ABLATE & 2) ? fmaf(s[0], c2, cst) : fmaf(max16(s), c2, cst);
+      } else {
+        bool folded = fold_ok;
+        float cb = 0.f;
+        if constexpr (BIAS == FAT5_BIAS_DENSE) {
+          folded = false;
+          float bv[16];
+          load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bv[r] * kLog2e);
+        } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          const int R = a.R;
+          const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;  // wave-uniform
+          if (dmax <= -R || dmin >= R) {
+            cb = (dmax <= -R) ? cst_neg : cst_pos;
+            if (!folded) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, cb);
+            }
+          } else {
+            folded = false;
+            const int dl = nb + 4 * hi - qrow;  // delta of r = 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int d = dl + (r & 3) + 8 * (r >> 2);
+              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
+            }
+          }
         } else {
-          const int dl = nb + 4 * hi - qrow;  // delta of r = 0
+          if (!folded) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = dl + (r & 3) + 8 * (r >> 2);
-            const int idx = min(max(d, -R), R) + R;
-            s[kb][r] = fmaf(s[kb][r], scale, sT[idx]);
+            for (int r = 0; r < 16; ++r) s[r] *= c2;
           }
         }
-      } else {
+        const bool nmask = nb + 32 > N;
+        const bool cmask = a.causal && (nb + 31 > qrow0 + P);
+        if (nmask || cmask) {
+          const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;  // last visible key of this row
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] *= scale;
+          for (int r = 0; r < 16; ++r)
+            if (nb + crow(r, hi) > lim) s[r] = -INFINITY;
+        }
+        const float m16 = max16(s);
+        mul = folded ? c2 : 1.f;
+        add = folded ? cb : 0.f;
+        mcand = folded ? fmaf(m16, c2, cb) : m16;  // -inf stays -inf (c2 > 0)
       }
-      const bool nmask = nb + 32 > N;
-      const bool cmask = a.causal && (nb + 31 > qrow0 + P);
-      if (nmask || cmask) {
-        const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;  // last visible key of this row
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (nb + crow(r, hi) > lim) s[kb][r] = -INFINITY;
-      }
-    }
 
-    // ---- online softmax ---------------------------------------------------------------------
-    float mx = s[0][0];
+      // online softmax (log2 domain), deferred rescale
+      mcand = fmaxf(mcand, xchg32(mcand));
+      if (__any(mcand > m_run + FAT5_DEFER_THR)) {
+        const float m_new = fmaxf(m_run, mcand);
+        const float alpha = fast_exp2(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+#if FAT5_PSUM_MFMA
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+#else
+        l_run *= alpha;
+#endif
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, xchg32(mx));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = fast_exp2((m_run - m_sub) * kLog2e);
-    const float nm = -m_sub * kLog2e;
-    float psum = 0.f;
+        for (int i = 0; i < DB; ++i)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        m_run = m_new;
+      }
+      const float ad = add - ((m_run == -INFINITY) ? 0.f : m_run);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[kb][r], kLog2e, nm));
-        s[kb][r] = p;
-        psum += p;
+        s[r] = (FAT5_ABLATE & 1) ? fmaf(s[r], mul, ad) : fast_exp2(fmaf(s[r], mul, ad));
+#if !FAT5_PSUM_MFMA
+        l_run += s[r];
+#endif
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-
-    // ---- O^T += V^T P^T ----------------------------------------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        const u32x4 pb = pack8<BF16>(s[kb], t2);
+        const u32x4 pb = pack8<BF16>(s, t2);
+        if (FAT5_ABLATE & 8) { asm volatile("" ::"v"(pb)); continue; }
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
-          oacc[db] = mfma32<BF16>(frag_tr<BN>(sV, 32 * db + lq, 32 * kb + 16 * t2 + 4 * hi), pb, oacc[db]);
+        for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(vfr[t2][db], pb, oacc[db]);
+#if FAT5_PSUM_MFMA
+        lacc = mfma32<BF16>(ones, pb, lacc);
+#endif
       }
-
-    if (more) {
-      char* nK = smem + ((t + 1) & 1) * Cfg::STAGE;
-      kst.store_rm(nK, tid);
-      vst.store_tr(nK + Cfg::KBYTES, tid);
     }
-    __syncthreads();
+
+    if (!(FAT5_ABLATE & 4)) {
+      if (more) {
+        char* nK = smem + (BUF ^ 1) * Cfg::STAGE;
+        kst.store_rm(nK, tid);
+        vst.store_rm(nK + Cfg::KBYTES, tid);
+      }
+      __syncthreads();
+    }
+  };
+
+  // Tile classes (workgroup-uniform), all boundaries rounded to EVEN tile indices so that every loop below runs
+  // (buffer 0, buffer 1) pairs of ONE body: accumulators stay in place (no register shuffles between bodies).
+  //   [0, ta)      FAST, constant cst_a  (no bias / all rows far-negative)
+  //   [ta, tb0)    generic
+  //   [tb0, tb1)   FAST, constant cst_b  (all rows far-positive)
+  //   [tb1, nt)    generic (N tail, causal diagonal)
+  int ta = 0, tb0 = 0, tb1 = 0;
+  float cst_a = 0.f, cst_b = 0.f;
+  if (fold_ok && BIAS != FAT5_BIAS_DENSE) {
+    int t_full = N / BN;                                            // tiles without an N tail
+    if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));  // n0 + BN - 1 <= m0 + P
+    t_full = min(t_full, nt);
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      const int lim_a = m0 - a.R - (BN - 1);                        // n0 + BN - 1 - m0 <= -R
+      ta = lim_a >= 0 ? min(t_full, lim_a / BN + 1) : 0;
+      const int lo = m0 + BM - 1 + a.R;                             // n0 - (m0 + BM - 1) >= R
+      tb0 = min(t_full, max(ta, (lo + BN - 1) / BN));
+      tb1 = t_full;
+      cst_a = cst_neg;
+      cst_b = cst_pos;
+    } else {
+      ta = t_full;
+    }
+    ta &= ~1;
+    tb0 = (tb0 + 1) & ~1;
+    tb1 &= ~1;
+    if (tb1 < tb0) tb0 = tb1 = ta;
   }
+  int t = 0;
+  for (; t < ta; t += 2) {
+    tile.template operator()<true, 0>(t, cst_a);
+    tile.template operator()<true, 1>(t + 1, cst_a);
+  }
+  const int g0 = min(max(tb0, ta), nt & ~1);
+  for (; t < g0; t += 2) {
+    tile.template operator()<false, 0>(t, 0.f);
+    tile.template operator()<false, 1>(t + 1, 0.f);
+  }
+  for (; t < tb1; t += 2) {
+    tile.template operator()<true, 0>(t, cst_b);
+    tile.template operator()<true, 1>(t + 1, cst_b);
+  }
+  for (; t + 1 < nt; t += 2) {
+    tile.template operator()<false, 0>(t, 0.f);
+    tile.template operator()<false, 1>(t + 1, 0.f);
+  }
+  if (t < nt) tile.template operator()<false, 0>(t, 0.f);
 
   // ---- epilogue: o = acc / l, L = m + ln(l) --------------------------------------------------
+#if FAT5_PSUM_MFMA
+  const float l_tot = lacc[0];
+#else
   const float l_tot = l_run + xchg32(l_run);
+#endif
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   if (qrow < M) {
     uint16_t* orow = ob + (int64_t)qrow * a.os[2];
@@ -247,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
         wv[1] = pack2<BF16>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
         *reinterpret_cast<u32x2*>(orow + 32 * db + 8 * g + 4 * hi) = wv;
       }
-    if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? m_run + fast_log2(l_tot) * kLn2 : -INFINITY;
+    if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run + fast_log2(l_tot)) * kLn2 : -INFINITY;
   }
 }
 

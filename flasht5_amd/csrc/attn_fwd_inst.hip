@@ -26,7 +26,9 @@ static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
 
 template <int D, bool BF16, int BIAS>
 static hipError_t launch_nw(const AttnArgs& a, int nw, int grid, hipStream_t s) {
-  return nw == 2 ? launch_one<D, BF16, BIAS, 2>(a, grid, s) : launch_one<D, BF16, BIAS, 4>(a, grid, s);
+  if (nw == 2) return launch_one<D, BF16, BIAS, 2>(a, grid, s);
+  if (nw == 8) return launch_one<D, BF16, BIAS, 8>(a, grid, s);
+  return launch_one<D, BF16, BIAS, 4>(a, grid, s);
 }
 template <int D, bool BF16>
 static hipError_t launch_bias(const AttnArgs& a, int bias, int nw, int grid, hipStream_t s) {
@@ -41,7 +43,7 @@ hipError_t CAT(launch_fwd_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias,
   return bf16 ? launch_bias<FAT5_INST_D, true>(a, bias, nw, grid, s) : launch_bias<FAT5_INST_D, false>(a, bias, nw, grid, s);
 }
 size_t CAT(smem_fwd_d, FAT5_INST_D)(int nw, int R, int bias) {
-  return nw == 2 ? FwdCfg<FAT5_INST_D, 2>::smem(R, bias) : FwdCfg<FAT5_INST_D, 4>::smem(R, bias);
+  return FwdCfg<FAT5_INST_D, 4>::smem(R, bias);  // independent of NW
 }
 
 }  // namespace fat5

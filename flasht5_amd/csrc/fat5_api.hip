@@ -44,11 +44,13 @@ struct BwdLayout {
   int nw_q, nw_kv;
 };
 
-int pick_nw(long ctas_at_nw4, const char* env) {
+int pick_nw(long ctas_at_nw4, const char* env, bool allow8 = false) {
   const int forced = env_int(env, 0);
-  if (forced == 2 || forced == 4) return forced;
+  if (forced == 2 || forced == 4 || (forced == 8 && allow8)) return forced;
   // below ~1.5 workgroups per CU a 4-wave tile leaves CUs idle: halve the tile
-  return ctas_at_nw4 < 384 ? 2 : 4;
+  if (ctas_at_nw4 < 384) return 2;
+  if (allow8 && ctas_at_nw4 >= 2048) return env_int("FAT5_DEFAULT_BIG_NW", 4);
+  return 4;
 }
 
 int check_common(const fat5_attn_params* p) {
@@ -67,7 +69,11 @@ int check_common(const fat5_attn_params* p) {
 }
 
 bool strides_ok(const void* ptr, const int64_t* s) {
-  return aligned16(ptr) && (s[0] % 8 == 0) && (s[1] % 8 == 0) && (s[2] % 8 == 0);
+  return aligned16(ptr) && (s[0] % 8 == 0) && (s[1] % 8 == 0) && (s[2] % 8 == 0) && s[2] > 0;
+}
+// the kernels address one (b,h) slice through a 32-bit buffer descriptor: its rows must span < 2 GiB
+bool slice_fits(int64_t rows, int64_t row_stride, int D) {
+  return ((rows - 1) * row_stride + D) * 2 < (int64_t(1) << 31);
 }
 
 void fill_common(const fat5_attn_params* p, AttnArgs& a) {
@@ -118,13 +124,15 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||
       !strides_ok(p->o, p->o_stride))
     return fail(FAT5_EINVAL, "fwd: q/k/v/o must be 16-byte aligned with strides that are multiples of 8 elements");
+  if (!slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) || !slice_fits(p->M, p->q_stride[2], p->D))
+    return fail(FAT5_EINVAL, "fwd: one (batch, head) slice must span less than 2 GiB");
   if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
   if (p->cu_seqlens_q && p->bias_mode != FAT5_BIAS_NONE) return fail(FAT5_EINVAL, "varlen supports bias_mode none only");
 
   AttnArgs a;
   fill_common(p, a);
   const long bh = (long)p->B * p->H;
-  const int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW");
+  const int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW", true);
   a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
   const long grid = bh * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");

@@ -1,0 +1,29 @@
+"""Run one attention kernel configuration a few times (for rocprofv3 --pmc / --kernel-trace runs).
+usage: python tools/run_one.py --S 8192 --mode none|rpe|dense --what fwd|bwd|both --iters 3 [--D 64] [--causal]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from attn_helpers import make_inputs
+from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+from flasht5_amd import positional_encoding as pe
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--S", type=int, default=8192); ap.add_argument("--mode", default="none"); ap.add_argument("--what", default="fwd")
+ap.add_argument("--iters", type=int, default=3); ap.add_argument("--D", type=int, default=64); ap.add_argument("--causal", action="store_true")
+ap.add_argument("--B", type=int, default=4); ap.add_argument("--H", type=int, default=12)
+a = ap.parse_args()
+q, k, v, _, do = make_inputs(a.B, a.H, a.S, a.S, a.D, torch.bfloat16, None, seed=1, strided=True)
+table = (torch.randn(32, a.H) * 0.5).cuda()
+kw = {}
+if a.mode == "rpe": kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128)
+elif a.mode == "dense": kw = dict(bias=pe.compute_bias(table, a.S, a.S).to(torch.bfloat16).contiguous())
+plan = AttentionPlan(q, k, v, do, causal=a.causal, sm_scale=0.125, **kw)
+plan.forward(); torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(a.iters):
+    if a.what in ("fwd", "both"): plan.forward()
+    if a.what in ("bwd", "both"): plan.backward()
+e.record(); torch.cuda.synchronize()
+print(f"{a.what} S={a.S} mode={a.mode}: {s.elapsed_time(e)/a.iters*1e3:.1f} us/iter")
