@@ -13,6 +13,12 @@
 //             dQ^T[d][q] += K^T . dS^T as the B operand without any cross-lane movement.
 //  kv kernel: S[q][k] and dP[q][k] (q in registers, keys on lanes) so that P / dS feed
 //             dV^T[d][k] += dO^T . P and dK^T[d][k] += Q^T . dS the same way.
+// Every streamed operand lives in ONE row-major swizzled LDS image: fragments whose contraction runs
+// along the row come from ds_read_b128, fragments whose contraction runs across rows (K^T, Q^T, dO^T)
+// from ds_read_b64_tr_b16 of the same image.  Tiles are prefetched through buffer descriptors
+// (rows past the end read as zero in hardware) one tile ahead, one barrier per tile.
+// Probabilities are recomputed in the exp2 domain: p = exp2(s*c2 + (bias2 - L2)), with sm_scale*log2e
+// and any tile-constant bias folded into the one FMA in front of v_exp_f32.
 #pragma once
 #include "attn_common.h"
 #include "attn_fwd.h"  // load_bias_block
@@ -27,17 +33,20 @@ struct BwdQCfg {
   static constexpr int BM = 32 * NW;
   static constexpr int BN = 64;
   static constexpr int NT = 64 * NW;
-  static constexpr int KRM = rm_bytes<D, BN>();  // K row-major
-  static constexpr int VRM = rm_bytes<D, BN>();  // V row-major
-  static constexpr int KTR = tr_bytes<D, BN>();  // K transposed
-  static constexpr int STAGE = KRM + VRM + KTR;
+  static constexpr int KRM = rm_bytes<D, BN>();
+  static constexpr int VRM = rm_bytes<D, BN>();
+  static constexpr int STAGE = KRM + VRM;
   static size_t smem(int R, int bias_mode) {
     return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0);
   }
 };
 
+#ifndef FAT5_BWD_MINW
+#define FAT5_BWD_MINW 2  // the register allocator must leave room for 2 waves per SIMD (<= 256 VGPR+AGPR)
+#endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+void attn_bwd_q_kernel(const AttnArgs a) {
   using Cfg = BwdQCfg<D, NW>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnArgs a) {
   const int qrow = qrow0 + lq;
   const int qrow_c = min(qrow, M - 1);
 
-  // Q and dO fragments (B operands), delta = rowsum(o * do)
+  // Q and dO fragments (B operands), delta = rowsum(o * do)  (reference _bwd_preprocess, :516-556)
   u32x4 qf[KK], dof[KK];
   float dsum = 0.f;
 #pragma unroll
@@ -85,112 +94,180 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnArgs a) {
   const float delta = dsum + xchg32(dsum);
   if (qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
   const float Lq = a.lse[stat_off + qrow_c];
-  // p = exp2(y*log2e - L*log2e); rows with L = -inf (fully masked) contribute nothing
-  const float nL = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
+  // p = exp2(x - L2); rows with L = -inf (fully masked) contribute nothing
+  const float nL2 = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
 
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     const int n1 = 2 * a.R + 1;
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i];
+    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;
   }
   const uint16_t* brow = nullptr;
   if constexpr (BIAS == FAT5_BIAS_DENSE)
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
 
+  FragAddr<D> fa;
+  fa.init(l);
   f32x16 dqacc[DB];
 #pragma unroll
   for (int i = 0; i < DB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
-  PairStage<D, BN, NT> kst, vst;
+  RowStage<D, BN, NT> kst, vst;
+  kst.init(a.ks[2], tid);
+  vst.init(a.vs[2], tid);
+  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
+  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
+  const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   if (nt > 0) {
-    kst.load(kb_, a.ks[2], 0, N, tid);
-    vst.load(vb, a.vs[2], 0, N, tid);
+    kst.load_buf(krs, 0, tid);
+    vst.load_buf(vrs, 0, tid);
     kst.store_rm(smem, tid);
     vst.store_rm(smem + Cfg::KRM, tid);
-    kst.store_tr(smem + Cfg::KRM + Cfg::VRM, tid);
   }
   __syncthreads();
+  // see attn_fwd.h: keep the compiler's waitcnt model from chaining the loop's MFMAs to the tile prefetch
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(qf[kk]), "v"(dof[kk]));
+  asm volatile("" ::"v"(nL2), "v"(delta));
 
-  const float scale = a.scale;
-  for (int t = 0; t < nt; ++t) {
+  const float c2 = a.scale * kLog2e;
+  float cst_neg = 0.f, cst_pos = 0.f;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    cst_neg = sT[0];
+    cst_pos = sT[2 * a.R];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto tile = [&]<bool FAST, int BUF>(int t, float cst) {
     const int n0 = t * BN;
-    const char* sK = smem + (t & 1) * Cfg::STAGE;
+    const char* sK = smem + BUF * Cfg::STAGE;
     const char* sV = sK + Cfg::KRM;
-    const char* sKt = sV + Cfg::VRM;
     const bool more = (t + 1 < nt);
     if (more) {
-      kst.load(kb_, a.ks[2], n0 + BN, N, tid);
-      vst.load(vb, a.vs[2], n0 + BN, N, tid);
+      kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
+      vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int nb = n0 + 32 * kb;
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      u32x4 kf[KK], vf[KK];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        s = mfma32<BF16>(frag_rm<D>(sK, 32 * kb + lq, kk, hi), qf[kk], s);
-        dp = mfma32<BF16>(frag_rm<D>(sV, 32 * kb + lq, kk, hi), dof[kk], dp);
+        kf[kk] = ld_rm<D>(sK, fa, kb, kk);
+        vf[kk] = ld_rm<D>(sV, fa, kb, kk);
       }
-      if constexpr (BIAS == FAT5_BIAS_DENSE) {
-        float bv[16];
-        load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
+      f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], scale, bv[r]);
-      } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        const int R = a.R;
-        const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;
-        if (dmax <= -R || dmin >= R) {
-          const float c = (dmax <= -R) ? sT[0] : sT[2 * R];
+      for (int kk = 0; kk < KK; ++kk) {
+        s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);      // S^T  = K Q^T
+        dp = mfma32<BF16>(vf[kk], dof[kk], kk == 0 ? zero16 : dp);   // dP^T = V dO^T
+      }
+      if constexpr (FAST) {
+        const float ad = cst + nL2;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], scale, c);
-        } else {
-          const int dl = nb + 4 * hi - qrow;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = dl + (r & 3) + 8 * (r >> 2);
-            s[r] = fmaf(s[r], scale, sT[min(max(d, -R), R) + R]);
-          }
-        }
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, ad)) * (dp[r] - delta);
       } else {
+        if constexpr (BIAS == FAT5_BIAS_DENSE) {
+          float bv[16];
+          load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= scale;
-      }
-      // p = exp(y - L), ds = p * (dp - delta)
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, fmaf(bv[r], kLog2e, nL2));
+        } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          const int R = a.R;
+          const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;
+          if (dmax <= -R || dmin >= R) {
+            const float ad = ((dmax <= -R) ? cst_neg : cst_pos) + nL2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(fmaf(s[r], kLog2e, nL));
-        s[r] = p * (dp[r] - delta);
-      }
-      const bool nmask = nb + 32 > N;
-      const bool cmask = a.causal && (nb + 31 > qrow0 + P);
-      if (nmask || cmask) {
-        const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, ad);
+          } else if (dmin > -R && dmax < R) {
+            const float* tp = sT + (R + nb + 4 * hi - qrow);  // interior of the band: base + immediate offsets
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (nb + crow(r, hi) > lim) s[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[(r & 3) + 8 * (r >> 2)] + nL2);
+          } else {
+            const int dl = nb + 4 * hi - qrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int d = dl + (r & 3) + 8 * (r >> 2);
+              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nL2);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nL2);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * (dp[r] - delta);  // dS = P (dP - delta)   (:713)
+        const bool nmask = nb + 32 > N;
+        const bool cmask = a.causal && (nb + 31 > qrow0 + P);
+        if (nmask || cmask) {
+          const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (nb + crow(r, hi) > lim) s[r] = 0.f;
+        }
       }
-      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (dS rounded to the input dtype like the reference, :720)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const u32x4 dsb = pack8<BF16>(s, t2);
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
-          dqacc[db] = mfma32<BF16>(frag_tr<BN>(sKt, 32 * db + lq, 32 * kb + 16 * t2 + 4 * hi), dsb, dqacc[db]);
+        for (int db = 0; db < DB; ++db) dqacc[db] = mfma32<BF16>(ld_tr<D>(sK, fa, kb, t2, db), dsb, dqacc[db]);
       }
     }
     if (more) {
-      char* nK = smem + ((t + 1) & 1) * Cfg::STAGE;
+      char* nK = smem + (BUF ^ 1) * Cfg::STAGE;
       kst.store_rm(nK, tid);
       vst.store_rm(nK + Cfg::KRM, tid);
-      kst.store_tr(nK + Cfg::KRM + Cfg::VRM, tid);
     }
     __syncthreads();
+  };
+
+  // tile classes as in the forward (boundaries rounded to even tile indices: one body per loop)
+  int ta = 0, tb0 = 0, tb1 = 0;
+  float cst_a = 0.f, cst_b = 0.f;
+  if (BIAS != FAT5_BIAS_DENSE) {
+    int t_full = N / BN;
+    if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));
+    t_full = min(t_full, nt);
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      const int lim_a = m0 - a.R - (BN - 1);
+      ta = lim_a >= 0 ? min(t_full, lim_a / BN + 1) : 0;
+      const int lo = m0 + BM - 1 + a.R;
+      tb0 = min(t_full, max(ta, (lo + BN - 1) / BN));
+      tb1 = t_full;
+      cst_a = cst_neg;
+      cst_b = cst_pos;
+    } else {
+      ta = t_full;
+    }
+    ta &= ~1;
+    tb0 = (tb0 + 1) & ~1;
+    tb1 &= ~1;
+    if (tb1 < tb0) tb0 = tb1 = ta;
   }
+  int t = 0;
+  for (; t < ta; t += 2) {
+    tile.template operator()<true, 0>(t, cst_a);
+    tile.template operator()<true, 1>(t + 1, cst_a);
+  }
+  const int g0 = min(max(tb0, ta), nt & ~1);
+  for (; t < g0; t += 2) {
+    tile.template operator()<false, 0>(t, 0.f);
+    tile.template operator()<false, 1>(t + 1, 0.f);
+  }
+  for (; t < tb1; t += 2) {
+    tile.template operator()<true, 0>(t, cst_b);
+    tile.template operator()<true, 1>(t + 1, cst_b);
+  }
+  for (; t + 1 < nt; t += 2) {
+    tile.template operator()<false, 0>(t, 0.f);
+    tile.template operator()<false, 1>(t + 1, 0.f);
+  }
+  if (t < nt) tile.template operator()<false, 0>(t, 0.f);
 
   if (qrow < M) {
+    const float scale = a.scale;
     uint16_t* drow = dqb + (int64_t)qrow * a.dqs[2];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -213,17 +290,20 @@ struct BwdKVCfg {
   static constexpr int BMQ = 64;       // query rows per loop step
   static constexpr int NT = 64 * NW;
   static constexpr int QRM = rm_bytes<D, BMQ>();
-  static constexpr int QTR = tr_bytes<D, BMQ>();
   static constexpr int STAT = BMQ * 4 * 2;  // -L*log2e and delta for the BMQ rows
-  static constexpr int STAGE = 2 * QRM + 2 * QTR + STAT;
+  static constexpr int STAGE = 2 * QRM + STAT;
   static size_t smem(int R, int bias_mode) {
     // rpe: table + one private accumulator per wave
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 * (1 + NW) + 64 : 0);
+    // rpe: table + one private diagonal accumulator per wave + one private 32x64 fp32 skew tile per wave
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * 8192 : 0);
+  }
+  static __host__ __device__ size_t rpe_off(int R) { return ((size_t)(2 * R + 1) * 4 * (1 + NW) + 63) / 64 * 64;
   }
 };
 
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+void attn_bwd_kv_kernel(const AttnArgs a) {
   using Cfg = BwdKVCfg<D, NW>;
   constexpr int BNK = Cfg::BNK, BMQ = Cfg::BMQ, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -261,11 +341,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) 
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
   const int n1 = 2 * a.R + 1;
   float* sD = sT + n1 + w * n1;
+  // Per-wave 32x64 fp32 "skew tile": row q of a near block is stored shifted by -q so that diagonals become columns;
+  // one column sum per lane then replaces 16 LDS float atomics per lane (ds_add_f32 costs ~600 cycles per wave
+  // instruction on gfx950 -- measured; tools/time_kv.py).
+  float* sG = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + Cfg::rpe_off(a.R)) + w * 2048;
   float far_neg = 0.f, far_pos = 0.f;
+  auto tree16 = [](const f32x16& x) {  // balanced tree: no long dependent chain, one live register afterwards
+    const float t0 = (x[0] + x[1]) + (x[2] + x[3]), t1 = (x[4] + x[5]) + (x[6] + x[7]);
+    const float t2 = (x[8] + x[9]) + (x[10] + x[11]), t3 = (x[12] + x[13]) + (x[14] + x[15]);
+    return (t0 + t1) + (t2 + t3);
+  };
   const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i];
+    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;
     for (int i = tid; i < n1 * NW; i += NT) sT[n1 + i] = 0.f;
+    for (int i = l; i < 2048; i += 64) sG[i] = 0.f;
   }
   const uint16_t* bbase = nullptr;
   uint16_t* dsbase = nullptr;
@@ -274,6 +364,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) 
     if (a.ds_out) dsbase = a.ds_out + (int64_t)b * a.dss[0] + (int64_t)h * a.dss[1];
   }
 
+  FragAddr<D> fa;
+  fa.init(l);
   f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
   for (int i = 0; i < DB; ++i)
@@ -285,110 +377,153 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) 
   if (a.causal) m_lo = max(0, n0 - P) / BMQ * BMQ;
   const int mt0 = m_lo / BMQ;
   const int mt1 = (M + BMQ - 1) / BMQ;
+  const int ntile = mt1 - mt0;
 
-  PairStage<D, BMQ, NT> qst, dost;
-  auto stage_stats = [&](char* st, int mrow0) {
-    float* sL = reinterpret_cast<float*>(st + 2 * Cfg::QRM + 2 * Cfg::QTR);
-    for (int i = tid; i < BMQ; i += NT) {
-      const int m = mrow0 + i;
-      float nl = -INFINITY, dl = 0.f;
+  RowStage<D, BMQ, NT> qst, dost;
+  qst.init(a.qs[2], tid);
+  dost.init(a.dos[2], tid);
+  const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
+  const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
+  const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
+  // row statistics of a tile: -L*log2e (or -inf for rows that contribute nothing) and delta
+  float st_l = 0.f, st_d = 0.f;
+  auto load_stats = [&](int mrow0) {
+    if (tid < BMQ) {
+      const int m = mrow0 + tid;
+      st_l = -INFINITY;
+      st_d = 0.f;
       if (m < M) {
         const float L = a.lse[stat_off + m];
-        nl = (L == -INFINITY) ? -INFINITY : -L * kLog2e;
-        dl = a.delta[stat_off + m];
+        st_l = (L == -INFINITY) ? -INFINITY : -L * kLog2e;
+        st_d = a.delta[stat_off + m];
       }
-      sL[i] = nl;
-      sL[BMQ + i] = dl;
     }
   };
-  if (mt0 < mt1) {
-    qst.load(qb, a.qs[2], mt0 * BMQ, M, tid);
-    dost.load(dob, a.dos[2], mt0 * BMQ, M, tid);
+  auto store_stats = [&](char* st) {
+    if (tid < BMQ) {
+      float* sL = reinterpret_cast<float*>(st + 2 * Cfg::QRM);
+      sL[tid] = st_l;
+      sL[BMQ + tid] = st_d;
+    }
+  };
+  if (ntile > 0) {
+    qst.load_buf(qrs, (uint32_t)(mt0 * BMQ) * qstride_b, tid);
+    dost.load_buf(dors, (uint32_t)(mt0 * BMQ) * dostride_b, tid);
+    load_stats(mt0 * BMQ);
     qst.store_rm(smem, tid);
     dost.store_rm(smem + Cfg::QRM, tid);
-    qst.store_tr(smem + 2 * Cfg::QRM, tid);
-    dost.store_tr(smem + 2 * Cfg::QRM + Cfg::QTR, tid);
-    stage_stats(smem, mt0 * BMQ);
+    store_stats(smem);
   }
   __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(kf[kk]), "v"(vf[kk]));
 
-  const float scale = a.scale;
-  for (int mt = mt0; mt < mt1; ++mt) {
+  const float c2 = a.scale * kLog2e;
+  float cst_neg = 0.f, cst_pos = 0.f;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    cst_neg = sT[0];
+    cst_pos = sT[2 * a.R];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // One 64-query tile.  FAST: nothing of the tile is masked for any key of the workgroup and the bias is the
+  // constant `cst` (none / all-far RPE); FARSIDE (RPE only): -1 far-negative, +1 far-positive, 0 not applicable.
+  auto tile = [&]<bool FAST, int BUF, int FARSIDE>(int mt, float cst) {
     const int mrow0 = mt * BMQ;
-    const int buf = (mt - mt0) & 1;
-    const char* sQ = smem + buf * Cfg::STAGE;
+    const char* sQ = smem + BUF * Cfg::STAGE;
     const char* sDO = sQ + Cfg::QRM;
-    const char* sQt = sDO + Cfg::QRM;
-    const char* sDOt = sQt + Cfg::QTR;
-    const float* sL = reinterpret_cast<const float*>(sDOt + Cfg::QTR);
+    const float* sL = reinterpret_cast<const float*>(sDO + Cfg::QRM);
     const bool more = (mt + 1 < mt1);
     if (more) {
-      qst.load(qb, a.qs[2], mrow0 + BMQ, M, tid);
-      dost.load(dob, a.dos[2], mrow0 + BMQ, M, tid);
+      qst.load_buf(qrs, (uint32_t)(mrow0 + BMQ) * qstride_b, tid);
+      dost.load_buf(dors, (uint32_t)(mrow0 + BMQ) * dostride_b, tid);
+      load_stats(mrow0 + BMQ);
     }
 #pragma unroll
     for (int qbk = 0; qbk < 2; ++qbk) {
       const int mb = mrow0 + 32 * qbk;  // first query row of this 32-row block
+      // S = Q K^T first (its own fragment registers die before dP = dO V^T is formed: the kernel runs at the
+      // 256-register limit of 2 waves per SIMD)
       f32x16 s, dp;
+      {
+        u32x4 qa[KK];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int kk = 0; kk < KK; ++kk) qa[kk] = ld_rm<D>(sQ, fa, qbk, kk);
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        s = mfma32<BF16>(frag_rm<D>(sQ, 32 * qbk + lq, kk, hi), kf[kk], s);
-        dp = mfma32<BF16>(frag_rm<D>(sDO, 32 * qbk + lq, kk, hi), vf[kk], dp);
+        for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(qa[kk], kf[kk], kk == 0 ? zero16 : s);
       }
-      // C layout: lane (key = krow, hi), register r <-> query row mb + crow(r, hi)
-      if constexpr (BIAS == FAT5_BIAS_DENSE) {
+      {
+        u32x4 da[KK];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + crow(r, hi);
-          const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
-          s[r] = fmaf(s[r], scale, bvl);
-        }
-      } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        const int R = a.R;
-        const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
-        if (dmax <= -R || dmin >= R) {
-          const float c = (dmax <= -R) ? sT[0] : sT[2 * R];
+        for (int kk = 0; kk < KK; ++kk) da[kk] = ld_rm<D>(sDO, fa, qbk, kk);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], scale, c);
-        } else {
-          const int dl = krow - mb - 4 * hi;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = dl - ((r & 3) + 8 * (r >> 2));
-            s[r] = fmaf(s[r], scale, sT[min(max(d, -R), R) + R]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= scale;
+        for (int kk = 0; kk < KK; ++kk) dp = mfma32<BF16>(da[kk], vf[kk], kk == 0 ? zero16 : dp);
       }
-      // per-row statistics for rows mb + 8g + 4hi + (0..3)
-      f32x16 p;
+      // row statistics for rows mb + 8g + 4hi + (0..3)
+      float nl[16], dl[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 nl4 = *reinterpret_cast<const float4*>(sL + 32 * qbk + 8 * g + 4 * hi);
         const float4 dl4 = *reinterpret_cast<const float4*>(sL + BMQ + 32 * qbk + 8 * g + 4 * hi);
-        const float nl[4] = {nl4.x, nl4.y, nl4.z, nl4.w};
-        const float dl[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          const float pv = fast_exp2(fmaf(s[r], kLog2e, nl[j]));
-          p[r] = pv;
-          s[r] = pv * (dp[r] - dl[j]);
-        }
+        nl[4 * g] = nl4.x; nl[4 * g + 1] = nl4.y; nl[4 * g + 2] = nl4.z; nl[4 * g + 3] = nl4.w;
+        dl[4 * g] = dl4.x; dl[4 * g + 1] = dl4.y; dl[4 * g + 2] = dl4.z; dl[4 * g + 3] = dl4.w;
       }
-      const bool nmask = krow0 + 32 > N;
-      const bool cmask = a.causal && (krow0 + 31 > mb + P);
-      if (nmask || cmask) {
-        // key visible to query m iff krow <= m + P (and krow < N)
+      // C layout: lane (key = krow, hi), register r <-> query row mb + crow(r, hi)
+      f32x16 p;
+      if constexpr (FAST) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + crow(r, hi);
-          const bool ok = (krow < N) && (!a.causal || krow <= m + P);
-          if (!ok) { p[r] = 0.f; s[r] = 0.f; }
+          p[r] = fast_exp2(fmaf(s[r], c2, cst + nl[r]));
+          s[r] = p[r] * (dp[r] - dl[r]);
+        }
+      } else {
+        if constexpr (BIAS == FAT5_BIAS_DENSE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + crow(r, hi);
+            const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
+            s[r] = fmaf(s[r], c2, fmaf(bvl, kLog2e, nl[r]));
+          }
+        } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          const int R = a.R;
+          const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
+          if (dmax <= -R || dmin >= R) {
+            const float c = (dmax <= -R) ? cst_neg : cst_pos;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c + nl[r]);
+          } else if (dmin > -R && dmax < R) {
+            const float* tp = sT + (R + krow - mb - 4 * hi - 27);  // interior of the band: base + immediate offsets
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[27 - ((r & 3) + 8 * (r >> 2))] + nl[r]);
+          } else {
+            const int d0 = krow - mb - 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int d = d0 - ((r & 3) + 8 * (r >> 2));
+              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nl[r]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nl[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] = fast_exp2(s[r]);
+          s[r] = p[r] * (dp[r] - dl[r]);
+        }
+        const bool nmask = krow0 + 32 > N;
+        const bool cmask = a.causal && (krow0 + 31 > mb + P);
+        if (nmask || cmask) {
+          // key visible to query m iff krow < N and (causal) krow <= m + P  <=>  crow(r,hi) >= thr  (per-lane thr)
+          int thr = a.causal ? (krow - P - mb) : -(1 << 30);
+          if (krow >= N) thr = 1 << 30;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = crow(r, hi) >= thr;
+            p[r] = ok ? p[r] : 0.f;
+            s[r] = ok ? s[r] : 0.f;
+          }
         }
       }
       // ---- bias gradient ------------------------------------------------------------------
@@ -401,48 +536,119 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) 
           }
         }
       } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+#ifndef FAT5_ABL_KV
+#define FAT5_ABL_KV 0
+#endif
         if (want_drpe) {
-          const int R = a.R;
-          const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
-          if (dmax <= -R || dmin >= R) {
-            float acc = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc += s[r];
-            if (dmax <= -R) far_neg += acc; else far_pos += acc;
+          if constexpr (FAST) {
+            if constexpr (FARSIDE < 0) far_neg += tree16(s); else far_pos += tree16(s);
           } else {
-            const int dl = krow - mb - 4 * hi;
+            const int R = a.R;
+            const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
+            if (dmax <= -R || dmin >= R) {
+              const float acc = (FAT5_ABL_KV & 2) ? s[0] : tree16(s);
+              if (dmax <= -R) far_neg += acc; else far_pos += acc;
+            } else {
+              // near block: skew-store (element (q, k) -> row q, column k - q + 31: a fixed set of positions per row,
+              // the rest of the tile stays zero), column sums, then ONE update per lane of its diagonal's bin
+              float* gw = sG + (4 * hi) * 63 + lq + 31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int d = dl - ((r & 3) + 8 * (r >> 2));
-              atomicAdd(&sD[min(max(d, -R), R) + R], s[r]);
+              for (int r = 0; r < 16; ++r) gw[((r & 3) + 8 * (r >> 2)) * 63] = (FAT5_ABL_KV & 1) ? 0.f : s[r];
+              float c0 = 0.f, c1 = 0.f, c2s = 0.f, c3 = 0.f;
+#pragma unroll
+              for (int qq = 0; qq < 32; qq += 4) {
+                c0 += sG[(qq + 0) * 64 + l];
+                c1 += sG[(qq + 1) * 64 + l];
+                c2s += sG[(qq + 2) * 64 + l];
+                c3 += sG[(qq + 3) * 64 + l];
+              }
+              const float cs = (c0 + c1) + (c2s + c3);
+              const int dbin = krow0 - mb - 31 + l;  // diagonal of this lane's column
+              if (dbin <= -R) far_neg += cs;
+              else if (dbin >= R) far_pos += cs;
+              else sD[dbin + R] += cs;  // wave-private array, distinct addresses across the lanes: plain read-modify-write
             }
           }
         }
       }
-      // ---- dV^T += dO^T P ;  dK^T += Q^T dS -------------------------------------------------
+      // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A fragments: transposed reads of the dO / Q images) -----
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const u32x4 pb = pack8<BF16>(p, t2);
         const u32x4 dsb = pack8<BF16>(s, t2);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          dvacc[db] = mfma32<BF16>(frag_tr<BMQ>(sDOt, 32 * db + lq, 32 * qbk + 16 * t2 + 4 * hi), pb, dvacc[db]);
-          dkacc[db] = mfma32<BF16>(frag_tr<BMQ>(sQt, 32 * db + lq, 32 * qbk + 16 * t2 + 4 * hi), dsb, dkacc[db]);
+          dvacc[db] = mfma32<BF16>(ld_tr<D>(sDO, fa, qbk, t2, db), pb, dvacc[db]);
+          dkacc[db] = mfma32<BF16>(ld_tr<D>(sQ, fa, qbk, t2, db), dsb, dkacc[db]);
         }
       }
     }
     if (more) {
-      char* nb_ = smem + (buf ^ 1) * Cfg::STAGE;
+      char* nb_ = smem + (BUF ^ 1) * Cfg::STAGE;
       qst.store_rm(nb_, tid);
       dost.store_rm(nb_ + Cfg::QRM, tid);
-      qst.store_tr(nb_ + 2 * Cfg::QRM, tid);
-      dost.store_tr(nb_ + 2 * Cfg::QRM + Cfg::QTR, tid);
-      stage_stats(nb_, mrow0 + BMQ);
+      store_stats(nb_);
     }
     __syncthreads();
+  };
+
+  // Tile classes over mt in [mt0, mt1) relative index i = mt - mt0 (even boundaries, see attn_fwd.h).
+  // Increasing m means decreasing delta = k - q:  [far-positive FAST] [generic] [far-negative FAST] [generic tail].
+  int ia = 0, ib0 = 0, ib1 = 0;  // FAST for i < ia (cst_a) and ib0 <= i < ib1 (cst_b)
+  float cst_a = 0.f, cst_b = 0.f;
+  const bool key_tail = n0 + BNK > N;
+#ifndef FAT5_BWD_NOFAST
+#define FAT5_BWD_NOFAST 0
+#endif
+  if (!FAT5_BWD_NOFAST && BIAS != FAT5_BIAS_DENSE && !key_tail) {
+    int mt_full = M / BMQ;  // tiles without an M tail
+    int mt_first = mt0;     // causal: first tile where every key of the workgroup is visible to every row
+    if (a.causal) mt_first = max(mt0, (max(0, n0 + BNK - 1 - P) + BMQ - 1) / BMQ);
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      // far-positive: n0 - (mrow0 + BMQ - 1) >= R  <=>  mrow0 <= n0 - R - (BMQ - 1)
+      const int lim_p = n0 - a.R - (BMQ - 1);
+      const int mt_p_end = lim_p >= 0 ? lim_p / BMQ + 1 : 0;   // tiles [mt_first, mt_p_end) are far-positive
+      // far-negative: n0 + BNK - 1 - mrow0 <= -R  <=>  mrow0 >= n0 + BNK - 1 + R
+      const int mt_n_beg = (n0 + BNK - 1 + a.R + BMQ - 1) / BMQ;
+      if (!a.causal) {  // (with a causal mask positive deltas are masked, never FAST)
+        ia = max(0, min(mt_p_end, mt_full) - mt0);
+        if (mt_first > mt0) ia = 0;
+      }
+      ib1 = max(ia, mt_full - mt0);
+      ib0 = min(ib1, max(ia, max(mt_n_beg, mt_first) - mt0));
+      cst_a = cst_pos;
+      cst_b = cst_neg;
+    } else {
+      ib1 = max(0, mt_full - mt0);
+      ib0 = min(ib1, max(0, mt_first - mt0));
+    }
+    ia &= ~1;
+    ib0 = (ib0 + 1) & ~1;
+    ib1 &= ~1;
+    if (ib1 < ib0) ib0 = ib1 = ia;
   }
+  int i = 0;
+  for (; i < ia; i += 2) {
+    tile.template operator()<true, 0, 1>(mt0 + i, cst_a);
+    tile.template operator()<true, 1, 1>(mt0 + i + 1, cst_a);
+  }
+  const int g0 = min(max(ib0, ia), ntile & ~1);
+  for (; i < g0; i += 2) {
+    tile.template operator()<false, 0, 0>(mt0 + i, 0.f);
+    tile.template operator()<false, 1, 0>(mt0 + i + 1, 0.f);
+  }
+  for (; i < ib1; i += 2) {
+    tile.template operator()<true, 0, -1>(mt0 + i, cst_b);
+    tile.template operator()<true, 1, -1>(mt0 + i + 1, cst_b);
+  }
+  for (; i + 1 < ntile; i += 2) {
+    tile.template operator()<false, 0, 0>(mt0 + i, 0.f);
+    tile.template operator()<false, 1, 0>(mt0 + i + 1, 0.f);
+  }
+  if (i < ntile) tile.template operator()<false, 0, 0>(mt0 + i, 0.f);
 
   if (krow < N) {
+    const float scale = a.scale;
     uint16_t* dkrow = dkb + (int64_t)krow * a.dks[2];
     uint16_t* dvrow = dvb + (int64_t)krow * a.dvs[2];
 #pragma unroll
@@ -467,17 +673,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnArgs a) 
         far_neg += __shfl_xor(far_neg, off, 64);
         far_pos += __shfl_xor(far_pos, off, 64);
       }
-      if (l == 0) {
+      if (l == 0) {  // lane 0 has hi = 0: its sD is the wave's first array
         sD[0] += far_neg;
         sD[2 * a.R] += far_pos;
       }
       __syncthreads();
       float* out = a.drpe_part + ((int64_t)bh * a.n_nblk + nblk) * n1;
-      for (int i = tid; i < n1; i += NT) {
+      for (int i2 = tid; i2 < n1; i2 += NT) {
         float acc = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) acc += sT[n1 + ww * n1 + i];
-        out[i] = acc;
+        for (int ww = 0; ww < NW; ++ww) acc += sT[n1 + ww * n1 + i2];
+        out[i2] = acc;
       }
     }
   }

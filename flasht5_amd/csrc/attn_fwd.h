@@ -271,6 +271,12 @@ void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, cb);
             }
+          } else if (dmin > -R && dmax < R) {
+            // interior of the band: no clamping -> the 16 gathers are base + immediate offset, no index VALU
+            folded = false;
+            const float* tp = sT + (R + nb + 4 * hi - qrow);  // entry of r = 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[(r & 3) + 8 * (r >> 2)]);
           } else {
             folded = false;
             const int dl = nb + 4 * hi - qrow;  // delta of r = 0
