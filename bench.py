@@ -42,7 +42,8 @@ def make_plan(S, mode, device, seed):
     table = (torch.randn(NUM_BUCKETS, H, generator=g) * 0.5).to(device)
     kw = {}
     if mode == "rpe":
-        kw = dict(rpe1d=pe.rpe1d_from_table(table, True, NUM_BUCKETS, MAX_DISTANCE), radius=MAX_DISTANCE)
+        kw = dict(rpe1d=pe.rpe1d_from_table(table, True, NUM_BUCKETS, MAX_DISTANCE), radius=MAX_DISTANCE,
+                  rpe_bucket=pe.bucket_index32(MAX_DISTANCE, True, NUM_BUCKETS, MAX_DISTANCE, device), num_buckets=NUM_BUCKETS)
     elif mode == "dense":
         kw = dict(bias=pe.compute_bias(table, S, S, True, NUM_BUCKETS, MAX_DISTANCE).to(torch.bfloat16).contiguous())
     plan = AttentionPlan(q, k, v, do, causal=False, sm_scale=0.125, **kw)
@@ -137,14 +138,10 @@ def main():
     import flasht5_amd  # noqa: F401  raises if libfat5.so is missing
     S, mode = args.seq, args.mode
     plan, table, idx = make_plan(S, mode, device, seed=rank)
-    dtable = torch.zeros(NUM_BUCKETS, H, dtype=torch.float32, device=device)
 
     def step_local():
         plan.forward()
-        plan.backward()
-        if mode == "rpe":  # scatter the (H, 2R+1) diagonal sums into the (32, H) table gradient
-            dtable.zero_()
-            dtable.index_add_(0, idx, plan.dbias.transpose(0, 1))
+        plan.backward()  # rpe mode: plan.dbias is the (32, H) table gradient, written by the reduction launch
 
     # ---- capture the local part of a step in a HIP graph (launch-bound at S = 512) ----
     for _ in range(3):
@@ -169,7 +166,7 @@ def main():
             step_local()
         if world > 1 and mode != "none":
             # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI
-            dist.all_reduce(dtable if mode == "rpe" else plan.dbias, op=dist.ReduceOp.SUM)
+            dist.all_reduce(plan.dbias, op=dist.ReduceOp.SUM)
 
     for _ in range(args.warmup):
         step()

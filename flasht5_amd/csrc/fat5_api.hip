@@ -47,8 +47,8 @@ struct BwdLayout {
 int pick_nw(long ctas_at_nw4, const char* env, bool allow8 = false) {
   const int forced = env_int(env, 0);
   if (forced == 2 || forced == 4 || (forced == 8 && allow8)) return forced;
-  // below ~1.5 workgroups per CU a 4-wave tile leaves CUs idle: halve the tile
-  if (ctas_at_nw4 < 384) return 2;
+  // measured at S = 512 (tools/time_b.py): the 4-wave tile wins down to ~0.75 workgroups per CU
+  if (ctas_at_nw4 < 160) return 2;
   if (allow8 && ctas_at_nw4 >= 2048) return env_int("FAT5_DEFAULT_BIG_NW", 4);
   return 4;
 }
@@ -160,7 +160,7 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     }
   }
   L.drpe_off = off;
-  if (p->bias_mode == FAT5_BIAS_RPE1D && p->drpe1d)
+  if (p->bias_mode == FAT5_BIAS_RPE1D && (p->drpe1d || p->drpe_table))
     off = align_up(off + (size_t)bh * L.n_nblk * (2 * p->rpe_radius + 1) * sizeof(float), 256);
   L.total = off;
   return FAT5_OK;
@@ -220,7 +220,11 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       if (e != hipSuccess) return hip_fail(e, "memset ds");
     }
   }
-  if (p->bias_mode == FAT5_BIAS_RPE1D && p->drpe1d) a.drpe_part = (float*)(ws + L.drpe_off);
+  if (p->bias_mode == FAT5_BIAS_RPE1D && (p->drpe1d || p->drpe_table)) {
+    if (p->drpe_table && (!p->rpe_bucket || p->rpe_num_buckets <= 0))
+      return fail(FAT5_EINVAL, "bwd: drpe_table needs rpe_bucket and rpe_num_buckets");
+    a.drpe_part = (float*)(ws + L.drpe_off);
+  }
 
   // 1) dQ (+ delta)
   a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
@@ -251,8 +255,9 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   }
   if (a.drpe_part && (stages & FAT5_BWD_REDUCE)) {
     const int n1 = 2 * p->rpe_radius + 1;
-    const int grid = (p->H * n1 + 255) / 256;
-    hipLaunchKernelGGL(drpe_reduce_kernel, dim3(grid), dim3(256), 0, stream, a.drpe_part, p->drpe1d, p->B, p->H, a.n_nblk, n1);
+    const size_t smem = (size_t)n1 * 24;
+    hipLaunchKernelGGL(drpe_reduce_kernel, dim3(p->H), dim3(1024), smem, stream, a.drpe_part, p->drpe1d, p->rpe_bucket,
+                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
   }

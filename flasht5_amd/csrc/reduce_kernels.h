@@ -56,16 +56,46 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
   }
 }
 
-// drpe1d[h][i] = sum_b sum_blk part[(b*H + h)*nblk + blk][i], fixed order.
-__global__ __launch_bounds__(256) void drpe_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                          int B, int H, int nblk, int n1) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= H * n1) return;
-  const int h = gid / n1, i = gid % n1;
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int k = 0; k < nblk; ++k) acc += part[(((int64_t)b * H + h) * nblk + k) * n1 + i];
-  out[gid] = acc;
+// One 1024-thread workgroup per head: drpe1d[h][i] = sum over the (b, key-block) partials (fixed order: four
+// interleaved partial chains per entry, then a fixed tree); optionally the T5 table gradient
+// dtable[bucket][h] = sum_{i: bucket[i] == bucket} drpe1d[h][i] in the same launch (8 lanes per bucket, fixed order).
+__global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restrict__ part, float* __restrict__ out1d,
+                                                           const int32_t* __restrict__ bucket, float* __restrict__ dtable,
+                                                           int B, int H, int nblk, int n1, int nbuckets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sv4 = reinterpret_cast<float*>(smem);          // [4][n1] partial chains
+  float* sv = sv4 + 4 * n1;                             // [n1] reduced diagonal sums of this head
+  int* sb = reinterpret_cast<int*>(sv + n1);            // [n1] bucket ids
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const int nparts = B * nblk;                          // partial rows of this head: (b, blk) -> b*H*nblk + h*nblk + blk
+  for (int wv = tid; wv < 4 * n1; wv += 1024) {
+    const int i = wv % n1, g = wv / n1;
+    float acc = 0.f;
+    for (int pidx = g; pidx < nparts; pidx += 4) {
+      const int b = pidx / nblk, blk = pidx % nblk;
+      acc += part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
+    }
+    sv4[g * n1 + i] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < n1; i += 1024) {
+    const float acc = (sv4[i] + sv4[n1 + i]) + (sv4[2 * n1 + i] + sv4[3 * n1 + i]);
+    sv[i] = acc;
+    if (out1d) out1d[(int64_t)h * n1 + i] = acc;
+    if (bucket) sb[i] = bucket[i];
+  }
+  if (!dtable) return;
+  __syncthreads();
+  // 8 lanes per bucket, each scans every 8th entry, then an in-group butterfly
+  const int sub = tid & 7;
+  for (int bk = tid >> 3; bk < nbuckets; bk += 128) {
+    float acc = 0.f;
+    for (int i = sub; i < n1; i += 8) acc += (sb[i] == bk) ? sv[i] : 0.f;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) dtable[(int64_t)bk * H + h] = acc;
+  }
 }
 
 }  // namespace fat5

@@ -83,7 +83,7 @@ def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
     return o, L
 
 
-def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbias):
+def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbias, rpe_bucket=None, num_buckets=0):
     q, k, v, o, do = _prep(q), _prep(k), _prep(v), _prep(o), _prep(do)
     B, H, M, D = q.shape
     N = k.shape[2]
@@ -109,8 +109,12 @@ def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbi
     elif rpe1d is not None:
         p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
         if need_dbias:
-            dbias = torch.empty_like(rpe1d)
-            p.drpe1d = dbias.data_ptr()
+            if rpe_bucket is not None:  # table gradient straight from the reduction launch
+                dbias = torch.empty((num_buckets, H), dtype=torch.float32, device=q.device)
+                p.rpe_bucket, p.drpe_table, p.rpe_num_buckets = rpe_bucket.data_ptr(), dbias.data_ptr(), num_buckets
+            else:
+                dbias = torch.empty_like(rpe1d)
+                p.drpe1d = dbias.data_ptr()
     lib = _lib.load()
     nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
@@ -209,7 +213,7 @@ class FlashAttentionRPE(torch.autograd.Function):
         idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, q.device)
         rpe1d = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
         o, L = _attn_fwd(q, k, v, None, rpe1d, R, causal, sm_scale)
-        ctx.save_for_backward(q, k, v, o, L, rpe1d, idx)
+        ctx.save_for_backward(q, k, v, o, L, rpe1d, _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device))
         ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype)
         return o
 
@@ -218,11 +222,9 @@ class FlashAttentionRPE(torch.autograd.Function):
         q, k, v, o, L, rpe1d, idx = ctx.saved_tensors
         R, causal, sm_scale, num_buckets, tdtype = ctx.meta
         need = ctx.needs_input_grad[3]
-        dq, dk, dv, drpe1d = _attn_bwd(o, do, q, k, v, None, rpe1d, R, L, causal, sm_scale, need)
-        dtable = None
-        if need:  # scatter the (H, 2R+1) diagonal sums into the (num_buckets, H) table
-            dtable = torch.zeros(num_buckets, q.shape[1], dtype=torch.float32, device=q.device)
-            dtable.index_add_(0, idx, drpe1d.transpose(0, 1))
+        # the (H, 2R+1) diagonal sums are scattered into the (num_buckets, H) table by the reduction launch itself
+        dq, dk, dv, dtable = _attn_bwd(o, do, q, k, v, None, rpe1d, R, L, causal, sm_scale, need, idx, num_buckets)
+        if dtable is not None:
             dtable = dtable.to(tdtype)
         return dq, dk, dv, dtable, None, None, None, None, None
 
@@ -276,7 +278,8 @@ class AttentionPlan:
 
     mode: "none" | "dense" (bias tensor) | "rpe" (rpe1d (H, 2R+1) fp32 + radius)."""
 
-    def __init__(self, q, k, v, do, *, bias=None, rpe1d=None, radius=0, causal=False, sm_scale=None, need_dbias=True):
+    def __init__(self, q, k, v, do, *, bias=None, rpe1d=None, radius=0, causal=False, sm_scale=None, need_dbias=True,
+                 rpe_bucket=None, num_buckets=0):
         _check_inputs(q, k, v)
         self.q, self.k, self.v, self.do = _prep(q), _prep(k), _prep(v), _prep(do)
         B, H, M, D = q.shape
@@ -298,7 +301,11 @@ class AttentionPlan:
                 p.dbias, p.dbias_batch, p.dbias_heads = self.dbias.data_ptr(), bias.shape[0], bias.shape[1]
         elif rpe1d is not None:
             p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
-            if need_dbias:
+            if need_dbias and rpe_bucket is not None:  # (num_buckets, H) table gradient from the reduction launch
+                self.rpe_bucket = rpe_bucket
+                self.dbias = torch.empty((num_buckets, H), dtype=torch.float32, device=dev)
+                p.rpe_bucket, p.drpe_table, p.rpe_num_buckets = rpe_bucket.data_ptr(), self.dbias.data_ptr(), num_buckets
+            elif need_dbias:
                 self.dbias = torch.empty_like(rpe1d)
                 p.drpe1d = self.dbias.data_ptr()
         self.lib = _lib.load()

@@ -58,6 +58,16 @@ def bucket_index(radius, bidirectional, num_buckets, max_distance, device):
     return idx
 
 
+def bucket_index32(radius, bidirectional, num_buckets, max_distance, device):
+    """int32 copy of `bucket_index` (what the C ABI's `rpe_bucket` takes)."""
+    key = ("i32", radius, bool(bidirectional), num_buckets, max_distance, str(device))
+    idx = _IDX_CACHE.get(key)
+    if idx is None:
+        idx = bucket_index(radius, bidirectional, num_buckets, max_distance, device).to(torch.int32).contiguous()
+        _IDX_CACHE[key] = idx
+    return idx
+
+
 def rpe_radius(max_distance):
     """Beyond |n - m| >= max_distance every relative position falls in the last bucket of its side."""
     return int(max_distance)

@@ -90,6 +90,14 @@ typedef struct fat5_attn_params {
   void* dbias;              /* DENSE: same shape/dtype as bias, contiguous; may be NULL */
   int32_t dbias_batch, dbias_heads; /* Bb, Hb of bias/dbias */
   float* drpe1d;            /* RPE1D: (H, 2R+1) fp32, overwritten; may be NULL */
+  /* RPE1D, optional: gradient of the T5 table itself, scattered in the same reduction launch.
+   * rpe_bucket[i] = bucket id of clamped relative position i - R (i in [0, 2R]); drpe_table is
+   * (rpe_num_buckets, H) fp32, overwritten: drpe_table[b][h] = sum_{i: rpe_bucket[i]=b} drpe1d[h][i]
+   * (what autograd's embedding backward computes from the dense dbias). */
+  const int32_t* rpe_bucket;
+  float* drpe_table;
+  int32_t rpe_num_buckets;
+  int32_t reserved0;
   void* workspace;          /* size from fat5_attn_bwd_workspace_bytes(); 256-B aligned */
   size_t workspace_bytes;
 } fat5_attn_params;
