@@ -91,7 +91,7 @@ void attn_bwd_q_kernel(const AttnArgs a) {
       dsum = fmaf(cvt_hi<BF16>(of[j]), cvt_hi<BF16>(dof[kk][j]), dsum);
     }
   }
-  const float delta = dsum + xchg32(dsum);
+  const float delta = pair_sum(dsum);
   if (qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
   const float Lq = a.lse[stat_off + qrow_c];
   // p = exp2(x - L2); rows with L = -inf (fully masked) contribute nothing

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -85,6 +86,18 @@ FAT5_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 FAT5_DEV float xchg32(float v) {  // value held by the partner lane (lane ^ 32)
   return __shfl_xor(v, 32, 64);
+}
+// max / sum over the lane pair (lane, lane ^ 32) with v_permlane32_swap: a VALU op (~2 issue slots) instead of a
+// ds_bpermute round trip through the LDS crossbar (~100+ cycles of exposed latency in front of the rescale branch)
+FAT5_DEV float pair_max(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+FAT5_DEV float pair_sum(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -36,9 +36,13 @@ struct FwdCfg {
   static constexpr int VBYTES = rm_bytes<D, BN>();
   static constexpr int STAGE = KBYTES + VBYTES;
   static size_t smem(int R, int bias_mode) {
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0);
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0) + 16;
   }
 };
+
+#ifndef FAT5_OPTIMISTIC
+#define FAT5_OPTIMISTIC 1  // bf16: all-visible constant-bias tiles skip the running row maximum (see attn_fwd_kernel)
+#endif
 
 // dense bias for one 32-key block, C layout of S^T: lane (q, hi) needs keys nb + crow(r, hi)
 template <bool BF16>
@@ -92,7 +96,8 @@ FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
 }
 
 #ifndef FAT5_PSUM_MFMA
-#define FAT5_PSUM_MFMA 1  // row sums of P on the matrix pipe (A = ones) instead of 32 VALU adds per tile
+#define FAT5_PSUM_MFMA 0  // 1: row sums of P on the matrix pipe (A = ones).  0 (default): 8 v_pk_add_f32 per block -- the chip is power
+                          // limited under this kernel (~1.95 GHz), two extra MFMAs per block cost more than the packed adds
 #endif
 
 #ifndef FAT5_ABLATE
@@ -108,7 +113,8 @@ void attn_fwd_kernel(const AttnArgs a) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
+  int* sFlag = reinterpret_cast<int*>(smem + 2 * Cfg::STAGE);  // optimistic pass overflowed -> redo exactly
+  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + 16);
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int bh, mblk;
@@ -162,20 +168,25 @@ void attn_fwd_kernel(const AttnArgs a) {
   FragAddr<D> fa;
   fa.init(l);
 
+  // Optimistic softmax (bf16 only).  FlashAttention's reference point m need not be the running row maximum: ANY m
+  // gives the exact result as long as exp2(x - m) neither overflows nor is flushed.  bf16 P and the fp32
+  // accumulators share fp32's exponent range, so once a row has a baseline (exact first tile pair) the all-visible
+  // constant-bias tiles skip the row maximum, the lane exchange and the rescale test (15 of ~70 VALU instructions per
+  // 32-key block): P = exp2(s*c2 + cst - m) with the stale m, l via the matrix pipe, and once per tile pair one compare
+  // renormalises O, l by an exact power of two when l >= 2^40.  A score more than ~87 nats above everything seen before
+  // would overflow inside one pair: l becomes inf/NaN, the workgroup notices at the end and redoes its tile with the
+  // exact algorithm (second pass).  fp16 P would overflow at 2^16, so fp16 always runs the exact pass.
+  constexpr bool OPT = FAT5_OPTIMISTIC && BF16 && BIAS != FAT5_BIAS_DENSE;
+  if (OPT && tid == 0) *sFlag = 0;
+
   f32x16 oacc[DB];
-#pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY;  // running row max, log2 units
+  float m_run;  // reference point of the exponentials (running row max, possibly stale), log2 units
 #if FAT5_PSUM_MFMA
-  f32x16 lacc;              // every register = running row sum of (rounded) P for this lane's query
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  f32x16 lacc;  // every register = running row sum of (rounded) P for this lane's query
   const uint32_t one2 = pack2<BF16>(1.f, 1.f);
   const u32x4 ones = {one2, one2, one2, one2};
 #else
-  float l_run = 0.f;        // per-lane partial row sum
+  f32x2 l_run;  // per-lane partial row sum (two interleaved chains: v_pk_add_f32)
 #endif
 
   RowStage<D, BN, NT> kst, vst;
@@ -184,14 +195,8 @@ void attn_fwd_kernel(const AttnArgs a) {
   const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
   const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
-  if (nt > 0) {
-    kst.load_buf(krs, 0, tid);
-    vst.load_buf(vrs, 0, tid);
-    kst.store_rm(smem, tid);
-    vst.store_rm(smem + Cfg::KBYTES, tid);
-  }
-  __syncthreads();
 
+  __syncthreads();  // sT / sFlag visible
   // Touch the Q fragments here: their global loads are otherwise still "pending" in the compiler's waitcnt model at
   // the loop header, and every QK^T MFMA inside the loop then waits on vmcnt, i.e. on the K/V PREFETCH of its own tile.
 #pragma unroll
@@ -208,7 +213,8 @@ void attn_fwd_kernel(const AttnArgs a) {
   // One K/V tile.  FAST: no key of the tile is masked for any row of the workgroup and the bias is one
   // constant `cst` (none, or an all-far RPE tile): raw scores stay in registers, scale and constant are folded
   // into the exponent FMA.  Otherwise the generic body handles masks / per-element bias per 32-key block.
-  auto tile = [&]<bool FAST, int BUF>(int t, float cst) {
+  auto tile = [&]<int MODE, int BUF>(int t, float cst) {  // MODE 0 generic, 1 FAST, 2 FAST optimistic
+    constexpr bool FAST = MODE != 0;
     const int n0 = t * BN;
     const char* sK = smem + BUF * Cfg::STAGE;
     const char* sV = sK + Cfg::KBYTES;
@@ -249,7 +255,10 @@ void attn_fwd_kernel(const AttnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 
       float mul, add, mcand;
-      if constexpr (FAST) {
+      if constexpr (MODE == 2) {
+        mul = c2;
+        add = cst;
+      } else if constexpr (FAST) {
         mul = c2;
         add = cst;
         mcand = (FAT5_ABLATE & 2) ? fmaf(s[0], c2, cst) : fmaf(max16(s), c2, cst);
@@ -307,8 +316,8 @@ void attn_fwd_kernel(const AttnArgs a) {
       }
 
       // online softmax (log2 domain), deferred rescale
-      mcand = fmaxf(mcand, xchg32(mcand));
-      if (__any(mcand > m_run + FAT5_DEFER_THR)) {
+      if constexpr (MODE != 2) mcand = pair_max(mcand);
+      if (MODE != 2 && __any(mcand > m_run + FAT5_DEFER_THR)) {
         const float m_new = fmaxf(m_run, mcand);
         const float alpha = fast_exp2(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
 #if FAT5_PSUM_MFMA
@@ -325,10 +334,15 @@ void attn_fwd_kernel(const AttnArgs a) {
       }
       const float ad = add - ((m_run == -INFINITY) ? 0.f : m_run);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = (FAT5_ABLATE & 1) ? fmaf(s[r], mul, ad) : fast_exp2(fmaf(s[r], mul, ad));
+      for (int r = 0; r < 16; r += 2) {
+        // packed FMA (v_pk_fma_f32): two exponents per instruction
+        f32x2 x = {s[r], s[r + 1]};
+        x = x * mul + ad;
+        if (!(FAT5_ABLATE & 1)) { x[0] = fast_exp2(x[0]); x[1] = fast_exp2(x[1]); }
+        s[r] = x[0];
+        s[r + 1] = x[1];
 #if !FAT5_PSUM_MFMA
-        l_run += s[r];
+        l_run += x;
 #endif
       }
 #pragma unroll
@@ -381,31 +395,117 @@ void attn_fwd_kernel(const AttnArgs a) {
     tb1 &= ~1;
     if (tb1 < tb0) tb0 = tb1 = ta;
   }
-  int t = 0;
-  for (; t < ta; t += 2) {
-    tile.template operator()<true, 0>(t, cst_a);
-    tile.template operator()<true, 1>(t + 1, cst_a);
+  // once per optimistic tile pair: keep l (and O) below 2^40 by an exact power of two
+  auto renorm = [&]() {
+#if FAT5_PSUM_MFMA
+    const float lchk = lacc[0];
+#else
+    const float lchk = l_run[0] + l_run[1];  // lane partial <= row sum: conservative trigger
+#endif
+    if (__builtin_expect(__any(!(lchk < 0x1p40f)), 0)) {
+#if FAT5_PSUM_MFMA
+      const float lc = lchk;
+#else
+      const float lc = pair_sum(lchk);  // both lanes of a row must pick the same exponent
+#endif
+      const int e = (lc >= 0x1p40f) ? (int)((__float_as_uint(lc) >> 23) & 0xffu) - 127 : 0;
+      const float alpha = __uint_as_float((uint32_t)(127 - min(e, 126)) << 23);  // 2^-e
+#if FAT5_PSUM_MFMA
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+#else
+      l_run *= alpha;
+#endif
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      m_run += (float)e;
+    }
+  };
+
+  for (int pass = 0;; ++pass) {
+    const bool opt = OPT && pass == 0;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    m_run = -INFINITY;
+#if FAT5_PSUM_MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#else
+    l_run = f32x2{0.f, 0.f};
+#endif
+    if (nt > 0) {
+      kst.load_buf(krs, 0, tid);
+      vst.load_buf(vrs, 0, tid);
+      kst.store_rm(smem, tid);
+      vst.store_rm(smem + Cfg::KBYTES, tid);
+    }
+    __syncthreads();
+
+    int t = 0;
+    // range A: exact (all of it, or just the baseline pair of an optimistic pass)
+    for (const int te = opt ? min(ta, 2) : ta; t < te; t += 2) {
+      tile.template operator()<1, 0>(t, cst_a);
+      tile.template operator()<1, 1>(t + 1, cst_a);
+    }
+    if constexpr (OPT) {
+      if (opt && t < ta) {
+        m_run = (m_run == -INFINITY) ? 0.f : m_run;  // rows without a visible key so far: l = 0, any finite m will do
+        for (; t < ta; t += 2) {
+          renorm();
+          tile.template operator()<2, 0>(t, cst_a);
+          tile.template operator()<2, 1>(t + 1, cst_a);
+        }
+      }
+    }
+    const int g0 = min(max(tb0, ta), nt & ~1);
+    for (; t < g0; t += 2) {
+      tile.template operator()<0, 0>(t, 0.f);
+      tile.template operator()<0, 1>(t + 1, 0.f);
+    }
+    // range B
+    for (const int te = opt ? (t == 0 ? min(tb1, 2) : t) : tb1; t < te; t += 2) {
+      tile.template operator()<1, 0>(t, cst_b);
+      tile.template operator()<1, 1>(t + 1, cst_b);
+    }
+    if constexpr (OPT) {
+      if (opt && t < tb1) {
+        m_run = (m_run == -INFINITY) ? 0.f : m_run;
+        for (; t < tb1; t += 2) {
+          renorm();
+          tile.template operator()<2, 0>(t, cst_b);
+          tile.template operator()<2, 1>(t + 1, cst_b);
+        }
+      }
+    }
+    for (; t + 1 < nt; t += 2) {
+      tile.template operator()<0, 0>(t, 0.f);
+      tile.template operator()<0, 1>(t + 1, 0.f);
+    }
+    if (t < nt) tile.template operator()<0, 0>(t, 0.f);
+
+    if constexpr (!OPT) {
+      break;
+    } else {
+      if (!opt) break;
+#if FAT5_PSUM_MFMA
+      if (!(lacc[0] < 0x1p120f)) *sFlag = 1;  // inf / NaN / about to overflow
+#else
+      if (!(l_run[0] + l_run[1] < 0x1p120f)) *sFlag = 1;
+#endif
+      __syncthreads();
+      if (*sFlag == 0) break;
+    }
   }
-  const int g0 = min(max(tb0, ta), nt & ~1);
-  for (; t < g0; t += 2) {
-    tile.template operator()<false, 0>(t, 0.f);
-    tile.template operator()<false, 1>(t + 1, 0.f);
-  }
-  for (; t < tb1; t += 2) {
-    tile.template operator()<true, 0>(t, cst_b);
-    tile.template operator()<true, 1>(t + 1, cst_b);
-  }
-  for (; t + 1 < nt; t += 2) {
-    tile.template operator()<false, 0>(t, 0.f);
-    tile.template operator()<false, 1>(t + 1, 0.f);
-  }
-  if (t < nt) tile.template operator()<false, 0>(t, 0.f);
 
   // ---- epilogue: o = acc / l, L = m + ln(l) --------------------------------------------------
 #if FAT5_PSUM_MFMA
   const float l_tot = lacc[0];
 #else
-  const float l_tot = l_run + xchg32(l_run);
+  const float l_tot = pair_sum(l_run[0] + l_run[1]);
 #endif
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   if (qrow < M) {

@@ -146,6 +146,37 @@ def test_default_scale_and_none_bias():
         assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16), key
 
 
+@pytest.mark.parametrize("boost,rows", [(0.0, "all"), (40.0, "all"), (400.0, "all"), (1000.0, "even")])
+def test_fwd_optimistic_softmax_edge_cases(boost, rows):
+    """bf16 all-visible tiles run without a running row maximum once a row has a baseline (attn_fwd.h, "optimistic").
+    Scores that rise by `boost` nats after the baseline tiles exercise: nothing (0), the power-of-two renormalisation
+    of O / l (40 nats ~ 2^58), and the overflow -> exact second pass of the workgroup (400 / 1000 nats; "even" = only
+    every other row overflows).  All must match the oracle like any other input."""
+    B, H, S, D = 1, 2, 1024, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, S, D, generator=g).bfloat16()
+    k = torch.randn(B, H, S, D, generator=g).bfloat16()
+    v = torch.randn(B, H, S, D, generator=g).bfloat16()
+    q[..., 0] = 4.0
+    if rows == "even":
+        q[..., 1::2, 0] = 0.0
+    k[..., 256:, 0] = boost / 4.0
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B, H, S, D, generator=g).bfloat16().cuda()
+    got = run_dense(q, k, v, None, do, 1.0, False)
+    ref = oracle_all(q, k, v, None, do, 1.0, False)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], torch.bfloat16)
+    # the backward consumes the L written by either pass.  Every key carries the same large component, so dq/dk are
+    # sums that cancel (rows of the softmax Jacobian sum to zero): the yardstick is the reference tests' own rule,
+    # a small multiple of the eager bf16 error (test_fa2_bias.py:64-67).
+    lp = eager_lowprec_errors(q, k, v, None, do, 1.0, False, ref)
+    for key in ("dq", "dk", "dv"):
+        e = maxdiff(got[key], ref[key])
+        assert torch.isfinite(got[key].float()).all(), key
+        assert e <= max(gbound(ref[key], torch.bfloat16), 3 * lp[key]), (key, e, lp[key])
+
+
 def test_deterministic():
     """two runs are bit-identical (no atomics on dQ/dK/dV/dense dBias) -- would have caught the reference's Q4 race."""
     q, k, v, b, do = make_inputs(2, 3, 256, 300, 64, torch.bfloat16, "11", seed=1)

@@ -17,7 +17,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   float c = 0.5f, m = 0.25f;
   for (int it = 0; it < iters; ++it) {
     // MFMA work: 4-chain + 6 independent-ish
-    if (MODE != 3) {
+    if (MODE == 4 || MODE == 6) __builtin_amdgcn_s_setprio(0);
+    if (MODE == 5) __builtin_amdgcn_s_setprio(2);
+    if (MODE == 7 || MODE == 8) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (MODE == 8) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(s) : "v"(a), "v"(b));
+        else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o0) : "v"(a), "v"(b));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o1) : "v"(b), "v"(a));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o2) : "v"(a), "v"(a));
+      }
+    } else if (MODE != 3) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), s, 0, 0, 0);
 #pragma unroll
@@ -28,6 +42,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
       }
     }
     // VALU work on x (independent of this iteration's MFMAs): 8 max3-ish, 16 fma, 16 exp, 8 cvt
+    if (MODE == 4) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(2); }
+    if (MODE == 5) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+    if (MODE == 6) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); }
     if (MODE != 2) {
       float mx = x[0];
 #pragma unroll
@@ -45,13 +62,13 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
       }
       b[0] ^= p[0] & 1; b[1] ^= p[1] & 1; b[2] ^= p[2] & 1; b[3] ^= p[3] & 1;
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 8) {
 #pragma unroll
       for (int g = 0; g < 10; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);   // 5 VALU
       }
-    } else if (MODE == 0) {
+    } else if (MODE == 0 || MODE >= 4) {
       __builtin_amdgcn_sched_group_barrier(0x8, 10, 0);
       __builtin_amdgcn_sched_group_barrier(0x2, 60, 0);
     }
@@ -86,6 +103,8 @@ int main() {
     run<3>("valu only", occ, iters);
     run<0>("phase separated", occ, iters);
     run<1>("interleaved 1:5", occ, iters);
+    run<7>("asm agpr acc (o only)", occ, iters);
+    run<8>("asm agpr acc (all)", occ, iters);
   }
   return 0;
 }
