@@ -44,7 +44,8 @@ class AttnParams(ctypes.Structure):
 
 
 EXPORTS = (
-    "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_stages",
+    "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
+    "fat5_attn_bwd_stages",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_ce_fwd", "fat5_ce_bwd",
 )
 
@@ -69,6 +70,8 @@ def load():
     lib.fat5_attn_bwd.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_void_p]
     lib.fat5_attn_bwd_stages.restype = ctypes.c_int
     lib.fat5_attn_bwd_stages.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_int, ctypes.c_void_p]
+    lib.fat5_attn_bwd_launches.restype = ctypes.c_int
+    lib.fat5_attn_bwd_launches.argtypes = [ctypes.POINTER(AttnParams)]
     lib.fat5_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.fat5_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(AttnParams)]
     i64, f32, vp, i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int

@@ -45,8 +45,7 @@ struct BwdQCfg {
 #define FAT5_BWD_MINW 2  // the register allocator must leave room for 2 waves per SIMD (<= 256 VGPR+AGPR)
 #endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
-void attn_bwd_q_kernel(const AttnArgs a) {
+FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   using Cfg = BwdQCfg<D, NW>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -55,7 +54,7 @@ void attn_bwd_q_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int bh, mblk;
-  decode_block(blockIdx.x, a.B * a.H, a.n_mblk, bh, mblk);
+  decode_block(bid, a.B * a.H, a.n_mblk, bh, mblk);
   const int b = bh / a.H, h = bh % a.H;
   const int M = a.M, N = a.N;
   const int m0 = mblk * BM;
@@ -92,7 +91,7 @@ void attn_bwd_q_kernel(const AttnArgs a) {
     }
   }
   const float delta = pair_sum(dsum);
-  if (qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
+  if (a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;  // (not needed by the fused launch)
   const float Lq = a.lse[stat_off + qrow_c];
   // p = exp2(x - L2); rows with L = -inf (fully masked) contribute nothing
   const float nL2 = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
@@ -301,9 +300,10 @@ struct BwdKVCfg {
   }
 };
 
-template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
-void attn_bwd_kv_kernel(const AttnArgs a) {
+// SELFD: delta = rowsum(o * do) is formed here from the O tile (prefetched beside dO) instead of being read from the
+// dQ kernel's scratch -- removes the only dependency between the two kernels so that they can share one launch.
+template <int D, bool BF16, int BIAS, int NW, bool SELFD>
+FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   using Cfg = BwdKVCfg<D, NW>;
   constexpr int BNK = Cfg::BNK, BMQ = Cfg::BMQ, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -311,7 +311,7 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int bh, nblk;
-  decode_block(blockIdx.x, a.B * a.H, a.n_nblk, bh, nblk);
+  decode_block(bid, a.B * a.H, a.n_nblk, bh, nblk);
   const int b = bh / a.H, h = bh % a.H;
   const int M = a.M, N = a.N;
   const int n0 = nblk * BNK;
@@ -385,25 +385,65 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
   const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
   const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
   const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
-  // row statistics of a tile: -L*log2e (or -inf for rows that contribute nothing) and delta
+  // SELFD: O tile with dO's thread -> (row, chunk) mapping; rows >= M read as zero -> delta 0
+  using OStage = RowStage<D, BMQ, NT>;
+  u32x4 ofr[SELFD ? OStage::PER : 1];
+  const uint16_t* ob = SELFD ? a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1] : nullptr;
+  const __amdgpu_buffer_rsrc_t ors = make_rows_rsrc(SELFD ? ob : dob, SELFD ? a.os[2] : a.dos[2], M, D);
+  uint32_t ogoff[OStage::PER];
+#pragma unroll
+  for (int i = 0; i < OStage::PER; ++i) {
+    const int id = tid + NT * i;
+    ogoff[i] = (uint32_t)((id / OStage::C) * a.os[2] + (id % OStage::C) * 8) * 2u;
+  }
+  const uint32_t ostride_b = (uint32_t)a.os[2] * 2u;
+  // Row statistics of a tile, staged in the form the MFMA accumulators are INITIALISED with (C operand of the first
+  // k-step instead of zero): S' = Q K^T - L/scale, so that p = exp2(S'*c2 + bias) needs no per-element "+ (-L)", and
+  // dP' = dO V^T - delta.  Rows that contribute nothing (m >= M, or L = -inf) start at -inf*sign(scale): p = 0.
+  const float inv_scale = 1.f / a.scale;  // scale != 0 (the API substitutes 1e-30 for an exact zero)
+  const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY;
   float st_l = 0.f, st_d = 0.f;
   auto load_stats = [&](int mrow0) {
     if (tid < BMQ) {
       const int m = mrow0 + tid;
-      st_l = -INFINITY;
+      st_l = ninf_c;
       st_d = 0.f;
       if (m < M) {
         const float L = a.lse[stat_off + m];
-        st_l = (L == -INFINITY) ? -INFINITY : -L * kLog2e;
-        st_d = a.delta[stat_off + m];
+        st_l = (L == -INFINITY) ? ninf_c : -L * inv_scale;
+        if constexpr (!SELFD) st_d = -a.delta[stat_off + m];
+      }
+    }
+    if constexpr (SELFD) {
+#pragma unroll
+      for (int i = 0; i < OStage::PER; ++i) {
+        if ((OStage::ITEMS % NT != 0) && tid + NT * i >= OStage::ITEMS) continue;
+        ofr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, ogoff[i], (uint32_t)mrow0 * ostride_b, 0));
       }
     }
   };
   auto store_stats = [&](char* st) {
+    float* sL = reinterpret_cast<float*>(st + 2 * Cfg::QRM);
     if (tid < BMQ) {
-      float* sL = reinterpret_cast<float*>(st + 2 * Cfg::QRM);
       sL[tid] = st_l;
-      sL[BMQ + tid] = st_d;
+      if constexpr (!SELFD) sL[BMQ + tid] = st_d;
+    }
+    if constexpr (SELFD) {
+      // per-chunk partial dot, then a butterfly over the C = D/8 consecutive lanes that hold one row
+#pragma unroll
+      for (int i = 0; i < OStage::PER; ++i) {
+        const int id = tid + NT * i;
+        if ((OStage::ITEMS % NT != 0) && id >= OStage::ITEMS) continue;
+        float pd = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pd = fmaf(cvt_lo<BF16>(ofr[i][j]), cvt_lo<BF16>(dost.r[i][j]), pd);
+          pd = fmaf(cvt_hi<BF16>(ofr[i][j]), cvt_hi<BF16>(dost.r[i][j]), pd);
+        }
+#pragma unroll
+        for (int off = 1; off < OStage::C; off <<= 1) pd += __shfl_xor(pd, off, 64);
+        if (id % OStage::C == 0) sL[BMQ + id / OStage::C] = -pd;
+      }
     }
   };
   if (ntile > 0) {
@@ -445,36 +485,38 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
       // S = Q K^T first (its own fragment registers die before dP = dO V^T is formed: the kernel runs at the
       // 256-register limit of 2 waves per SIMD)
       f32x16 s, dp;
+      // accumulator initial values: rows mb + 8g + 4hi + (0..3)  <->  registers 4g .. 4g+3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 nl4 = *reinterpret_cast<const float4*>(sL + 32 * qbk + 8 * g + 4 * hi);
+        s[4 * g] = nl4.x; s[4 * g + 1] = nl4.y; s[4 * g + 2] = nl4.z; s[4 * g + 3] = nl4.w;
+      }
       {
         u32x4 qa[KK];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) qa[kk] = ld_rm<D>(sQ, fa, qbk, kk);
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(qa[kk], kf[kk], kk == 0 ? zero16 : s);
+        for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(qa[kk], kf[kk], s);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 dl4 = *reinterpret_cast<const float4*>(sL + BMQ + 32 * qbk + 8 * g + 4 * hi);
+        dp[4 * g] = dl4.x; dp[4 * g + 1] = dl4.y; dp[4 * g + 2] = dl4.z; dp[4 * g + 3] = dl4.w;
       }
       {
         u32x4 da[KK];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) da[kk] = ld_rm<D>(sDO, fa, qbk, kk);
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) dp = mfma32<BF16>(da[kk], vf[kk], kk == 0 ? zero16 : dp);
-      }
-      // row statistics for rows mb + 8g + 4hi + (0..3)
-      float nl[16], dl[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 nl4 = *reinterpret_cast<const float4*>(sL + 32 * qbk + 8 * g + 4 * hi);
-        const float4 dl4 = *reinterpret_cast<const float4*>(sL + BMQ + 32 * qbk + 8 * g + 4 * hi);
-        nl[4 * g] = nl4.x; nl[4 * g + 1] = nl4.y; nl[4 * g + 2] = nl4.z; nl[4 * g + 3] = nl4.w;
-        dl[4 * g] = dl4.x; dl[4 * g + 1] = dl4.y; dl[4 * g + 2] = dl4.z; dl[4 * g + 3] = dl4.w;
+        for (int kk = 0; kk < KK; ++kk) dp = mfma32<BF16>(da[kk], vf[kk], dp);
       }
       // C layout: lane (key = krow, hi), register r <-> query row mb + crow(r, hi)
       f32x16 p;
       if constexpr (FAST) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = fast_exp2(fmaf(s[r], c2, cst + nl[r]));
-          s[r] = p[r] * (dp[r] - dl[r]);
+          p[r] = fast_exp2(fmaf(s[r], c2, cst));
+          s[r] = p[r] * dp[r];
         }
       } else {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
@@ -482,7 +524,7 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
           for (int r = 0; r < 16; ++r) {
             const int m = mb + crow(r, hi);
             const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
-            s[r] = fmaf(s[r], c2, fmaf(bvl, kLog2e, nl[r]));
+            s[r] = fmaf(s[r], c2, bvl * kLog2e);
           }
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           const int R = a.R;
@@ -490,27 +532,27 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
           if (dmax <= -R || dmin >= R) {
             const float c = (dmax <= -R) ? cst_neg : cst_pos;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c + nl[r]);
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c);
           } else if (dmin > -R && dmax < R) {
             const float* tp = sT + (R + krow - mb - 4 * hi - 27);  // interior of the band: base + immediate offsets
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[27 - ((r & 3) + 8 * (r >> 2))] + nl[r]);
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[27 - ((r & 3) + 8 * (r >> 2))]);
           } else {
             const int d0 = krow - mb - 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int d = d0 - ((r & 3) + 8 * (r >> 2));
-              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nl[r]);
+              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
             }
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nl[r]);
+          for (int r = 0; r < 16; ++r) s[r] *= c2;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           p[r] = fast_exp2(s[r]);
-          s[r] = p[r] * (dp[r] - dl[r]);
+          s[r] = p[r] * dp[r];
         }
         const bool nmask = krow0 + 32 > N;
         const bool cmask = a.causal && (krow0 + 31 > mb + P);
@@ -687,6 +729,28 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
       }
     }
   }
+}
+
+// ---- launchable kernels -------------------------------------------------------------------------------------
+template <int D, bool BF16, int BIAS, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+void attn_bwd_q_kernel(const AttnArgs a) {
+  attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x);
+}
+template <int D, bool BF16, int BIAS, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+void attn_bwd_kv_kernel(const AttnArgs a) {
+  attn_bwd_kv_body<D, BF16, BIAS, NW, false>(a, blockIdx.x);
+}
+// Both backward kernels in ONE launch (horizontal fusion) for problems whose two grids together fit the chip at two
+// workgroups per CU: workgroups [0, n_kv_blocks) run the dK/dV body (the longer one first), the rest the dQ body.
+// Neither half depends on the other (the dK/dV half forms delta itself), so a short-sequence backward costs
+// max(dQ, dK/dV) instead of their sum.
+template <int D, bool BF16, int BIAS, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+void attn_bwd_fused_kernel(const AttnArgs a) {
+  if ((int)blockIdx.x < a.n_kv_blocks) attn_bwd_kv_body<D, BF16, BIAS, NW, true>(a, blockIdx.x);
+  else attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x - a.n_kv_blocks);
 }
 
 }  // namespace fat5

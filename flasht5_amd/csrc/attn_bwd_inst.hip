@@ -1,6 +1,7 @@
 // Instantiations of the backward kernels for one head_dim (compile with -DFAT5_INST_D=32|64|128).
 #include "attn_bwd.h"
 #include "attn_launch.h"
+#include <algorithm>
 
 #ifndef FAT5_INST_D
 #error "FAT5_INST_D must be defined"
@@ -41,6 +42,17 @@ static hipError_t launch_kv(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int D, bool BF16, int BIAS, int NW>
+static hipError_t launch_fused(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = std::max(BwdKVCfg<D, NW>::smem(a.R, BIAS), BwdQCfg<D, NW>::smem(a.R, BIAS));
+  auto kern = attn_bwd_fused_kernel<D, BF16, BIAS, NW>;
+  static size_t configured = 0;
+  hipError_t e = set_smem(kern, smem, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  return hipGetLastError();
+}
+
 #define DISPATCH(FN, a, bf16, bias, nw, grid, s)                                                     \
   do {                                                                                               \
     if (bf16) {                                                                                      \
@@ -59,6 +71,18 @@ hipError_t CAT(launch_bwd_q_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bia
 }
 hipError_t CAT(launch_bwd_kv_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
   DISPATCH(launch_kv, a, bf16, bias, nw, grid, s);
+}
+// fused launch: 4-wave tiles only (the small-problem configuration)
+hipError_t CAT(launch_bwd_fused_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  (void)nw;
+  if (bf16) {
+    if (bias == FAT5_BIAS_NONE) return launch_fused<FAT5_INST_D, true, 0, 4>(a, grid, s);
+    if (bias == FAT5_BIAS_DENSE) return launch_fused<FAT5_INST_D, true, 1, 4>(a, grid, s);
+    return launch_fused<FAT5_INST_D, true, 2, 4>(a, grid, s);
+  }
+  if (bias == FAT5_BIAS_NONE) return launch_fused<FAT5_INST_D, false, 0, 4>(a, grid, s);
+  if (bias == FAT5_BIAS_DENSE) return launch_fused<FAT5_INST_D, false, 1, 4>(a, grid, s);
+  return launch_fused<FAT5_INST_D, false, 2, 4>(a, grid, s);
 }
 size_t CAT(smem_bwd_q_d, FAT5_INST_D)(int nw, int R, int bias) {
   return nw == 2 ? BwdQCfg<FAT5_INST_D, 2>::smem(R, bias) : BwdQCfg<FAT5_INST_D, 4>::smem(R, bias);

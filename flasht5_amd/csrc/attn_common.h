@@ -187,6 +187,7 @@ struct AttnArgs {
   int32_t causal, R;
   int32_t bias_vec4;        // dense bias rows can be read with aligned 8-byte loads
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
+  int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
   float scale;
 };
 

@@ -173,6 +173,20 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
   return L.total;
 }
 
+static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv) {
+  static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
+  return fuse_env && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= 2 * 256;
+}
+
+int fat5_attn_bwd_launches(const fat5_attn_params* p) {
+  if (check_common(p)) return 0;
+  BwdLayout L;
+  bwd_layout(p, L);
+  const long bh = (long)p->B * p->H;
+  const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
+  return bwd_fusable(L, grid_q, grid_kv) ? 1 : 2;
+}
+
 int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) { return fat5_attn_bwd_stages(p, FAT5_BWD_ALL, stream_); }
 
 int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
@@ -205,6 +219,9 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.dos[i] = p->do_stride[i]; a.dqs[i] = p->dq_stride[i]; a.dks[i] = p->dk_stride[i]; a.dvs[i] = p->dv_stride[i];
   }
   a.delta = (float*)(ws + L.delta_off);
+  // the dK/dV kernel stages -L/scale (accumulator initial value): an exact zero scale (softmax of the bias alone,
+  // dq = dk = 0) runs with 1e-30 -- q.k * 1e-30 and the 1e-30-scaled dq / dk vanish in fp32 / the output dtype
+  if (a.scale == 0.f) a.scale = 1e-30f;
   const int64_t MN = (int64_t)p->M * p->N;
   const long bh = (long)p->B * p->H;
   const bool bf16 = p->dtype == FAT5_BF16;
@@ -226,19 +243,31 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.drpe_part = (float*)(ws + L.drpe_off);
   }
 
-  // 1) dQ (+ delta)
   a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
   a.n_nblk = L.n_nblk;
-  if (stages & FAT5_BWD_DQ) {
-    launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
-    hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)(bh * a.n_mblk), stream);
-    if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
-  }
-  // 2) dK, dV, dBias
-  if (stages & FAT5_BWD_DKDV) {
-    launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
-    hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)(bh * a.n_nblk), stream);
-    if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
+  a.n_kv_blocks = 0;
+  const long grid_q = bh * a.n_mblk, grid_kv = bh * a.n_nblk;
+  // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
+  // side by side (attn_bwd_fused_kernel).  FAT5_BWD_FUSE=0 disables (developer A/B).
+  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, grid_q, grid_kv);
+  if (fuse) {
+    a.n_kv_blocks = (int)grid_kv;
+    launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
+    hipError_t e = fn(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
+    if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused launch");
+  } else {
+    // 1) dQ (+ delta)
+    if (stages & FAT5_BWD_DQ) {
+      launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
+      hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)grid_q, stream);
+      if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
+    }
+    // 2) dK, dV, dBias
+    if (stages & FAT5_BWD_DKDV) {
+      launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
+      hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)grid_kv, stream);
+      if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
+    }
   }
   // 3) reductions over the broadcast dims
   if (L.ds_staged && (stages & FAT5_BWD_REDUCE)) {

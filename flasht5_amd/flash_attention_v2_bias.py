@@ -319,6 +319,10 @@ class AttentionPlan:
         _lib.check(self.lib.fat5_attn_fwd(ctypes.byref(self.p), _lib.stream_ptr(self.device)), "fat5_attn_fwd")
         return self.o
 
+    def bwd_launches(self):
+        """1: dQ and dK/dV halves share one launch (short sequences); 2: two kernels (fat5_attn_bwd_launches)."""
+        return int(self.lib.fat5_attn_bwd_launches(ctypes.byref(self.p)))
+
     def backward(self, stages=7):
         _lib.check(self.lib.fat5_attn_bwd_stages(ctypes.byref(self.p), int(stages), _lib.stream_ptr(self.device)),
                    "fat5_attn_bwd")

@@ -113,9 +113,14 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* hip_stream);
 size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p);
 /* backward: reads q,k,v,o,lse,dout(,bias|rpe1d); writes dq,dk,dv(,dbias|drpe1d). */
 int fat5_attn_bwd(const fat5_attn_params* p, void* hip_stream);
+/* number of main kernel launches fat5_attn_bwd uses for this problem: 1 = dQ and dK/dV halves side by side in one
+ * launch (short sequences: both grids fit the chip together), 2 = dQ kernel then dK/dV kernel; 0 on invalid params.
+ * (Profilers use it to name the dominant kernel; the reduction launch is not counted.) */
+int fat5_attn_bwd_launches(const fat5_attn_params* p);
 /* the same backward, one stage at a time (profiling / stream overlap).  Order matters:
  * FAT5_BWD_DQ (writes delta + dq) must precede FAT5_BWD_DKDV (reads delta; writes dk, dv, dS / partial
- * diagonal sums), which must precede FAT5_BWD_REDUCE (dbias / drpe1d).  fat5_attn_bwd == FAT5_BWD_ALL. */
+ * diagonal sums), which must precede FAT5_BWD_REDUCE (dbias / drpe1d).  fat5_attn_bwd == FAT5_BWD_ALL.
+ * FAT5_BWD_DQ | FAT5_BWD_DKDV in one call may use the single side-by-side launch (fat5_attn_bwd_launches). */
 enum fat5_bwd_stage { FAT5_BWD_DQ = 1, FAT5_BWD_DKDV = 2, FAT5_BWD_REDUCE = 4, FAT5_BWD_ALL = 7 };
 int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* hip_stream);
 
