@@ -37,10 +37,22 @@ struct BwdQCfg {
   static constexpr int VRM = rm_bytes<D, BN>();
   static constexpr int STAGE = KRM + VRM;
   static size_t smem(int R, int bias_mode) {
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0);
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0);
   }
 };
 
+#ifndef FAT5_TRACE
+#define FAT5_TRACE 0  // developer: wave 0 of every workgroup stamps s_memtime into the delta scratch (tools/trace_bwd.py)
+#endif
+#if FAT5_TRACE
+#define FAT5_STAMP(slot)                                                                                   \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && (slot) < 16)                                                                   \
+      reinterpret_cast<unsigned long long*>(a.delta)[(size_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define FAT5_STAMP(slot) do {} while (0)
+#endif
 #ifndef FAT5_BWD_MINW
 #define FAT5_BWD_MINW 2  // the register allocator must leave room for 2 waves per SIMD (<= 256 VGPR+AGPR)
 #endif
@@ -52,6 +64,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
 
+  FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int bh, mblk;
   decode_block(bid, a.B * a.H, a.n_mblk, bh, mblk);
@@ -96,9 +109,10 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   // p = exp2(x - L2); rows with L = -inf (fully masked) contribute nothing
   const float nL2 = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
 
+  const float* sTa = sT;  // this lane's aligned copy of the table
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    const int n1 = 2 * a.R + 1;
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;
+    rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+    sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   }
   const uint16_t* brow = nullptr;
   if constexpr (BIAS == FAT5_BIAS_DENSE)
@@ -180,9 +194,16 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, ad);
           } else if (dmin > -R && dmax < R) {
-            const float* tp = sT + (R + nb + 4 * hi - qrow);  // interior of the band: base + immediate offsets
+            // interior of the band: four aligned 16-byte reads of this lane's table copy
+            const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[(r & 3) + 8 * (r >> 2)] + nL2);
+            for (int g = 0; g < 4; ++g) {
+              const float4 bq = tp4[2 * g];
+              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nL2);
+              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nL2);
+              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nL2);
+              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nL2);
+            }
           } else {
             const int dl = nb + 4 * hi - qrow;
 #pragma unroll
@@ -220,6 +241,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
       vst.store_rm(nK + Cfg::KRM, tid);
     }
     __syncthreads();
+    FAT5_STAMP(2 + t);
   };
 
   // tile classes as in the forward (boundaries rounded to even tile indices: one body per loop)
@@ -245,6 +267,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     tb1 &= ~1;
     if (tb1 < tb0) tb0 = tb1 = ta;
   }
+  FAT5_STAMP(1);
   int t = 0;
   for (; t < ta; t += 2) {
     tile.template operator()<true, 0>(t, cst_a);
@@ -278,6 +301,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
         *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
       }
   }
+  FAT5_STAMP(15);
 }
 
 // =============================================================================================
@@ -291,13 +315,14 @@ struct BwdKVCfg {
   static constexpr int QRM = rm_bytes<D, BMQ>();
   static constexpr int STAT = BMQ * 4 * 2;  // -L*log2e and delta for the BMQ rows
   static constexpr int STAGE = 2 * QRM + STAT;
+  static constexpr int SKEW_ROW = 160;         // bytes per row of a wave's 32 x 64 bf16 skew tile (padded: tr reads conflict free)
+  static constexpr int SKEW = 32 * SKEW_ROW;
   static size_t smem(int R, int bias_mode) {
     // rpe: table + one private accumulator per wave
     // rpe: table + one private diagonal accumulator per wave + one private 32x64 fp32 skew tile per wave
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * 8192 : 0);
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0);
   }
-  static __host__ __device__ size_t rpe_off(int R) { return ((size_t)(2 * R + 1) * 4 * (1 + NW) + 63) / 64 * 64;
-  }
+  static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * NW + 63) / 64 * 64; }
 };
 
 // SELFD: delta = rowsum(o * do) is formed here from the O tile (prefetched beside dO) instead of being read from the
@@ -309,6 +334,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int bh, nblk;
   decode_block(bid, a.B * a.H, a.n_nblk, bh, nblk);
@@ -340,12 +366,46 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   // RPE: table + per-wave private diagonal accumulators in LDS
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
   const int n1 = 2 * a.R + 1;
-  float* sD = sT + n1 + w * n1;
-  // Per-wave 32x64 fp32 "skew tile": row q of a near block is stored shifted by -q so that diagonals become columns;
-  // one column sum per lane then replaces 16 LDS float atomics per lane (ds_add_f32 costs ~600 cycles per wave
-  // instruction on gfx950 -- measured; tools/time_kv.py).
-  float* sG = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + Cfg::rpe_off(a.R)) + w * 2048;
+  float* sD0 = sT + 4 * rpe_n1p(a.R);  // NW wave-private (2R+1) diagonal accumulators behind the four table copies
+  float* sD = sD0 + w * n1;
+  // Per-wave 32x64 bf16 "skew tile": dS of a near block is stored with row q shifted by -q (element (q, k) at column
+  // k - q + 31), so diagonals become columns.  Column sums = ones(32x32) x tile on the matrix pipe (4 MFMAs, operand
+  // fragments by transposing reads), one value per lane -- this replaces 16 LDS float atomics per lane (ds_add_f32 costs
+  // ~600 cycles per wave instruction on gfx950; tools/time_kv.py) and, before that, 32 reads + 32 adds per lane.
+  // dS enters rounded to the input dtype, exactly like the reference's bias gradient (ds.to(dtype), :720 / :214).
+  char* sG = smem + 2 * Cfg::STAGE + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
+  // element r of this lane (row crow(r, hi), key lq): byte offset sk_w + 158 * ((r & 3) + 8 * (r >> 2))
+  const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
+  int sk_r[2];  // transposing reads: rows 8*j2 + 4*hi + e (+16 per k-step), 16-column group g, 8-byte piece c
+  {
+    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g = (l >> 4) & 1;
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) sk_r[j2] = (8 * j2 + 4 * hi + e) * Cfg::SKEW_ROW + 32 * g + 8 * c;
+  }
+  const uint32_t one2s = pack2<BF16>(1.f, 1.f);
+  const u32x4 ones = {one2s, one2s, one2s, one2s};
+  // column c of the block at query row mb is the diagonal  krow0 - mb - 31 + c.  Columns 32..63 of block j are the
+  // diagonals of columns 0..31 of block j-1 (mb grows by 32): `carry` holds those until the next block completes them.
+  float carry = 0.f;
+  int carry_d0 = 0;          // diagonal of lane 0's carried value
+  bool carry_valid = false;  // wave-uniform
   float far_neg = 0.f, far_pos = 0.f;
+  // one finished diagonal sum per lane of the lower half-wave (both halves hold the same columns): far bins in
+  // registers, near bins stored into the wave-private (zero-initialised) array
+  auto emit_diag = [&](float v, int d) {
+    if (hi == 0) {
+      if (d <= -a.R) far_neg += v;
+      else if (d >= a.R) far_pos += v;
+      else sD[d + a.R] = v;  // every near diagonal of a wave is finished exactly once (query blocks ascend)
+    }
+  };
+  auto flush_carry = [&]() {
+    if (carry_valid) {
+      emit_diag(carry, carry_d0 + lq);
+      carry_valid = false;
+      carry = 0.f;
+    }
+  };
   auto tree16 = [](const f32x16& x) {  // balanced tree: no long dependent chain, one live register afterwards
     const float t0 = (x[0] + x[1]) + (x[2] + x[3]), t1 = (x[4] + x[5]) + (x[6] + x[7]);
     const float t2 = (x[8] + x[9]) + (x[10] + x[11]), t3 = (x[12] + x[13]) + (x[14] + x[15]);
@@ -353,9 +413,9 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   };
   const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;
-    for (int i = tid; i < n1 * NW; i += NT) sT[n1 + i] = 0.f;
-    for (int i = l; i < 2048; i += 64) sG[i] = 0.f;
+    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    for (int i = tid; i < n1 * NW; i += NT) sD0[i] = 0.f;
+    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
   const uint16_t* bbase = nullptr;
   uint16_t* dsbase = nullptr;
@@ -379,23 +439,22 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   const int mt1 = (M + BMQ - 1) / BMQ;
   const int ntile = mt1 - mt0;
 
-  RowStage<D, BMQ, NT> qst, dost;
-  qst.init(a.qs[2], tid);
-  dost.init(a.dos[2], tid);
+  // Q / dO tiles go global -> LDS directly (no staging registers: this body sits at the 256-VGPR limit of two
+  // waves per SIMD, and every spilled register is a scratch round trip on the critical path of a 1-2 waves/SIMD grid)
+  using Dma = DmaStage<D, BMQ, NT>;
+  Dma qdm, dodm;
+  qdm.init(a.qs[2], tid);
+  dodm.init(a.dos[2], tid);
   const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
   const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
   const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
-  // SELFD: O tile with dO's thread -> (row, chunk) mapping; rows >= M read as zero -> delta 0
-  using OStage = RowStage<D, BMQ, NT>;
-  u32x4 ofr[SELFD ? OStage::PER : 1];
+  // SELFD: the O pieces that pair with this thread's dO pieces (same row / same swizzled chunk), through registers;
+  // rows >= M read as zero -> delta 0
+  u32x4 ofr[SELFD ? Dma::PER : 1];
   const uint16_t* ob = SELFD ? a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1] : nullptr;
   const __amdgpu_buffer_rsrc_t ors = make_rows_rsrc(SELFD ? ob : dob, SELFD ? a.os[2] : a.dos[2], M, D);
-  uint32_t ogoff[OStage::PER];
-#pragma unroll
-  for (int i = 0; i < OStage::PER; ++i) {
-    const int id = tid + NT * i;
-    ogoff[i] = (uint32_t)((id / OStage::C) * a.os[2] + (id % OStage::C) * 8) * 2u;
-  }
+  Dma odm;
+  odm.init(a.os[2], tid);
   const uint32_t ostride_b = (uint32_t)a.os[2] * 2u;
   // Row statistics of a tile, staged in the form the MFMA accumulators are INITIALISED with (C operand of the first
   // k-step instead of zero): S' = Q K^T - L/scale, so that p = exp2(S'*c2 + bias) needs no per-element "+ (-L)", and
@@ -416,12 +475,13 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     }
     if constexpr (SELFD) {
 #pragma unroll
-      for (int i = 0; i < OStage::PER; ++i) {
-        if ((OStage::ITEMS % NT != 0) && tid + NT * i >= OStage::ITEMS) continue;
-        ofr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, ogoff[i], (uint32_t)mrow0 * ostride_b, 0));
-      }
+      for (int i = 0; i < Dma::PER; ++i)
+        ofr[i] = odm.load_piece(ors, (uint32_t)mrow0 * ostride_b, i);
     }
   };
+  // `st` = the LDS buffer the tile was DMA'd into.  SELFD reads this thread's OWN dO pieces back (visible to the issuing
+  // wave after its vmcnt), dots them with the O pieces, and a butterfly over the C = D/8 consecutive lanes of a row
+  // finishes delta.
   auto store_stats = [&](char* st) {
     float* sL = reinterpret_cast<float*>(st + 2 * Cfg::QRM);
     if (tid < BMQ) {
@@ -429,29 +489,27 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       if constexpr (!SELFD) sL[BMQ + tid] = st_d;
     }
     if constexpr (SELFD) {
-      // per-chunk partial dot, then a butterfly over the C = D/8 consecutive lanes that hold one row
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < OStage::PER; ++i) {
-        const int id = tid + NT * i;
-        if ((OStage::ITEMS % NT != 0) && id >= OStage::ITEMS) continue;
+      for (int i = 0; i < Dma::PER; ++i) {
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(st + Cfg::QRM + Dma::own_off(tid, i));
         float pd = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          pd = fmaf(cvt_lo<BF16>(ofr[i][j]), cvt_lo<BF16>(dost.r[i][j]), pd);
-          pd = fmaf(cvt_hi<BF16>(ofr[i][j]), cvt_hi<BF16>(dost.r[i][j]), pd);
+          pd = fmaf(cvt_lo<BF16>(ofr[i][j]), cvt_lo<BF16>(dv[j]), pd);
+          pd = fmaf(cvt_hi<BF16>(ofr[i][j]), cvt_hi<BF16>(dv[j]), pd);
         }
 #pragma unroll
-        for (int off = 1; off < OStage::C; off <<= 1) pd += __shfl_xor(pd, off, 64);
-        if (id % OStage::C == 0) sL[BMQ + id / OStage::C] = -pd;
+        for (int off = 1; off < Dma::C; off <<= 1) pd += __shfl_xor(pd, off, 64);
+        const int id = tid + NT * i;
+        if (id % Dma::C == 0) sL[BMQ + id / Dma::C] = -pd;
       }
     }
   };
   if (ntile > 0) {
-    qst.load_buf(qrs, (uint32_t)(mt0 * BMQ) * qstride_b, tid);
-    dost.load_buf(dors, (uint32_t)(mt0 * BMQ) * dostride_b, tid);
+    qdm.issue(qrs, (uint32_t)(mt0 * BMQ) * qstride_b, smem, tid);
+    dodm.issue(dors, (uint32_t)(mt0 * BMQ) * dostride_b, smem + Cfg::QRM, tid);
     load_stats(mt0 * BMQ);
-    qst.store_rm(smem, tid);
-    dost.store_rm(smem + Cfg::QRM, tid);
     store_stats(smem);
   }
   __syncthreads();
@@ -474,9 +532,10 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     const char* sDO = sQ + Cfg::QRM;
     const float* sL = reinterpret_cast<const float*>(sDO + Cfg::QRM);
     const bool more = (mt + 1 < mt1);
-    if (more) {
-      qst.load_buf(qrs, (uint32_t)(mrow0 + BMQ) * qstride_b, tid);
-      dost.load_buf(dors, (uint32_t)(mrow0 + BMQ) * dostride_b, tid);
+    if (more) {  // next tile straight into the other buffer (its last readers passed the previous tile's barrier)
+      char* nb_ = smem + (BUF ^ 1) * Cfg::STAGE;
+      qdm.issue(qrs, (uint32_t)(mrow0 + BMQ) * qstride_b, nb_, tid);
+      dodm.issue(dors, (uint32_t)(mrow0 + BMQ) * dostride_b, nb_ + Cfg::QRM, tid);
       load_stats(mrow0 + BMQ);
     }
 #pragma unroll
@@ -534,9 +593,18 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c);
           } else if (dmin > -R && dmax < R) {
-            const float* tp = sT + (R + krow - mb - 4 * hi - 27);  // interior of the band: base + immediate offsets
+            // interior of the band: entries of r = 4g..4g+3 are 4 consecutive DEscending table entries; this lane's
+            // alignment (R + krow - 3) & 3 is constant -> four aligned 16-byte reads of its table copy
+            const int al = (R + krow - 3) & 3;
+            const float* tb = sT + al * rpe_n1p(R) + (R + krow - mb - 4 * hi - 3 - al);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[27 - ((r & 3) + 8 * (r >> 2))]);
+            for (int g = 0; g < 4; ++g) {
+              const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
+              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
+              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
+              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
+              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
+            }
           } else {
             const int d0 = krow - mb - 4 * hi;
 #pragma unroll
@@ -577,38 +645,41 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
             if (m < M && krow < N) dsbase[(int64_t)m * a.dss[2] + krow] = to16<BF16>(s[r]);
           }
         }
-      } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-#ifndef FAT5_ABL_KV
-#define FAT5_ABL_KV 0
-#endif
+      }
+      // operands of the two output GEMMs (P and dS rounded to the input dtype like the reference, :702 / :720)
+      u32x4 pbv[2], dsv[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        pbv[t2] = pack8<BF16>(p, t2);
+        dsv[t2] = pack8<BF16>(s, t2);
+      }
+      bool near_blk = false;  // wave-uniform: this block's diagonal sums go through the skew tile
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         if (want_drpe) {
           if constexpr (FAST) {
+            flush_carry();
             if constexpr (FARSIDE < 0) far_neg += tree16(s); else far_pos += tree16(s);
           } else {
             const int R = a.R;
             const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
             if (dmax <= -R || dmin >= R) {
-              const float acc = (FAT5_ABL_KV & 2) ? s[0] : tree16(s);
+              flush_carry();
+              const float acc = tree16(s);
               if (dmax <= -R) far_neg += acc; else far_pos += acc;
             } else {
-              // near block: skew-store (element (q, k) -> row q, column k - q + 31: a fixed set of positions per row,
-              // the rest of the tile stays zero), column sums, then ONE update per lane of its diagonal's bin
-              float* gw = sG + (4 * hi) * 63 + lq + 31;
+              near_blk = true;
+              // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31: a fixed set of positions per
+              // row, the rest of the tile stays zero)
+              char* gw = sG + sk_w;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) gw[((r & 3) + 8 * (r >> 2)) * 63] = (FAT5_ABL_KV & 1) ? 0.f : s[r];
-              float c0 = 0.f, c1 = 0.f, c2s = 0.f, c3 = 0.f;
+              for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-              for (int qq = 0; qq < 32; qq += 4) {
-                c0 += sG[(qq + 0) * 64 + l];
-                c1 += sG[(qq + 1) * 64 + l];
-                c2s += sG[(qq + 2) * 64 + l];
-                c3 += sG[(qq + 3) * 64 + l];
-              }
-              const float cs = (c0 + c1) + (c2s + c3);
-              const int dbin = krow0 - mb - 31 + l;  // diagonal of this lane's column
-              if (dbin <= -R) far_neg += cs;
-              else if (dbin >= R) far_pos += cs;
-              else sD[dbin + R] += cs;  // wave-private array, distinct addresses across the lanes: plain read-modify-write
+                for (int wd = 0; wd < 4; ++wd) {
+                  const int r = 8 * t2 + 2 * wd;
+                  const uint32_t word = dsv[t2][wd];
+                  *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
+                  *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
+                }
             }
           }
         }
@@ -616,22 +687,42 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A fragments: transposed reads of the dO / Q images) -----
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        const u32x4 pb = pack8<BF16>(p, t2);
-        const u32x4 dsb = pack8<BF16>(s, t2);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-          dvacc[db] = mfma32<BF16>(ld_tr<D>(sDO, fa, qbk, t2, db), pb, dvacc[db]);
-          dkacc[db] = mfma32<BF16>(ld_tr<D>(sQ, fa, qbk, t2, db), dsb, dkacc[db]);
+          dvacc[db] = mfma32<BF16>(ld_tr<D>(sDO, fa, qbk, t2, db), pbv[t2], dvacc[db]);
+          dkacc[db] = mfma32<BF16>(ld_tr<D>(sQ, fa, qbk, t2, db), dsv[t2], dkacc[db]);
+        }
+      }
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        if (near_blk) {
+          // column sums of the skew tile on the matrix pipe: C = ones(32x32) x tile; every row of C is the vector of
+          // column sums, lane l holds column (l & 31) of its half.  (The row order inside a fragment is irrelevant.)
+          typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+          f32x16 clo, chi;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+              const char* p0 = sG + sk_r[0] + 16 * ks * Cfg::SKEW_ROW + 64 * ch;
+              const char* p1 = sG + sk_r[1] + 16 * ks * Cfg::SKEW_ROW + 64 * ch;
+              const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
+              const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
+              const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
+              if (ch == 0) clo = mfma32<BF16>(ones, fr, ks == 0 ? zero16 : clo);
+              else chi = mfma32<BF16>(ones, fr, ks == 0 ? zero16 : chi);
+            }
+          const int d_hi0 = krow0 - mb + 1;  // diagonal of column 32
+          if (carry_valid && carry_d0 != d_hi0) flush_carry();
+          emit_diag(chi[0] + (carry_valid ? carry : 0.f), d_hi0 + lq);
+          carry = clo[0];
+          carry_d0 = krow0 - mb - 31;
+          carry_valid = true;
         }
       }
     }
-    if (more) {
-      char* nb_ = smem + (BUF ^ 1) * Cfg::STAGE;
-      qst.store_rm(nb_, tid);
-      dost.store_rm(nb_ + Cfg::QRM, tid);
-      store_stats(nb_);
-    }
-    __syncthreads();
+    if (more) store_stats(smem + (BUF ^ 1) * Cfg::STAGE);
+    __syncthreads();  // (carries the vmcnt(0) that retires this wave's DMA pieces)
+    FAT5_STAMP(2 + mt - mt0);
   };
 
   // Tile classes over mt in [mt0, mt1) relative index i = mt - mt0 (even boundaries, see attn_fwd.h).
@@ -669,6 +760,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     ib1 &= ~1;
     if (ib1 < ib0) ib0 = ib1 = ia;
   }
+  FAT5_STAMP(1);
   int i = 0;
   for (; i < ia; i += 2) {
     tile.template operator()<true, 0, 1>(mt0 + i, cst_a);
@@ -706,15 +798,14 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
       }
   }
+  FAT5_STAMP(14);
 
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     if (want_drpe) {
-      // wave-reduce the far sums (fixed butterfly order), fold into the wave's private array
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        far_neg += __shfl_xor(far_neg, off, 64);
-        far_pos += __shfl_xor(far_pos, off, 64);
-      }
+      flush_carry();
+      // wave-reduce the far sums (fixed order), fold into the wave's private array
+      far_neg = wave_sum(far_neg);
+      far_pos = wave_sum(far_pos);
       if (l == 0) {  // lane 0 has hi = 0: its sD is the wave's first array
         sD[0] += far_neg;
         sD[2 * a.R] += far_pos;
@@ -724,11 +815,12 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       for (int i2 = tid; i2 < n1; i2 += NT) {
         float acc = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) acc += sT[n1 + ww * n1 + i2];
+        for (int ww = 0; ww < NW; ++ww) acc += sD0[ww * n1 + i2];
         out[i2] = acc;
       }
     }
   }
+  FAT5_STAMP(15);
 }
 
 // ---- launchable kernels -------------------------------------------------------------------------------------

@@ -100,6 +100,25 @@ FAT5_DEV float pair_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Sum over the 64 lanes of a wave, result in every lane, fixed order: DPP quad / mirror steps inside each row of 16,
+// then v_permlane16_swap / v_permlane32_swap across rows -- six VALU-side steps instead of six ds_bpermute round trips.
+template <int CTRL>
+FAT5_DEV float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+FAT5_DEV float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]  (lane ^ 1)
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]  (lane ^ 2)
+  v = dpp_add<0x141>(v);  // row_half_mirror: the other quad of each 8
+  v = dpp_add<0x140>(v);  // row_mirror: the other 8 of each 16
+  {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return pair_sum(v);
+}
+
 // ------------------------------------------------------------------------------------------
 // LDS images.
 // Row-major [rows][D] 16-bit tile with 16-byte chunks XOR-swizzled so that a ds_read_b128 of
@@ -159,6 +178,23 @@ FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile) {
   } else {
     bh = bid / ntile;
     tile = bid % ntile;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// RPE table in LDS: FOUR copies of the (2R+1) log2-scaled entries, copy c shifted left by c elements
+// (copy_c[m] = T[m + c]).  A lane's 16 gathers per 32x32 block are four runs of 4 consecutive entries whose
+// alignment (mod 4) is a per-lane constant, so it reads its own copy with 4 aligned ds_read_b128 instead of
+// 16 ds_read_b32.  Copy 0 doubles as the plain table (constants, clamped edge path).
+// ------------------------------------------------------------------------------------------
+FAT5_DEV constexpr int rpe_n1p(int R) { return (2 * R + 1 + 3) & ~3; }
+__host__ __device__ constexpr size_t rpe_table_bytes(int R) { return (size_t)4 * ((2 * R + 1 + 3) & ~3) * 4; }
+FAT5_DEV void rpe_table_fill(float* sT, const float* rpe1d_h, int R, int tid, int nthreads) {
+  const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
+  for (int i = tid; i < 4 * n1p; i += nthreads) {
+    const int c = i / n1p, m = i - c * n1p;
+    sT[i] = (m + c < n1) ? rpe1d_h[m + c] * kLog2e : 0.f;
   }
 }
 
@@ -317,6 +353,50 @@ struct RowStage {
       *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
     }
   }
+};
+
+// ------------------------------------------------------------------------------------------
+// Direct global -> LDS tile staging (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass.
+// The hardware writes lane L's 16 bytes at (wave-uniform LDS base) + 16*L, i.e. the image is lane-linear; the
+// XOR swizzle of the row-major image is therefore applied to the SOURCE: the lane that fills slot c' of row r
+// fetches chunk c' ^ swz(r) (readers look for chunk c at slot c ^ swz(r); same involution on both sides).
+// Work item id = tid + NT*i -> row id / C, slot id % C; rows of consecutive i differ by NT/C (a multiple of 16,
+// so the swizzle term is the same for every i and one VGPR addresses all pieces).  Rows past the descriptor's
+// end arrive as zeros.  Completion: the issuing wave's vmcnt, then a barrier for the other waves' reads.
+// ------------------------------------------------------------------------------------------
+template <int D, int ROWS, int NT>
+struct DmaStage {
+  static constexpr int C = D / 8;
+  static constexpr int ITEMS = ROWS * C;
+  static constexpr int PER = ITEMS / NT;
+  static constexpr int RP = NT / C;                       // rows covered by one piece of the whole workgroup
+  static constexpr int NV = (RP % 16 == 0) ? 1 : 16 / RP; // distinct swizzle phases among the pieces
+  static_assert(ITEMS % NT == 0 && NT % C == 0 && (16 % RP == 0 || RP % 16 == 0) && PER % NV == 0, "unsupported tile split");
+  uint32_t voff[NV];    // this lane's byte offset inside a tile for pieces 0 .. NV-1
+  uint32_t piece_step;  // bytes between the rows of pieces i and i + NV (wave-uniform)
+  FAT5_DEV void init(int64_t row_stride, int tid) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int row = tid / C + RP * v, slot = tid % C;
+      voff[v] = (uint32_t)(row * row_stride * 2 + ((slot ^ swz<D>(row)) << 4));
+    }
+    piece_step = (uint32_t)(RP * NV * row_stride * 2);
+  }
+  // tile at byte offset tile_off of the descriptor -> LDS image at `img` (workgroup-uniform)
+  FAT5_DEV void issue(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, char* img, int tid) const {
+    typedef __attribute__((address_space(3))) void* lds_t;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_t)(uintptr_t)(uint32_t)(uintptr_t)(img + (NT * i + 64 * wave) * 16), 16,
+                                               voff[i % NV], tile_off + piece_step * (i / NV), 0, 0);
+  }
+  // the same pieces into registers (operands that pair with a DMA'd tile piece by piece)
+  FAT5_DEV u32x4 load_piece(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, int i) const {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i % NV], tile_off + piece_step * (i / NV), 0));
+  }
+  // LDS byte offset of the 16 bytes this thread's piece i lands at
+  FAT5_DEV static constexpr int own_off(int tid, int i) { return (tid + NT * i) * 16; }
 };
 
 // Per-lane LDS byte offsets of the fragment reads, hoisted out of the tile loops.  With the swizzle of

@@ -36,7 +36,7 @@ struct FwdCfg {
   static constexpr int VBYTES = rm_bytes<D, BN>();
   static constexpr int STAGE = KBYTES + VBYTES;
   static size_t smem(int R, int bias_mode) {
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? (size_t)(2 * R + 1) * 4 + 16 : 0) + 16;
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) + 16;
   }
 };
 
@@ -157,9 +157,10 @@ void attn_fwd_kernel(const AttnArgs a) {
   for (int kk = 0; kk < KK; ++kk)
     qf[kk] = *reinterpret_cast<const u32x4*>(qb + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
 
+  const float* sTa = sT;  // this lane's aligned copy of the table
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    const int n1 = 2 * a.R + 1;
-    for (int i = tid; i < n1; i += NT) sT[i] = a.rpe1d[(int64_t)h * n1 + i] * kLog2e;  // log2 units
+    rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+    sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   }
   const uint16_t* brow = nullptr;
   if constexpr (BIAS == FAT5_BIAS_DENSE)
@@ -283,9 +284,16 @@ void attn_fwd_kernel(const AttnArgs a) {
           } else if (dmin > -R && dmax < R) {
             // interior of the band: no clamping -> the 16 gathers are base + immediate offset, no index VALU
             folded = false;
-            const float* tp = sT + (R + nb + 4 * hi - qrow);  // entry of r = 0
+            // entries of r = 4g .. 4g+3 are consecutive and 16-byte aligned in this lane's table copy
+            const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, tp[(r & 3) + 8 * (r >> 2)]);
+            for (int g = 0; g < 4; ++g) {
+              const float4 bq = tp4[2 * g];
+              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
+              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y);
+              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z);
+              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
+            }
           } else {
             folded = false;
             const int dl = nb + 4 * hi - qrow;  // delta of r = 0

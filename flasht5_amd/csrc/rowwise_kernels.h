@@ -55,11 +55,7 @@ struct Elem<FAT5_F16> : Elem16<FAT5_F16> {};
 template <>
 struct Elem<FAT5_BF16> : Elem16<FAT5_BF16> {};
 
-FAT5_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// wave_sum: attn_common.h (DPP + permlane swaps)
 FAT5_DEV float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
