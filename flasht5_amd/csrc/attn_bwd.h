@@ -69,16 +69,30 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   int bh, mblk;
   decode_block(bid, a.B * a.H, a.n_mblk, bh, mblk);
   const int b = bh / a.H, h = bh % a.H;
-  const int M = a.M, N = a.N;
+  int M = a.M, N = a.N;
+  int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],
+          dooff = (int64_t)b * a.dos[0], dqoff = (int64_t)b * a.dqs[0];
+  int64_t stat_off = ((int64_t)b * a.H + h) * a.M;
+  if (a.cu_q) {  // packed batch: (total, H, D) tensors, lse / delta (H, total_q)
+    const int q0 = a.cu_q[b], k0 = a.cu_k[b];
+    M = a.cu_q[b + 1] - q0;
+    N = a.cu_k[b + 1] - k0;
+    qoff = (int64_t)q0 * a.qs[2];
+    ooff = (int64_t)q0 * a.os[2];
+    dooff = (int64_t)q0 * a.dos[2];
+    dqoff = (int64_t)q0 * a.dqs[2];
+    koff = (int64_t)k0 * a.ks[2];
+    voff = (int64_t)k0 * a.vs[2];
+    stat_off = (int64_t)h * a.total_q + q0;
+  }
   const int m0 = mblk * BM;
   if (m0 >= M) return;
-  const uint16_t* qb = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
-  const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
-  const uint16_t* vb = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
-  const uint16_t* ob = a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1];
-  const uint16_t* dob = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1];
-  uint16_t* dqb = a.dq + (int64_t)b * a.dqs[0] + (int64_t)h * a.dqs[1];
-  const int64_t stat_off = ((int64_t)b * a.H + h) * M;
+  const uint16_t* qb = a.q + qoff + (int64_t)h * a.qs[1];
+  const uint16_t* kb_ = a.k + koff + (int64_t)h * a.ks[1];
+  const uint16_t* vb = a.v + voff + (int64_t)h * a.vs[1];
+  const uint16_t* ob = a.o + ooff + (int64_t)h * a.os[1];
+  const uint16_t* dob = a.dout + dooff + (int64_t)h * a.dos[1];
+  uint16_t* dqb = a.dq + dqoff + (int64_t)h * a.dqs[1];
 
   const int P = N - M;
   int n_end = N;
@@ -339,16 +353,31 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   int bh, nblk;
   decode_block(bid, a.B * a.H, a.n_nblk, bh, nblk);
   const int b = bh / a.H, h = bh % a.H;
-  const int M = a.M, N = a.N;
+  int M = a.M, N = a.N;
+  int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],
+          dooff = (int64_t)b * a.dos[0], dkoff = (int64_t)b * a.dks[0], dvoff = (int64_t)b * a.dvs[0];
+  int64_t stat_off = ((int64_t)b * a.H + h) * a.M;
+  if (a.cu_q) {  // packed batch: (total, H, D) tensors, lse / delta (H, total_q)
+    const int q0 = a.cu_q[b], k0 = a.cu_k[b];
+    M = a.cu_q[b + 1] - q0;
+    N = a.cu_k[b + 1] - k0;
+    qoff = (int64_t)q0 * a.qs[2];
+    ooff = (int64_t)q0 * a.os[2];
+    dooff = (int64_t)q0 * a.dos[2];
+    koff = (int64_t)k0 * a.ks[2];
+    voff = (int64_t)k0 * a.vs[2];
+    dkoff = (int64_t)k0 * a.dks[2];
+    dvoff = (int64_t)k0 * a.dvs[2];
+    stat_off = (int64_t)h * a.total_q + q0;
+  }
   const int n0 = nblk * BNK;
   if (n0 >= N) return;
-  const uint16_t* qb = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
-  const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
-  const uint16_t* vb = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
-  const uint16_t* dob = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1];
-  uint16_t* dkb = a.dk + (int64_t)b * a.dks[0] + (int64_t)h * a.dks[1];
-  uint16_t* dvb = a.dv + (int64_t)b * a.dvs[0] + (int64_t)h * a.dvs[1];
-  const int64_t stat_off = ((int64_t)b * a.H + h) * M;
+  const uint16_t* qb = a.q + qoff + (int64_t)h * a.qs[1];
+  const uint16_t* kb_ = a.k + koff + (int64_t)h * a.ks[1];
+  const uint16_t* vb = a.v + voff + (int64_t)h * a.vs[1];
+  const uint16_t* dob = a.dout + dooff + (int64_t)h * a.dos[1];
+  uint16_t* dkb = a.dk + dkoff + (int64_t)h * a.dks[1];
+  uint16_t* dvb = a.dv + dvoff + (int64_t)h * a.dvs[1];
 
   const int P = N - M;
   const int krow0 = n0 + 32 * w;
@@ -451,7 +480,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   // SELFD: the O pieces that pair with this thread's dO pieces (same row / same swizzled chunk), through registers;
   // rows >= M read as zero -> delta 0
   u32x4 ofr[SELFD ? Dma::PER : 1];
-  const uint16_t* ob = SELFD ? a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1] : nullptr;
+  const uint16_t* ob = SELFD ? a.o + ooff + (int64_t)h * a.os[1] : nullptr;
   const __amdgpu_buffer_rsrc_t ors = make_rows_rsrc(SELFD ? ob : dob, SELFD ? a.os[2] : a.dos[2], M, D);
   Dma odm;
   odm.init(a.os[2], tid);

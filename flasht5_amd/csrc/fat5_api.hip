@@ -149,7 +149,8 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   L.n_nblk = (p->N + 32 * L.nw_kv - 1) / (32 * L.nw_kv);
   size_t off = 0;
   L.delta_off = off;
-  off = align_up(off + (size_t)bh * p->M * sizeof(float), 256);
+  // delta: (B,H,M) -- packed batches: (H, total_q), the layout of lse
+  off = align_up(off + (p->cu_seqlens_q ? (size_t)p->H * p->total_q : (size_t)bh * p->M) * sizeof(float), 256);
   L.ds_staged = false;
   L.ds_off = off;
   if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
@@ -193,7 +194,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   int rc = check_common(p);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  if (p->cu_seqlens_q) return fail(FAT5_EINVAL, "bwd: varlen not supported yet");
+  if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
+  if (p->cu_seqlens_q && p->bias_mode != FAT5_BIAS_NONE) return fail(FAT5_EINVAL, "varlen supports bias_mode none only");
   if (!p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv)
     return fail(FAT5_EINVAL, "bwd: null tensor pointer");
   if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||

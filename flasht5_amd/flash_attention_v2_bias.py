@@ -269,6 +269,69 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max
     return o, lse
 
 
+def _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale):
+    Tq, H, D = q.shape
+    p = _lib.AttnParams()
+    p.B, p.H, p.M, p.N, p.D = cu_q.numel() - 1, H, int(max_q), int(max_k), D
+    p.dtype, p.causal, p.sm_scale = _lib.dtype_code(q.dtype), int(bool(causal)), float(sm_scale)
+    p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v)):
+        setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
+    p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cu_q.data_ptr(), cu_k.data_ptr(), Tq, k.shape[0]
+    return p
+
+
+def _varlen_ok(t):
+    return t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
+
+
+def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False,
+                          sm_scale=None):
+    """Backward of the packed (cu_seqlens) attention: returns dq (total_q, H, D), dk, dv (total_k, H, D)."""
+    q, k, v, o, do = (t if _varlen_ok(t) else t.contiguous() for t in (q, k, v, o, do))
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(q.shape[-1])
+    cq = cu_seqlens_q.to(torch.int32).contiguous()
+    ck = cu_seqlens_k.to(torch.int32).contiguous()
+    dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
+    p = _varlen_params(q, k, v, cq, ck, max_seqlen_q, max_seqlen_k, causal, sm_scale)
+    p.o, p.lse, p.dout, p.dq, p.dk, p.dv = (t.data_ptr() for t in (o, lse, do, dq, dk, dv))
+    for name, t in (("o_stride", o), ("do_stride", do), ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
+        setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
+    lib = _lib.load()
+    nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd(varlen)")
+    return dq, dk, dv
+
+
+class FlashAttentionVarlen(torch.autograd.Function):
+    """Packed batches: q (total_q, H, D), k/v (total_k, H, D), int32 cu_seqlens on the device.
+    No bias (the reference has no cu_seqlens path at all: it pads, `data_collator_ul2.py:49-87`)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale):
+        o, lse = flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale)
+        ctx.save_for_backward(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k)
+        ctx.meta = (int(max_seqlen_q), int(max_seqlen_k), bool(causal), sm_scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, cq, ck = ctx.saved_tensors
+        mq, mk, causal, sm_scale = ctx.meta
+        dq, dk, dv = flash_attn_varlen_bwd(do, q, k, v, o, lse, cq, ck, mq, mk, causal, sm_scale)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None):
+    """Differentiable packed attention (same argument order as the flash_attn var-len entry point the reference's
+    `fa2` attention types would call)."""
+    return FlashAttentionVarlen.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale)
+
+
 # ------------------------------------------------------------------------------------------------
 # pre-planned fwd+bwd (fixed buffers, prebuilt C descriptors): what a training loop / hipGraph replays
 # ------------------------------------------------------------------------------------------------

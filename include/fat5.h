@@ -77,7 +77,8 @@ typedef struct fat5_attn_params {
   /* ---- packed var-len (optional; reference has none -- SURVEY 8(f) n2) ----
    * when cu_seqlens_q != NULL: B = number of sequences, q/o are (total_q, H, D) addressed as
    * base + (cu_seqlens_q[b] + m) * stride[2] + h * stride[1] (stride[0] ignored), k/v likewise
-   * with cu_seqlens_k; M/N are the MAXIMUM lengths; lse is (H, total_q). */
+   * with cu_seqlens_k; M/N are the MAXIMUM lengths; lse is (H, total_q).  Forward and backward (dq like q, dk/dv like
+   * k/v, dout like o); bias_mode must be FAT5_BIAS_NONE. */
   const int32_t* cu_seqlens_q;
   const int32_t* cu_seqlens_k;
   int32_t total_q, total_k;

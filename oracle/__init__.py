@@ -4,7 +4,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package.  The product path (``flasht5_amd``) never does.
 """
 from .attention import (attn_ref, attn_fwd_oracle, attn_bwd_oracle,
-                        attn_varlen_oracle)
+                        attn_varlen_oracle, attn_varlen_bwd_oracle)
 from .rpe import (relative_position_bucket, compute_bias, bias1d_from_table,
                   table_grad_from_dbias1d, toeplitz_from_bias1d)
 from .rmsnorm import rmsnorm_fwd_oracle, rmsnorm_bwd_oracle, rmsnorm_eager

@@ -121,3 +121,26 @@ def attn_varlen_oracle(q, k, v, cu_q, cu_k, sm_scale, causal=False):
         oi, _ = attn_fwd_oracle(qi, ki, vi, None, sm_scale, causal)
         out[qs:qe] = oi[0].permute(1, 0, 2)
     return out
+
+
+def attn_varlen_bwd_oracle(q, k, v, do, cu_q, cu_k, sm_scale, causal=False):
+    """Gradients of `attn_varlen_oracle` (per-sequence loop of the FA2 backward formulas, `attn_bwd_oracle`).
+    Returns dq (Tq, H, D), dk, dv (Tk, H, D) fp32; empty sequences contribute zeros."""
+    dq = torch.zeros(q.shape, dtype=torch.float32)
+    dk = torch.zeros(k.shape, dtype=torch.float32)
+    dv = torch.zeros(v.shape, dtype=torch.float32)
+    for i in range(len(cu_q) - 1):
+        qs, qe, ks, ke = cu_q[i], cu_q[i + 1], cu_k[i], cu_k[i + 1]
+        if qe == qs or ke == ks:
+            continue
+        qi = q[qs:qe].permute(1, 0, 2).unsqueeze(0)
+        ki = k[ks:ke].permute(1, 0, 2).unsqueeze(0)
+        vi = v[ks:ke].permute(1, 0, 2).unsqueeze(0)
+        doi = do[qs:qe].permute(1, 0, 2).unsqueeze(0)
+        oi, Li = attn_fwd_oracle(qi, ki, vi, None, sm_scale, causal)
+        dqi, dki, dvi, _, _ = attn_bwd_oracle(qi, ki, vi, None, oi, Li, doi, sm_scale, causal)
+        dq[qs:qe] = dqi[0].permute(1, 0, 2)
+        dk[ks:ke] = dki[0].permute(1, 0, 2)
+        dv[ks:ke] = dvi[0].permute(1, 0, 2)
+    return dq, dk, dv
+

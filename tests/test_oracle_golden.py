@@ -137,3 +137,28 @@ def test_varlen_oracle_matches_dense():
     o0, _ = oracle.attn_fwd_oracle(q[0:5].permute(1, 0, 2)[None], k[0:9].permute(1, 0, 2)[None],
                                    v[0:9].permute(1, 0, 2)[None], None, 0.125)
     assert md(out[0:5], o0[0].permute(1, 0, 2)) == 0
+
+
+def test_varlen_bwd_oracle_matches_autograd():
+    """the packed backward restatement equals autograd through the per-sequence eager attention (`attn_ref`)"""
+    g = torch.Generator().manual_seed(1)
+    H, D = 2, 32
+    cu_q, cu_k = [0, 5, 5, 17, 18], [0, 9, 12, 40, 41]
+    q = torch.randn(cu_q[-1], H, D, generator=g)
+    k = torch.randn(cu_k[-1], H, D, generator=g)
+    v = torch.randn(cu_k[-1], H, D, generator=g)
+    do = torch.randn(cu_q[-1], H, D, generator=g)
+    for causal in (False, True):
+        leaves = [t.clone().requires_grad_() for t in (q, k, v)]
+        outs = []
+        for i in range(len(cu_q) - 1):
+            qs, qe, ks, ke = cu_q[i], cu_q[i + 1], cu_k[i], cu_k[i + 1]
+            if qe == qs or ke == ks:
+                continue
+            oi = oracle.attn_ref(leaves[0][qs:qe].permute(1, 0, 2)[None], leaves[1][ks:ke].permute(1, 0, 2)[None],
+                                 leaves[2][ks:ke].permute(1, 0, 2)[None], None, 0.25, causal=causal, upcast=True)
+            outs.append((oi[0].permute(1, 0, 2) * do[qs:qe]).sum())
+        grads = torch.autograd.grad(sum(outs), leaves)
+        got = oracle.attn_varlen_bwd_oracle(q, k, v, do, cu_q, cu_k, 0.25, causal)
+        for a, b in zip(got, grads):
+            assert md(a, b) < 2e-5
