@@ -12,10 +12,12 @@ from . import _lib
 _lib.load()  # fail loudly at import time when the HIP library is missing
 
 from .flash_attention_v2_bias import (flash_attention_v2_bias, FlashAttentionAdditiveBias,  # noqa: E402
-                                      flash_attention_v2_rpe, FlashAttentionRPE, flash_attn_varlen_fwd, flash_attn_varlen_bwd,
+                                      flash_attention_v2_rpe, FlashAttentionRPE, flash_attention_v2_rpe1d, FlashAttentionRPE1D,
+                                      flash_attn_varlen_fwd, flash_attn_varlen_bwd,
                                       flash_attn_varlen_func, FlashAttentionVarlen)
 from .rms_norm import fast_rms_layernorm, Fast_RMS_Layernorm  # noqa: E402
 from .cross_entropy_loss import cross_entropy_loss, CrossEntropyLoss  # noqa: E402
-from .positional_encoding import relative_position_bucket, compute_bias, rpe1d_from_table  # noqa: E402
+from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_from_table,  # noqa: E402
+                                  RelativePositionalEncoding)
 
 __version__ = "0.1.0"

@@ -238,6 +238,41 @@ def flash_attention_v2_rpe(q, k, v, rpe_table, bidirectional=True, num_buckets=3
     return FlashAttentionRPE.apply(q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale)
 
 
+class FlashAttentionRPE1D(torch.autograd.Function):
+    """RPE mode on the 1-D generator itself: `rpe1d (H, 2R+1)` fp32 with bias[h][m][n] = rpe1d[h][clamp(n-m,-R,R)+R].
+    Differentiable in q, k, v and rpe1d, so ONE generator (built once per step from the T5 table by
+    `rpe1d_from_table` / `RelativePositionalEncoding.forward_1d`) can feed every layer: autograd sums the per-layer
+    `(H, 2R+1)` gradients and scatters them into the `(num_buckets, H)` table once."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, rpe1d, radius, causal, sm_scale):
+        D = q.shape[-1]
+        assert D in {32, 64, 128}
+        if sm_scale is None:
+            sm_scale = 1.0 / math.sqrt(D)
+        if radius > _lib.MAX_RPE_RADIUS:
+            raise ValueError(f"radius {radius} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
+        if rpe1d.shape != (q.shape[1], 2 * radius + 1):
+            raise ValueError("rpe1d must be (n_heads, 2 * radius + 1)")
+        r1 = rpe1d.detach().float().contiguous()
+        o, L = _attn_fwd(q, k, v, None, r1, radius, causal, sm_scale)
+        ctx.save_for_backward(q, k, v, o, L, r1)
+        ctx.meta = (radius, causal, sm_scale, rpe1d.dtype)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, L, r1 = ctx.saved_tensors
+        radius, causal, sm_scale, rdtype = ctx.meta
+        dq, dk, dv, d1 = _attn_bwd(o, do, q, k, v, None, r1, radius, L, causal, sm_scale, ctx.needs_input_grad[3])
+        return dq, dk, dv, (d1.to(rdtype) if d1 is not None else None), None, None, None
+
+
+def flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, causal=False, sm_scale=None):
+    """Attention with the Toeplitz bias generated in-kernel from `rpe1d (H, 2*radius+1)` (see FlashAttentionRPE1D)."""
+    return FlashAttentionRPE1D.apply(q, k, v, rpe1d, int(radius), causal, sm_scale)
+
+
 # ------------------------------------------------------------------------------------------------
 # packed var-len forward (config 4: decoder cross-attention over cu_seqlens; forward only for now)
 # ------------------------------------------------------------------------------------------------

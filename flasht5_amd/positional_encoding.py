@@ -78,3 +78,49 @@ def rpe1d_from_table(table, bidirectional=True, num_buckets=32, max_distance=128
     R = rpe_radius(max_distance)
     idx = bucket_index(R, bidirectional, num_buckets, max_distance, table.device)
     return table.index_select(0, idx).transpose(0, 1).float().contiguous()
+
+
+class RelativePositionalEncoding(torch.nn.Module):
+    """Mirror of the reference module (src/utils/positional_encoding.py:11-110; constructor arguments and the
+    `relative_attention_bias` parameter name are the reference's, so its checkpoints load) with one more output form:
+
+    * `forward(q, k, v)` -> `(q, k, v, bias)` with the dense `(1, H, M, N)` bias in q's dtype, like the reference (:103-110);
+    * `forward_1d()` -> `(rpe1d, radius)`: the `(H, 2R+1)` fp32 generator of the linear-memory mode.  Build it ONCE per
+      step and hand it to every layer's `flash_attention_v2_rpe1d`; the table gradient is then one accumulated scatter.
+
+    `randomized_position` (reference :79-89) has no Toeplitz structure and is supported by the dense form only."""
+
+    def __init__(self, relative_attention_num_buckets, relative_attention_max_distance, n_heads, max_sequence_length=0,
+                 bidirectional=True, randomized_position=False):
+        super().__init__()
+        self.relative_attention_num_buckets = relative_attention_num_buckets
+        self.relative_attention_max_distance = relative_attention_max_distance
+        self.n_heads = n_heads
+        self.max_sequence_length = max_sequence_length
+        self.bidirectional = bidirectional
+        self.randomized_position = randomized_position
+        self.relative_attention_bias = torch.nn.Embedding(relative_attention_num_buckets, n_heads)
+
+    def compute_bias(self, query_length, key_length, device=None):
+        if self.randomized_position:
+            raise NotImplementedError("randomized_position: build the dense bias with the reference formula and pass it "
+                                      "to flash_attention_v2_bias")
+        w = self.relative_attention_bias.weight
+        if device is not None and w.device != torch.device(device):
+            w = w.to(device)
+        return compute_bias(w, query_length, key_length, self.bidirectional, self.relative_attention_num_buckets,
+                            self.relative_attention_max_distance)
+
+    def forward(self, q, k=None, v=None):
+        query_length = q.shape[1]
+        key_length = k.shape[1] if k is not None else query_length
+        bias = self.compute_bias(query_length, key_length, device=q.device).contiguous().to(q.dtype)
+        return q, k, v, bias
+
+    def forward_1d(self):
+        if self.randomized_position:
+            raise NotImplementedError("randomized positions are not a function of n - m")
+        r1 = rpe1d_from_table(self.relative_attention_bias.weight, self.bidirectional, self.relative_attention_num_buckets,
+                              self.relative_attention_max_distance)
+        return r1, rpe_radius(self.relative_attention_max_distance)
+

@@ -218,6 +218,34 @@ def test_rpe_mode_matches_dense_oracle(B, H, M, N, causal, bidir, md):
     assert maxdiff(dt.cpu(), tl.grad) <= 5e-3 * max(1.0, tl.grad.abs().max().item()) + 2e-2
 
 
+
+def test_shared_rpe1d_across_layers():
+    """one `(H, 2R+1)` generator built once from the T5 table feeds several layers; autograd sums the
+    per-layer diagonal gradients and scatters them into the table once.  Truth: the dense oracle per layer."""
+    from flasht5_amd import flash_attention_v2_rpe1d
+    from flasht5_amd.positional_encoding import RelativePositionalEncoding
+    B, H, S, D, layers = 2, 2, 256, 64, 3
+    torch.manual_seed(21)
+    mod = RelativePositionalEncoding(32, 128, H).cuda()
+    table = mod.relative_attention_bias.weight.detach().clone()
+    bias = oracle.compute_bias(table.cpu(), S, S, True, 32, 128).contiguous().cuda()
+    r1, R = mod.forward_1d()
+    total, outs, db_sum = 0.0, [], torch.zeros(1, H, S, S)
+    for layer in range(layers):
+        q, k, v, _, do = make_inputs(B, H, S, S, D, torch.bfloat16, None, seed=50 + layer)
+        o = flash_attention_v2_rpe1d(q, k, v, r1, R, False, 1.0)
+        total = total + (o.float() * do.float()).sum()
+        ref = oracle_all(q, k, v, bias, do, 1.0, False)
+        assert maxdiff(o, ref["o"]) <= bound(ref["o"], torch.bfloat16)
+        _, _, _, _, db = oracle.attn_bwd_oracle(q, k, v, bias, o.detach(), ref["L"], do, 1.0, False)
+        db_sum += db.cpu()
+    total.backward()
+    tl = table.cpu().clone().requires_grad_()
+    oracle.compute_bias(tl, S, S, True, 32, 128).backward(db_sum)
+    got = mod.relative_attention_bias.weight.grad.cpu()
+    assert maxdiff(got, tl.grad) <= 5e-3 * max(1.0, tl.grad.abs().max().item()) + 2e-2 * layers
+
+
 def test_rpe_equals_dense_kernel_full_cfg2():
     """config 2 at full size: the RPE-mode kernels and the dense-bias kernels agree (same table)."""
     from flasht5_amd import flash_attention_v2_rpe, flash_attention_v2_bias, compute_bias

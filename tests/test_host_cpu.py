@@ -78,6 +78,32 @@ def test_host_bucket_and_bias_match_oracle():
         assert torch.equal(r1[:, idx].unsqueeze(0), oracle.compute_bias(table, M, N, bidir, 32, 128).float())
 
 
+
+def test_rpe_module_mirror_dense_and_1d():
+    """`RelativePositionalEncoding` mirror: dense output equals the oracle's builder on the module's own table, the
+    1-D generator reproduces it through the Toeplitz rule, and its gradient is the table gradient of the dense form."""
+    from flasht5_amd import positional_encoding as pe
+    torch.manual_seed(3)
+    mod = pe.RelativePositionalEncoding(32, 128, 4, bidirectional=True)
+    q = torch.zeros(2, 40, 8)  # the reference's forward reads lengths from dim 1 (:105-106)
+    k = torch.zeros(2, 70, 8)
+    _, _, _, bias = mod(q, k)
+    w = mod.relative_attention_bias.weight.detach()
+    assert bias.shape == (1, 4, 40, 70)
+    assert torch.equal(bias, oracle.compute_bias(w, 40, 70, True, 32, 128))
+    r1, R = mod.forward_1d()
+    assert r1.shape == (4, 2 * R + 1) and R == 128
+    idx = torch.clamp(torch.arange(70)[None, :] - torch.arange(40)[:, None], -R, R) + R
+    assert torch.equal(r1.detach()[:, idx].unsqueeze(0), bias.detach().float())
+    # gradient through the generator == gradient through the dense bias
+    g = torch.randn(1, 4, 40, 70)
+    (r1[:, idx].unsqueeze(0) * g).sum().backward()
+    g1 = mod.relative_attention_bias.weight.grad.clone()
+    mod.relative_attention_bias.weight.grad = None
+    (mod.compute_bias(40, 70) * g).sum().backward()
+    assert torch.allclose(g1, mod.relative_attention_bias.weight.grad, atol=1e-5)
+
+
 def test_shard_units_partition():
     from flasht5_amd.sharding import shard_units, heads_needing_reduction
     for B, H in ((4, 12), (3, 5), (1, 7)):
