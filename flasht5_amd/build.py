@@ -66,6 +66,11 @@ def build_lib(force=False, verbose=True):
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
             print(f"[fat5 build] linked {LIB}", flush=True)
+        # every kernel stub must resolve (a silently skipped template instantiation shows up as an undefined symbol)
+        chk = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], capture_output=True, text=True)
+        if chk.returncode != 0:
+            os.remove(LIB)
+            raise RuntimeError(f"{LIB} does not load:\n{chk.stderr[-2000:]}")
     return LIB
 
 

@@ -140,17 +140,15 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
-  RowStage<D, BN, NT> kst, vst;
+  DmaStage<D, BN, NT> kst, vst;  // K / V tiles global -> LDS directly (see the dK/dV body)
   kst.init(a.ks[2], tid);
   vst.init(a.vs[2], tid);
   const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
   const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   if (nt > 0) {
-    kst.load_buf(krs, 0, tid);
-    vst.load_buf(vrs, 0, tid);
-    kst.store_rm(smem, tid);
-    vst.store_rm(smem + Cfg::KRM, tid);
+    kst.issue(krs, 0, smem, tid);
+    vst.issue(vrs, 0, smem + Cfg::KRM, tid);
   }
   __syncthreads();
   // see attn_fwd.h: keep the compiler's waitcnt model from chaining the loop's MFMAs to the tile prefetch
@@ -172,8 +170,9 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     const char* sV = sK + Cfg::KRM;
     const bool more = (t + 1 < nt);
     if (more) {
-      kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
-      vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
+      char* nK = smem + (BUF ^ 1) * Cfg::STAGE;  // (its last readers passed the previous tile's barrier)
+      kst.issue(krs, (uint32_t)(n0 + BN) * kstride_b, nK, tid);
+      vst.issue(vrs, (uint32_t)(n0 + BN) * vstride_b, nK + Cfg::KRM, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -248,11 +247,6 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) dqacc[db] = mfma32<BF16>(ld_tr<D>(sK, fa, kb, t2, db), dsb, dqacc[db]);
       }
-    }
-    if (more) {
-      char* nK = smem + (BUF ^ 1) * Cfg::STAGE;
-      kst.store_rm(nK, tid);
-      vst.store_rm(nK + Cfg::KRM, tid);
     }
     __syncthreads();
     FAT5_STAMP(2 + t);

@@ -368,10 +368,11 @@ template <int D, int ROWS, int NT>
 struct DmaStage {
   static constexpr int C = D / 8;
   static constexpr int ITEMS = ROWS * C;
-  static constexpr int PER = ITEMS / NT;
+  static constexpr int PER = ITEMS >= NT ? ITEMS / NT : 1;  // (ITEMS < NT: the trailing waves have nothing to fetch)
   static constexpr int RP = NT / C;                       // rows covered by one piece of the whole workgroup
   static constexpr int NV = (RP % 16 == 0) ? 1 : 16 / RP; // distinct swizzle phases among the pieces
-  static_assert(ITEMS % NT == 0 && NT % C == 0 && (16 % RP == 0 || RP % 16 == 0) && PER % NV == 0, "unsupported tile split");
+  static_assert((ITEMS % NT == 0 || (NT % ITEMS == 0 && ITEMS % 64 == 0)) && NT % C == 0 && (16 % RP == 0 || RP % 16 == 0) &&
+                    PER % NV == 0, "unsupported tile split");
   uint32_t voff[NV];    // this lane's byte offset inside a tile for pieces 0 .. NV-1
   uint32_t piece_step;  // bytes between the rows of pieces i and i + NV (wave-uniform)
   FAT5_DEV void init(int64_t row_stride, int tid) {
@@ -384,12 +385,16 @@ struct DmaStage {
   }
   // tile at byte offset tile_off of the descriptor -> LDS image at `img` (workgroup-uniform)
   FAT5_DEV void issue(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, char* img, int tid) const {
+#if defined(__HIP_DEVICE_COMPILE__)  // (hipcc's host pass mis-instantiates templates that reach this builtin)
     typedef __attribute__((address_space(3))) void* lds_t;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
+    for (int i = 0; i < PER; ++i) {
+      if (ITEMS < NT && 64 * wave >= ITEMS) continue;  // wave-uniform
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_t)(uintptr_t)(uint32_t)(uintptr_t)(img + (NT * i + 64 * wave) * 16), 16,
                                                voff[i % NV], tile_off + piece_step * (i / NV), 0, 0);
+    }
+#endif
   }
   // the same pieces into registers (operands that pair with a DMA'd tile piece by piece)
   FAT5_DEV u32x4 load_piece(__amdgpu_buffer_rsrc_t rsrc, uint32_t tile_off, int i) const {

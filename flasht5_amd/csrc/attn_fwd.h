@@ -103,12 +103,14 @@ FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
 #ifndef FAT5_ABLATE
 #define FAT5_ABLATE 0  // developer ablations (bitmask): 1 no exp, 2 no max, 4 no staging/barrier, 8 no PV, 16 no QK
 #endif
+#ifndef FAT5_FWD_DMA
+#define FAT5_FWD_DMA 1  // K/V tiles global -> LDS directly (buffer_load ... lds) instead of through registers + ds_write
+#endif
 #ifndef FAT5_FWD_MINW
 #define FAT5_FWD_MINW 2  // waves per SIMD the register allocator must leave room for
 #endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_FWD_MINW)))
-void attn_fwd_kernel(const AttnArgs a) {
+FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   using Cfg = FwdCfg<D, NW>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -190,7 +192,11 @@ void attn_fwd_kernel(const AttnArgs a) {
   f32x2 l_run;  // per-lane partial row sum (two interleaved chains: v_pk_add_f32)
 #endif
 
+#if FAT5_FWD_DMA
+  DmaStage<D, BN, NT> kst, vst;
+#else
   RowStage<D, BN, NT> kst, vst;
+#endif
   kst.init(a.ks[2], tid);
   vst.init(a.vs[2], tid);
   const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
@@ -222,8 +228,14 @@ void attn_fwd_kernel(const AttnArgs a) {
     const bool more = (t + 1 < nt);
     // prefetch of the next tile through the buffer descriptors (zero-filled past row N-1 by the hardware)
     if (!(FAT5_ABLATE & 4) && more) {
+#if FAT5_FWD_DMA
+      char* nK = smem + (BUF ^ 1) * Cfg::STAGE;  // (its last readers passed the previous tile's barrier)
+      kst.issue(krs, (uint32_t)(n0 + BN) * kstride_b, nK, tid);
+      vst.issue(vrs, (uint32_t)(n0 + BN) * vstride_b, nK + Cfg::KBYTES, tid);
+#else
       kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
       vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
+#endif
     }
     // ---- S^T = K Q^T for both 32-key blocks first: all K fragments in flight, two independent MFMA chains
     //      (the second block's MFMAs run under the first block's softmax VALU work) ----
@@ -366,12 +378,14 @@ void attn_fwd_kernel(const AttnArgs a) {
     }
 
     if (!(FAT5_ABLATE & 4)) {
+#if !FAT5_FWD_DMA
       if (more) {
         char* nK = smem + (BUF ^ 1) * Cfg::STAGE;
         kst.store_rm(nK, tid);
         vst.store_rm(nK + Cfg::KBYTES, tid);
       }
-      __syncthreads();
+#endif
+      __syncthreads();  // (with DMA staging: carries the vmcnt(0) that retires this wave's pieces)
     }
   };
 
@@ -446,10 +460,15 @@ void attn_fwd_kernel(const AttnArgs a) {
     l_run = f32x2{0.f, 0.f};
 #endif
     if (nt > 0) {
+#if FAT5_FWD_DMA
+      kst.issue(krs, 0, smem, tid);
+      vst.issue(vrs, 0, smem + Cfg::KBYTES, tid);
+#else
       kst.load_buf(krs, 0, tid);
       vst.load_buf(vrs, 0, tid);
       kst.store_rm(smem, tid);
       vst.store_rm(smem + Cfg::KBYTES, tid);
+#endif
     }
     __syncthreads();
 
@@ -529,6 +548,12 @@ void attn_fwd_kernel(const AttnArgs a) {
       }
     if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run + fast_log2(l_tot)) * kLn2 : -INFINITY;
   }
+}
+
+template <int D, bool BF16, int BIAS, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_FWD_MINW)))
+void attn_fwd_kernel(const AttnArgs a) {
+  attn_fwd_body<D, BF16, BIAS, NW>(a);
 }
 
 }  // namespace fat5
