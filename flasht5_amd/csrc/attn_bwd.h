@@ -155,6 +155,10 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(qf[kk]), "v"(dof[kk]));
   asm volatile("" ::"v"(nL2), "v"(delta));
+  // dP^T accumulators start at -delta (this lane's query row): dS = P * dP' needs no per-element subtract
+  f32x16 ndelta16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ndelta16[r] = -delta;
 
   const float c2 = a.scale * kLog2e;
   float cst_neg = 0.f, cst_pos = 0.f;
@@ -187,12 +191,12 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);      // S^T  = K Q^T
-        dp = mfma32<BF16>(vf[kk], dof[kk], kk == 0 ? zero16 : dp);   // dP^T = V dO^T
+        dp = mfma32<BF16>(vf[kk], dof[kk], kk == 0 ? ndelta16 : dp);  // dP^T - delta = V dO^T - delta
       }
       if constexpr (FAST) {
         const float ad = cst + nL2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, ad)) * (dp[r] - delta);
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, ad)) * dp[r];
       } else {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
           float bv[16];
@@ -230,7 +234,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nL2);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * (dp[r] - delta);  // dS = P (dP - delta)   (:713)
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];  // dS = P (dP - delta)   (:713)
         const bool nmask = nb + 32 > N;
         const bool cmask = a.causal && (nb + 31 > qrow0 + P);
         if (nmask || cmask) {
