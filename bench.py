@@ -169,30 +169,44 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
+    from flasht5_amd.sharding import OverlappedGradReduce
+    reducer = OverlappedGradReduce(plan.dbias) if (world > 1 and mode != "none") else None
+
     def step():
         if graph is not None:
             graph.replay()
         else:
             step_local()
-        if world > 1 and mode != "none":
-            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI
-            dist.all_reduce(plan.dbias, op=dist.ReduceOp.SUM)
+        if reducer is not None:
+            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI -- one all-reduce per step,
+            # asynchronous on RCCL's stream (overlaps the next step's kernels like DDP overlaps its buckets)
+            reducer.submit(plan.dbias)
 
     # Untimed pre-warm, by wall clock: a step is ~60 us, so a fixed W would end long before the GPU has left its idle
     # clock (585 MHz -> ~1.95 GHz sustained) and before the host's graph-launch path is warm.
+    # (LOCAL work only: a wall-clock loop runs a different number of iterations on every rank, so it must not
+    # contain collectives)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.5:
         for _ in range(50):
-            step()
+            if graph is not None:
+                graph.replay()
+            else:
+                step_local()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if reducer is not None:
+        reducer.drain()
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if reducer is not None:
+        reducer.drain()  # every step's all-reduce finishes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -48,6 +48,50 @@ def allreduce_bias_grad(grad: torch.Tensor, group=None, async_op: bool = False):
     return None
 
 
+class OverlappedGradReduce:
+    """Data-parallel steps whose only exchange is a tiny gradient (the (num_buckets, H) table gradient, 1.5 KB): the
+    all-reduce of step i runs on RCCL's stream while step i+1 computes, like DDP overlaps its buckets with the rest of
+    the backward.  Two staging buffers alternate: `submit(grad)` snapshots the gradient (stream-ordered copy) and starts
+    one asynchronous SUM all-reduce; the buffer is reused two steps later, after waiting for its previous reduction.
+    Every step's gradient is reduced exactly once; `drain()` waits for whatever is still in flight and returns the
+    results in submission order."""
+
+    def __init__(self, like: torch.Tensor, group=None):
+        self.group = group
+        self.buf = [torch.empty_like(like, dtype=torch.float32) for _ in range(2)]
+        self.work = [None, None]
+        self.n = 0
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def submit(self, grad: torch.Tensor):
+        """returns the reduced gradient of the step submitted two calls ago (None for the first two calls)"""
+        if not self.active:
+            return grad
+        j = self.n % 2
+        done = None
+        if self.work[j] is not None:
+            self.work[j].wait()
+            done = self.buf[j].clone() if self.keep_results else None
+        self.buf[j].copy_(grad)
+        self.work[j] = dist.all_reduce(self.buf[j], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.n += 1
+        return done
+
+    keep_results = False  # tests flip this to check every reduced value; the bench only needs the work done
+
+    def drain(self):
+        out = []
+        if not self.active:
+            return out
+        order = [self.n % 2, (self.n + 1) % 2]  # older submission first
+        for j in order:
+            if self.work[j] is not None:
+                self.work[j].wait()
+                self.work[j] = None
+                out.append(self.buf[j])
+        return out
+
+
 def gather_units(local: torch.Tensor, B: int, H: int, world: int, rank: int, group=None) -> torch.Tensor:
     """Reassemble a (B, H, ...) tensor from per-rank stacks of unit results (test / validation helper; the hot
     path never gathers activations)."""

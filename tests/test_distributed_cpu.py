@@ -64,3 +64,33 @@ def _worker(rank, world, port, B, H, M, N, D):
 def test_two_rank_unit_sharding_and_bias_grad_allreduce():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 3, 4, 40, 56, 32), nprocs=2, join=True)
+
+
+def _overlap_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flasht5_amd.sharding import OverlappedGradReduce
+    grad = torch.zeros(32, 12)
+    red = OverlappedGradReduce(grad)
+    red.keep_results = True
+    got = []
+    steps = 7
+    for i in range(steps):
+        grad.fill_(float((rank + 1) * (i + 1)))  # the "backward" of step i overwrites the gradient buffer
+        r = red.submit(grad)
+        if r is not None:
+            got.append(r)
+    got += [t.clone() for t in red.drain()]
+    assert len(got) == steps  # every step reduced exactly once ...
+    want = sum(r + 1 for r in range(world))
+    for i, t in enumerate(got):  # ... in order, with the value of ITS step (not a later overwrite)
+        assert torch.all(t == want * (i + 1)), (i, t.flatten()[0].item())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_grad_reduce_two_ranks():
+    """bench.py's N>1 path: one asynchronous all-reduce per step, double-buffered, drained at the end."""
+    mp.spawn(_overlap_worker, args=(2, _free_port()), nprocs=2, join=True)
+
