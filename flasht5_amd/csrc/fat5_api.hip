@@ -370,11 +370,11 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
   })
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rmsnorm_bwd launch");
-  const int g2 = (int)((n + 255) / 256);
+  const int g2 = (int)((n + 63) / 64);
   switch (w_dtype) {
-    case FAT5_F32: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F32>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
-    case FAT5_F16: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F16>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
-    default: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_BF16>, dim3(g2), dim3(256), 0, stream, part, dw, blocks, (int)n); break;
+    case FAT5_F32: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F32>, dim3(g2), dim3(1024), 0, stream, part, dw, blocks, (int)n); break;
+    case FAT5_F16: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_F16>, dim3(g2), dim3(1024), 0, stream, part, dw, blocks, (int)n); break;
+    default: hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel<FAT5_BF16>, dim3(g2), dim3(1024), 0, stream, part, dw, blocks, (int)n); break;
   }
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rmsnorm_dw_reduce launch");

@@ -243,16 +243,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_scalar_kernel(const void* __r
   for (int c = threadIdx.x; c < n; c += blockDim.x) out[c] = sdw[c];
 }
 
-// dw[c] = sum_p part[p][c]  -> weight dtype (rms_norm.py:234)
+// dw[c] = sum_p part[p][c]  -> weight dtype (rms_norm.py:234).  Latency-bound: the partial rows were just written by other
+// CUs, every read is a ~1 us round trip -- so all reads of a thread are in flight before its first add.  One workgroup =
+// 64 columns x 16 row groups (1024 threads); thread (g, col) owns the partial rows p = g (mod 16), up to 16 of them per
+// round, summed in a fixed order; the 16 groups are combined through LDS in a fixed tree.  Deterministic.
 template <int WDT>
-__global__ __launch_bounds__(256) void rmsnorm_dw_reduce_kernel(const float* __restrict__ part, void* __restrict__ dw_,
-                                                                int nparts, int n) {
+__global__ __launch_bounds__(1024) void rmsnorm_dw_reduce_kernel(const float* __restrict__ part, void* __restrict__ dw_,
+                                                                 int nparts, int n) {
   typedef Elem<WDT> W;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  __shared__ float sacc[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * n + c];
-  W::st1(reinterpret_cast<typename W::T*>(dw_) + c, acc);
+  if (c < n) {
+    for (int p0 = g; p0 < nparts; p0 += 256) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int pp = p0 + 16 * u;
+        v[u] = (pp < nparts) ? part[(int64_t)pp * n + c] : 0.f;
+      }
+      const float t0 = (v[0] + v[1]) + (v[2] + v[3]), t1 = (v[4] + v[5]) + (v[6] + v[7]);
+      const float t2 = (v[8] + v[9]) + (v[10] + v[11]), t3 = (v[12] + v[13]) + (v[14] + v[15]);
+      acc += (t0 + t1) + (t2 + t3);
+    }
+  }
+  sacc[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && c < n) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      t[k] = (sacc[4 * k][lane] + sacc[4 * k + 1][lane]) + (sacc[4 * k + 2][lane] + sacc[4 * k + 3][lane]);
+    W::st1(reinterpret_cast<typename W::T*>(dw_) + c, (t[0] + t[1]) + (t[2] + t[3]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
