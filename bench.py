@@ -51,8 +51,15 @@ def make_plan(S, mode, device, seed):
     return plan, table, idx
 
 
-def event_time(fn, iters, warmup=3):
-    """average ms per call of fn(), measured with HIP events on the current stream"""
+def event_time(fn, iters, warmup=3, prewarm_s=0.2):
+    """average ms per call of fn(), measured with HIP events on the current stream, at steady-state clocks: a
+    wall-clock pre-warm first (after an idle gap -- plan construction, the previous measurement's teardown -- the GPU
+    sits at its idle clock for the first milliseconds)"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < prewarm_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -241,7 +248,7 @@ def main():
             by_seq = {}
             for s2 in (512, 2048, 8192):
                 p2 = plan if s2 == S else make_plan(s2, mode, device, seed=rank)[0]
-                it = 50 if s2 <= 2048 else 10
+                it = 50 if s2 <= 2048 else 20
                 tf = event_time(p2.forward, it)
                 p2.forward()
                 tb = event_time(p2.backward, it)

@@ -103,11 +103,16 @@ FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
 #ifndef FAT5_ABLATE
 #define FAT5_ABLATE 0  // developer ablations (bitmask): 1 no exp, 2 no max, 4 no staging/barrier, 8 no PV, 16 no QK
 #endif
+#ifndef FAT5_FWD_ONEBLK
+#define FAT5_FWD_ONEBLK 1  // form the scores of ONE 32-key block at a time and fetch V fragments right before their MFMAs:
+                          // ~166 live registers at D <= 64 -> three waves per SIMD (S=2048: 3072 waves = exactly one
+                          // round instead of 1.5; +11 % there, +3-4 % at S=8192).  0: both blocks' scores up front.
+#endif
 #ifndef FAT5_FWD_DMA
 #define FAT5_FWD_DMA 1  // K/V tiles global -> LDS directly (buffer_load ... lds) instead of through registers + ds_write
 #endif
 #ifndef FAT5_FWD_MINW
-#define FAT5_FWD_MINW 2  // waves per SIMD the register allocator must leave room for
+#define FAT5_FWD_MINW 3  // waves per SIMD the register allocator must leave room for at D <= 64 (D = 128: always 2)
 #endif
 template <int D, bool BF16, int BIAS, int NW>
 FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
@@ -237,6 +242,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
 #endif
     }
+#if !FAT5_FWD_ONEBLK
     // ---- S^T = K Q^T for both 32-key blocks first: all K fragments in flight, two independent MFMA chains
     //      (the second block's MFMAs run under the first block's softmax VALU work) ----
     f32x16 sblk[2];
@@ -255,17 +261,32 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
           sblk[kb] = mfma32<BF16>(kf[kb][kk], qf[kk], kk == 0 ? zero16 : sblk[kb]);
         }
     }
+#endif
     // ---- per block: online softmax -> O^T += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int nb = n0 + 32 * kb;
+#if FAT5_FWD_ONEBLK
+      // one block at a time: 32 fewer live registers (fits three waves per SIMD); overlap comes from the other waves
+      f32x16 s;
+      {
+        u32x4 kf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = ld_rm<D>(sK, fa, kb, kk);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
+      }
+#else
       f32x16& s = sblk[kb];
+#endif
+#if !FAT5_FWD_ONEBLK
       u32x4 vfr[2][DB];  // V^T fragments of this block: issued now, consumed after the softmax
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
         for (int db = 0; db < DB; ++db) vfr[t2][db] = ld_tr<D>(sV, fa, kb, t2, db);
       __builtin_amdgcn_sched_barrier(0);
+#endif
 
       float mul, add, mcand;
       if constexpr (MODE == 2) {
@@ -369,12 +390,20 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       for (int t2 = 0; t2 < 2; ++t2) {
         const u32x4 pb = pack8<BF16>(s, t2);
         if (FAT5_ABLATE & 8) { asm volatile("" ::"v"(pb)); continue; }
+#if FAT5_FWD_ONEBLK
+#pragma unroll
+        for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(ld_tr<D>(sV, fa, kb, t2, db), pb, oacc[db]);
+#else
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(vfr[t2][db], pb, oacc[db]);
+#endif
 #if FAT5_PSUM_MFMA
         lacc = mfma32<BF16>(ones, pb, lacc);
 #endif
       }
+#if FAT5_FWD_ONEBLK
+      __builtin_amdgcn_sched_barrier(0);  // keep the next block's fragment loads from being hoisted over this block
+#endif
     }
 
     if (!(FAT5_ABLATE & 4)) {
@@ -551,7 +580,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 }
 
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_FWD_MINW)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
 void attn_fwd_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW>(a);
 }
