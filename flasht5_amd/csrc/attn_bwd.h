@@ -851,8 +851,11 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
 }
 
 // ---- launchable kernels -------------------------------------------------------------------------------------
+#ifndef FAT5_BWDQ_MINW
+#define FAT5_BWDQ_MINW 2  // (3 fits at D <= 64 with a few spills but measured no faster: 82.7 vs 83.3 us at S=2048)
+#endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_BWDQ_MINW : 2)))
 void attn_bwd_q_kernel(const AttnArgs a) {
   attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x);
 }
