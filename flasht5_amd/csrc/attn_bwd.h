@@ -129,8 +129,11 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   }
   const uint16_t* brow = nullptr;
-  if constexpr (BIAS == FAT5_BIAS_DENSE)
+  uint16_t* dsrow = nullptr;  // this lane's row of the rounded dS tile (dense bias gradient), or nullptr
+  if constexpr (BIAS == FAT5_BIAS_DENSE) {
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
+    if (a.ds_out) dsrow = a.ds_out + (int64_t)b * a.dss[0] + (int64_t)h * a.dss[1] + (int64_t)qrow_c * a.dss[2];
+  }
 
   FragAddr<D> fa;
   fa.init(l);
@@ -245,9 +248,31 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
         }
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (dS rounded to the input dtype like the reference, :720)
+      u32x4 dsv[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) dsv[t2] = pack8<BF16>(s, t2);
+      if constexpr (BIAS == FAT5_BIAS_DENSE) {
+        // dense bias gradient: this orientation holds 4 consecutive keys of a query row per register group, so the
+        // rounded dS tile leaves as 8-byte stores (the dK/dV body would need sixteen 2-byte stores per lane)
+        if (dsrow && qrow < M) {
+          if (a.ds_vec4 && nb + 32 <= N) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const u32x2 w2 = {dsv[g >> 1][2 * (g & 1)], dsv[g >> 1][2 * (g & 1) + 1]};
+              *reinterpret_cast<u32x2*>(dsrow + nb + 8 * g + 4 * hi) = w2;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int n = nb + crow(r, hi);
+              if (n < N) dsrow[n] = to16<BF16>(s[r]);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        const u32x4 dsb = pack8<BF16>(s, t2);
+        const u32x4 dsb = dsv[t2];
 #pragma unroll
         for (int db = 0; db < DB; ++db) dqacc[db] = mfma32<BF16>(ld_tr<D>(sK, fa, kb, t2, db), dsb, dqacc[db]);
       }
@@ -329,10 +354,12 @@ struct BwdKVCfg {
   static constexpr int STAGE = 2 * QRM + STAT;
   static constexpr int SKEW_ROW = 160;         // bytes per row of a wave's 32 x 64 bf16 skew tile (padded: tr reads conflict free)
   static constexpr int SKEW = 32 * SKEW_ROW;
+  static constexpr int BIASB = BMQ * BNK * 2;  // dense mode: one (64 query rows x BNK keys) 16-bit bias tile per buffer
   static size_t smem(int R, int bias_mode) {
     // rpe: table + one private accumulator per wave
     // rpe: table + one private diagonal accumulator per wave + one private 32x64 fp32 skew tile per wave
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0);
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0) +
+           (bias_mode == FAT5_BIAS_DENSE ? 2 * (size_t)BIASB : 0);
   }
   static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * NW + 63) / 64 * 64; }
 };
@@ -445,10 +472,16 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
   const uint16_t* bbase = nullptr;
-  uint16_t* dsbase = nullptr;
+  // Dense bias: lane = key, registers = 16 query rows -> a direct read is sixteen 2-byte gathers from 16 rows (0.7 TB/s
+  // measured).  Instead the (64 x BNK) tile of this workgroup goes global -> LDS in 16-byte pieces beside Q / dO (row
+  // major, unswizzled) and the lanes pick their elements with ds_read_u16 (base + immediate offsets).
+  using BDma = DmaStage<BNK, BMQ, NT, false>;
+  BDma bdm;
+  char* sB = smem + 2 * Cfg::STAGE;  // [2][BMQ][BNK] 16-bit
+  const bool bias_dma = (BIAS == FAT5_BIAS_DENSE) && a.bias_dma;
   if constexpr (BIAS == FAT5_BIAS_DENSE) {
     bbase = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1];
-    if (a.ds_out) dsbase = a.ds_out + (int64_t)b * a.dss[0] + (int64_t)h * a.dss[1];
+    bdm.init(a.bs[2], tid);
   }
 
   FragAddr<D> fa;
@@ -475,6 +508,9 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
   const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
   const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
+  const __amdgpu_buffer_rsrc_t brs = make_rows_rsrc(bias_dma ? bbase + n0 : dob, bias_dma ? a.bs[2] : a.dos[2], M,
+                                                    bias_dma ? min(BNK, N - n0) : D);
+  const uint32_t bstride_b = (uint32_t)a.bs[2] * 2u;
   // SELFD: the O pieces that pair with this thread's dO pieces (same row / same swizzled chunk), through registers;
   // rows >= M read as zero -> delta 0
   u32x4 ofr[SELFD ? Dma::PER : 1];
@@ -536,6 +572,8 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   if (ntile > 0) {
     qdm.issue(qrs, (uint32_t)(mt0 * BMQ) * qstride_b, smem, tid);
     dodm.issue(dors, (uint32_t)(mt0 * BMQ) * dostride_b, smem + Cfg::QRM, tid);
+    if constexpr (BIAS == FAT5_BIAS_DENSE)
+      if (bias_dma) bdm.issue(brs, (uint32_t)(mt0 * BMQ) * bstride_b, sB, tid);
     load_stats(mt0 * BMQ);
     store_stats(smem);
   }
@@ -563,6 +601,8 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       char* nb_ = smem + (BUF ^ 1) * Cfg::STAGE;
       qdm.issue(qrs, (uint32_t)(mrow0 + BMQ) * qstride_b, nb_, tid);
       dodm.issue(dors, (uint32_t)(mrow0 + BMQ) * dostride_b, nb_ + Cfg::QRM, tid);
+      if constexpr (BIAS == FAT5_BIAS_DENSE)
+        if (bias_dma) bdm.issue(brs, (uint32_t)(mrow0 + BMQ) * bstride_b, sB + (BUF ^ 1) * Cfg::BIASB, tid);
       load_stats(mrow0 + BMQ);
     }
 #pragma unroll
@@ -606,11 +646,19 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         }
       } else {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
+          if (bias_dma) {
+            // this lane's column of the staged tile: row 32*qbk + crow(r, hi), key 32*w + lq
+            const uint16_t* tb = reinterpret_cast<const uint16_t*>(sB + BUF * Cfg::BIASB) + (32 * qbk + 4 * hi) * BNK + 32 * w + lq;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mb + crow(r, hi);
-            const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
-            s[r] = fmaf(s[r], c2, bvl * kLog2e);
+            for (int r = 0; r < 16; ++r)
+              s[r] = fmaf(s[r], c2, cvt16<BF16>(tb[((r & 3) + 8 * (r >> 2)) * BNK]) * kLog2e);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mb + crow(r, hi);
+              const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
+              s[r] = fmaf(s[r], c2, bvl * kLog2e);
+            }
           }
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           const int R = a.R;
@@ -663,16 +711,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
           }
         }
       }
-      // ---- bias gradient ------------------------------------------------------------------
-      if constexpr (BIAS == FAT5_BIAS_DENSE) {
-        if (dsbase) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mb + crow(r, hi);
-            if (m < M && krow < N) dsbase[(int64_t)m * a.dss[2] + krow] = to16<BF16>(s[r]);
-          }
-        }
-      }
+      // (dense bias gradient: the rounded dS tile is written by the dQ body, whose layout allows 8-byte stores)
       // operands of the two output GEMMs (P and dS rounded to the input dtype like the reference, :702 / :720)
       u32x4 pbv[2], dsv[2];
 #pragma unroll

@@ -222,6 +222,8 @@ struct AttnArgs {
   int32_t total_q, total_k;
   int32_t causal, R;
   int32_t bias_vec4;        // dense bias rows can be read with aligned 8-byte loads
+  int32_t ds_vec4;          // dense dS rows can be written with aligned 8-byte stores
+  int32_t bias_dma;         // dense bias rows are 16-byte aligned: tiles can go global -> LDS directly
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
   float scale;
@@ -364,13 +366,13 @@ struct RowStage {
 // so the swizzle term is the same for every i and one VGPR addresses all pieces).  Rows past the descriptor's
 // end arrive as zeros.  Completion: the issuing wave's vmcnt, then a barrier for the other waves' reads.
 // ------------------------------------------------------------------------------------------
-template <int D, int ROWS, int NT>
+template <int D, int ROWS, int NT, bool SWZ = true>
 struct DmaStage {
   static constexpr int C = D / 8;
   static constexpr int ITEMS = ROWS * C;
   static constexpr int PER = ITEMS >= NT ? ITEMS / NT : 1;  // (ITEMS < NT: the trailing waves have nothing to fetch)
   static constexpr int RP = NT / C;                       // rows covered by one piece of the whole workgroup
-  static constexpr int NV = (RP % 16 == 0) ? 1 : 16 / RP; // distinct swizzle phases among the pieces
+  static constexpr int NV = (RP % 16 == 0 || !SWZ) ? 1 : 16 / RP; // distinct swizzle phases among the pieces
   static_assert((ITEMS % NT == 0 || (NT % ITEMS == 0 && ITEMS % 64 == 0)) && NT % C == 0 && (16 % RP == 0 || RP % 16 == 0) &&
                     PER % NV == 0, "unsupported tile split");
   uint32_t voff[NV];    // this lane's byte offset inside a tile for pieces 0 .. NV-1
@@ -379,7 +381,7 @@ struct DmaStage {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int row = tid / C + RP * v, slot = tid % C;
-      voff[v] = (uint32_t)(row * row_stride * 2 + ((slot ^ swz<D>(row)) << 4));
+      voff[v] = (uint32_t)(row * row_stride * 2 + ((SWZ ? (slot ^ swz<D>(row)) : slot) << 4));
     }
     piece_step = (uint32_t)(RP * NV * row_stride * 2);
   }

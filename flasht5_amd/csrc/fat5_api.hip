@@ -92,6 +92,9 @@ void fill_common(const fat5_attn_params* p, AttnArgs& a) {
   if (p->bias_mode == FAT5_BIAS_DENSE) {
     a.bias_vec4 = ((reinterpret_cast<uintptr_t>(p->bias) & 7) == 0) && (p->bias_stride[0] % 4 == 0) &&
                   (p->bias_stride[1] % 4 == 0) && (p->bias_stride[2] % 4 == 0);
+    static const int bdma_env = [] { const char* e = getenv("FAT5_BIAS_DMA"); return e ? atoi(e) : 1; }();
+    a.bias_dma = bdma_env && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
+                 (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0);
   }
 }
 
@@ -234,7 +237,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       a.ds_out = (uint16_t*)p->dbias;
     }
     a.dss[0] = (int64_t)p->H * MN; a.dss[1] = MN; a.dss[2] = p->N;
-    if (p->causal && (stages & FAT5_BWD_DKDV)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
+    a.ds_vec4 = (p->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 7) == 0);
+    if (p->causal && (stages & FAT5_BWD_DQ)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
       hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
       if (e != hipSuccess) return hip_fail(e, "memset ds");
     }
