@@ -359,3 +359,77 @@ def test_bad_arguments_raise():
         flash_attention_v2_bias(q.float(), k.float(), v.float(), None)
     with pytest.raises(RuntimeError):
         flash_attention_v2_bias(q.cpu(), k.cpu(), v.cpu(), None)  # no CPU fallback
+
+
+# ---- seeded shape fuzz: every bias mode / dtype / mask / tail combination the tile classifiers can see ------------
+def _fuzz_cases():
+    import random
+    rnd = random.Random(20260928)
+    cases = []
+    for i in range(36):
+        D = rnd.choice([32, 64, 64, 64, 128])
+        M = rnd.choice([1, 17, 33, 64, 95, 128, 200, 257, 320, 449, 512, 700])
+        N = rnd.choice([1, 19, 32, 64, 100, 128, 191, 256, 333, 448, 512, 640])
+        cases.append((i, rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5]), M, N, D, rnd.choice([False, True]),
+                      rnd.choice(["none", "dense_bh", "dense_1h", "dense_11", "rpe", "rpe", "rpe_uni"]),
+                      rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16]), rnd.choice([16, 32, 64, 128]),
+                      rnd.choice([1.0, 0.125, 0.37])))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-B{c[1]}H{c[2]}M{c[3]}N{c[4]}D{c[5]}{'c' if c[6] else ''}-{c[7]}")
+def test_fuzz_shapes_modes(case):
+    from flasht5_amd import flash_attention_v2_rpe
+    _, B, H, M, N, D, causal, mode, dtype, md, scale = case
+    if mode == "rpe_uni" and md <= 16:
+        md = 64  # unidirectional: max_exact = 16, max_distance must exceed it (the reference formula divides by log(md/16))
+    if mode.startswith("rpe"):
+        q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=case[0])
+        g = torch.Generator().manual_seed(case[0] + 500)
+        table = torch.randn(32, H, generator=g) * 0.5
+        bidir = mode == "rpe"
+        bias = oracle.compute_bias(table, M, N, bidir, 32, md).contiguous().cuda()
+        ref = oracle_all(q, k, v, bias, do, scale, causal)
+        leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+        tb = table.cuda().requires_grad_()
+        o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, scale)
+        dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+        got = {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv}
+        _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, bias, o.detach(), ref["L"], do, scale, causal)
+        tl = table.clone().requires_grad_()
+        oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db_alg.cpu())
+        assert torch.isfinite(dt).all()
+        assert maxdiff(dt.cpu(), tl.grad) <= 1e-2 * max(1.0, tl.grad.abs().max().item()) + 3e-2
+    else:
+        kind = {"none": None, "dense_bh": "bh", "dense_1h": "1h", "dense_11": "11"}[mode]
+        q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, kind, seed=case[0])
+        ref = oracle_all(q, k, v, b, do, scale, causal)
+        got = run_dense(q, k, v, b, do, scale, causal)
+        if b is not None:
+            assert maxdiff(got["db"], ref["db"]) <= gbound(ref["db"], dtype) * (2.0 if kind != "bh" else 1.0)
+    for key in ("o", "dq", "dk", "dv"):
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), key
+
+
+@pytest.mark.parametrize("M,N,causal,md,bidir,dtype", [
+    (1536, 1536, False, 32, True, torch.bfloat16), (1100, 1300, False, 64, True, torch.bfloat16),
+    (1300, 1100, True, 32, True, torch.bfloat16), (1024, 1600, True, 128, False, torch.float16),
+    (1601, 999, False, 16, True, torch.float16), (2048, 2048, True, 64, True, torch.bfloat16)])
+def test_rpe_long_rows_far_and_near_tiles(M, N, causal, md, bidir, dtype):
+    """Sequences several times the RPE radius: far-constant FAST tiles on both sides of the band, generic tiles on the band
+    and at the causal / tail edges, and the carried diagonal sums across many consecutive near blocks."""
+    from flasht5_amd import flash_attention_v2_rpe
+    B, H = 1, 2
+    q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, bidir, md, seed=M + 7 * N)
+    ref = oracle_all(q, k, v, bias, do, 0.125, causal)
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    tb = table.cuda().requires_grad_()
+    o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, 0.125)
+    dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+    _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, bias, o.detach(), ref["L"], do, 0.125, causal)
+    tl = table.clone().requires_grad_()
+    oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db_alg.cpu())
+    for got, key in ((o, "o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert maxdiff(got, ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), key
+    assert maxdiff(dt.cpu(), tl.grad) <= 1e-2 * max(1.0, tl.grad.abs().max().item()) + 3e-2
