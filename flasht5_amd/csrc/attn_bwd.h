@@ -36,8 +36,10 @@ struct BwdQCfg {
   static constexpr int KRM = rm_bytes<D, BN>();
   static constexpr int VRM = rm_bytes<D, BN>();
   static constexpr int STAGE = KRM + VRM;
+  static constexpr int BIASB = BM * BN * 2;  // dense mode: one (BM x 64) 16-bit bias tile per buffer
   static size_t smem(int R, int bias_mode) {
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0);
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) +
+           (bias_mode == FAT5_BIAS_DENSE ? 2 * (size_t)BIASB : 0);
   }
 };
 
@@ -130,9 +132,25 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   }
   const uint16_t* brow = nullptr;
   uint16_t* dsrow = nullptr;  // this lane's row of the rounded dS tile (dense bias gradient), or nullptr
+  uint16_t* dstile = nullptr; // the (b, h) slice of the dS output
+  // dense bias tiles: global -> LDS beside K / V (see the forward)
+  using BDma = DmaStage<BN, BM, NT, true>;
+  BDma bdm;
+  BiasTileReader brd;
+  char* sB = smem + 2 * Cfg::STAGE;  // [2][BM][64] 16-bit
+  const bool bias_dma = (BIAS == FAT5_BIAS_DENSE) && a.bias_dma && a.cu_q == nullptr;
+  __amdgpu_buffer_rsrc_t brs = make_rows_rsrc(qb, a.qs[2], 0, D);
   if constexpr (BIAS == FAT5_BIAS_DENSE) {
+    if (bias_dma) {
+      bdm.init(a.bs[2], tid);
+      brd.init(32 * w + lq, hi);
+      brs = make_rows_rsrc(a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)m0 * a.bs[2], a.bs[2], M - m0, N);
+    }
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
-    if (a.ds_out) dsrow = a.ds_out + (int64_t)b * a.dss[0] + (int64_t)h * a.dss[1] + (int64_t)qrow_c * a.dss[2];
+    if (a.ds_out) {
+      dstile = a.ds_out + (int64_t)b * a.dss[0] + (int64_t)h * a.dss[1];
+      dsrow = dstile + (int64_t)qrow_c * a.dss[2];
+    }
   }
 
   FragAddr<D> fa;
@@ -152,6 +170,8 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   if (nt > 0) {
     kst.issue(krs, 0, smem, tid);
     vst.issue(vrs, 0, smem + Cfg::KRM, tid);
+    if constexpr (BIAS == FAT5_BIAS_DENSE)
+      if (bias_dma) bdm.issue(brs, 0, sB, tid);
   }
   __syncthreads();
   // see attn_fwd.h: keep the compiler's waitcnt model from chaining the loop's MFMAs to the tile prefetch
@@ -175,11 +195,15 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     const int n0 = t * BN;
     const char* sK = smem + BUF * Cfg::STAGE;
     const char* sV = sK + Cfg::KRM;
+    // dense dS of a full tile goes through LDS (whole-row stores); tails and unaligned outputs use per-lane stores
+    const bool ds_lds = (BIAS == FAT5_BIAS_DENSE) && bias_dma && dstile != nullptr && a.ds_vec8 && (n0 + BN <= N);
     const bool more = (t + 1 < nt);
     if (more) {
       char* nK = smem + (BUF ^ 1) * Cfg::STAGE;  // (its last readers passed the previous tile's barrier)
       kst.issue(krs, (uint32_t)(n0 + BN) * kstride_b, nK, tid);
       vst.issue(vrs, (uint32_t)(n0 + BN) * vstride_b, nK + Cfg::KRM, tid);
+      if constexpr (BIAS == FAT5_BIAS_DENSE)
+        if (bias_dma) bdm.issue(brs, (uint32_t)(n0 + BN) * 2u, sB + (BUF ^ 1) * Cfg::BIASB, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -203,7 +227,8 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
       } else {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
           float bv[16];
-          load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
+          if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kb, bv);
+          else load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, fmaf(bv[r], kLog2e, nL2));
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
@@ -254,7 +279,11 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
       if constexpr (BIAS == FAT5_BIAS_DENSE) {
         // dense bias gradient: this orientation holds 4 consecutive keys of a query row per register group, so the
         // rounded dS tile leaves as 8-byte stores (the dK/dV body would need sixteen 2-byte stores per lane)
-        if (dsrow && qrow < M) {
+        if (ds_lds) {
+          // full tile: park the rounded dS block in the (already consumed) bias tile, same positions; it leaves the
+          // workgroup as whole 128-byte rows at the end of the tile
+          brd.store(sB + BUF * Cfg::BIASB, kb, dsv);
+        } else if (dsrow && qrow < M) {
           if (a.ds_vec4 && nb + 32 <= N) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -275,6 +304,21 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
         const u32x4 dsb = dsv[t2];
 #pragma unroll
         for (int db = 0; db < DB; ++db) dqacc[db] = mfma32<BF16>(ld_tr<D>(sK, fa, kb, t2, db), dsb, dqacc[db]);
+      }
+    }
+    if constexpr (BIAS == FAT5_BIAS_DENSE) {
+      if (ds_lds) {
+        // this wave's 32 rows x 128 bytes of dS (written by this wave only): 16-byte pieces, 8 lanes per row -> every
+        // store instruction writes 8 whole rows of the tile
+        const char* tl = sB + BUF * Cfg::BIASB + (32 * w) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = l + 64 * i, row = j >> 3, slot = j & 7;
+          const u32x4 vv = *reinterpret_cast<const u32x4*>(tl + row * 128 + slot * 16);
+          const int m = m0 + 32 * w + row;
+          const int n = n0 + ((slot ^ swz<64>(row)) << 3);
+          if (m < M) *reinterpret_cast<u32x4*>(dstile + (int64_t)m * a.dss[2] + n) = vv;
+        }
       }
     }
     __syncthreads();

@@ -223,6 +223,7 @@ struct AttnArgs {
   int32_t causal, R;
   int32_t bias_vec4;        // dense bias rows can be read with aligned 8-byte loads
   int32_t ds_vec4;          // dense dS rows can be written with aligned 8-byte stores
+  int32_t ds_vec8;          // ... and with aligned 16-byte stores (rows start 16-byte aligned)
   int32_t bias_dma;         // dense bias rows are 16-byte aligned: tiles can go global -> LDS directly
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
@@ -404,6 +405,44 @@ struct DmaStage {
   }
   // LDS byte offset of the 16 bytes this thread's piece i lands at
   FAT5_DEV static constexpr int own_off(int tid, int i) { return (tid + NT * i) * 16; }
+};
+
+// ------------------------------------------------------------------------------------------
+// Dense-bias tile of a query-parallel body (forward, dQ): (32*NW query rows) x 64 keys, 16-bit, staged global -> LDS
+// by DmaStage<64, rows, NT> (source-swizzled like a D = 64 image).  Lane (row, hi) needs, per 32-key block kb, the
+// four 8-byte groups of keys 32*kb + 8*g + 4*hi .. +3: chunk 4*kb + g, half hi.  With slot = chunk ^ swz<64>(row) the
+// XOR splits into a kb part (bit 2) and a g part (bits 0-1), so two base offsets and four group offsets per lane
+// address everything with plain adds; the 32 rows of a wave spread over all banks (unswizzled they would share one).
+// ------------------------------------------------------------------------------------------
+struct BiasTileReader {
+  int base[2];  // byte offset of (row, kb), half hi
+  int goff[4];  // byte offset of group g
+  FAT5_DEV void init(int row, int hi) {
+    const int sw = swz<64>(row);
+    base[0] = row * 128 + ((sw & 4) << 4) + 8 * hi;
+    base[1] = row * 128 + ((4 ^ (sw & 4)) << 4) + 8 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) goff[g] = (g ^ (sw & 3)) << 4;
+  }
+  // overwrite this lane's positions of block kb with four packed 8-byte groups (the dS tile reuses the bias tile)
+  FAT5_DEV void store(char* tile, int kb, const u32x4 (&v)[2]) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 w2 = {v[g >> 1][2 * (g & 1)], v[g >> 1][2 * (g & 1) + 1]};
+      *reinterpret_cast<u32x2*>(tile + base[kb] + goff[g]) = w2;
+    }
+  }
+  template <bool BF16>
+  FAT5_DEV void load(const char* tile, int kb, float (&bv)[16]) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 w = *reinterpret_cast<const u32x2*>(tile + base[kb] + goff[g]);
+      bv[4 * g + 0] = cvt_lo<BF16>(w[0]);
+      bv[4 * g + 1] = cvt_hi<BF16>(w[0]);
+      bv[4 * g + 2] = cvt_lo<BF16>(w[1]);
+      bv[4 * g + 3] = cvt_hi<BF16>(w[1]);
+    }
+  }
 };
 
 // Per-lane LDS byte offsets of the fragment reads, hoisted out of the tile loops.  With the swizzle of

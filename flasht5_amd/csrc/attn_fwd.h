@@ -35,8 +35,10 @@ struct FwdCfg {
   static constexpr int KBYTES = rm_bytes<D, BN>();
   static constexpr int VBYTES = rm_bytes<D, BN>();
   static constexpr int STAGE = KBYTES + VBYTES;
+  static constexpr int BIASB = BM * BN * 2;  // dense mode: one (BM x 64) 16-bit bias tile per buffer
   static size_t smem(int R, int bias_mode) {
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) + 16;
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) + 16 +
+           (bias_mode == FAT5_BIAS_DENSE ? 2 * (size_t)BIASB : 0);
   }
 };
 
@@ -170,8 +172,22 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   }
   const uint16_t* brow = nullptr;
-  if constexpr (BIAS == FAT5_BIAS_DENSE)
+  // dense bias: the (BM x 64) tile of this workgroup goes global -> LDS beside K / V in 16-byte pieces (a direct read is
+  // 8 bytes per lane from 32 different rows per instruction); fallback for rows that are not 16-byte aligned
+  using BDma = DmaStage<BN, BM, NT, true>;
+  BDma bdm;
+  BiasTileReader brd;
+  char* sB = smem + 2 * Cfg::STAGE + 16;  // [2][BM][64] 16-bit (the RPE table region is unused in dense mode)
+  const bool bias_dma = (BIAS == FAT5_BIAS_DENSE) && a.bias_dma && a.cu_q == nullptr;
+  __amdgpu_buffer_rsrc_t brs = make_rows_rsrc(qb, a.qs[2], 0, D);
+  if constexpr (BIAS == FAT5_BIAS_DENSE) {
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
+    if (bias_dma) {
+      bdm.init(a.bs[2], tid);
+      brd.init(32 * w + lq, hi);
+      brs = make_rows_rsrc(a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)m0 * a.bs[2], a.bs[2], M - m0, N);
+    }
+  }
 
   FragAddr<D> fa;
   fa.init(l);
@@ -237,6 +253,8 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       char* nK = smem + (BUF ^ 1) * Cfg::STAGE;  // (its last readers passed the previous tile's barrier)
       kst.issue(krs, (uint32_t)(n0 + BN) * kstride_b, nK, tid);
       vst.issue(vrs, (uint32_t)(n0 + BN) * vstride_b, nK + Cfg::KBYTES, tid);
+      if constexpr (BIAS == FAT5_BIAS_DENSE)
+        if (bias_dma) bdm.issue(brs, (uint32_t)(n0 + BN) * 2u, sB + (BUF ^ 1) * Cfg::BIASB, tid);
 #else
       kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
       vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
@@ -302,7 +320,8 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
           folded = false;
           float bv[16];
-          load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
+          if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kb, bv);
+          else load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bv[r] * kLog2e);
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
@@ -492,6 +511,8 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #if FAT5_FWD_DMA
       kst.issue(krs, 0, smem, tid);
       vst.issue(vrs, 0, smem + Cfg::KBYTES, tid);
+      if constexpr (BIAS == FAT5_BIAS_DENSE)
+        if (bias_dma) bdm.issue(brs, 0, sB, tid);
 #else
       kst.load_buf(krs, 0, tid);
       vst.load_buf(vrs, 0, tid);

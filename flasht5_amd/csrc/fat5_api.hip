@@ -238,6 +238,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     }
     a.dss[0] = (int64_t)p->H * MN; a.dss[1] = MN; a.dss[2] = p->N;
     a.ds_vec4 = (p->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 7) == 0);
+    a.ds_vec8 = (p->N % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 15) == 0);
     if (p->causal && (stages & FAT5_BWD_DQ)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
       hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
       if (e != hipSuccess) return hip_fail(e, "memset ds");
