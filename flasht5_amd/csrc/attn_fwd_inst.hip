@@ -1,6 +1,5 @@
 // Instantiations of the forward kernel for one head_dim (compile with -DFAT5_INST_D=32|64|128).
 #include "attn_fwd.h"
-#include "attn_fwd_pipe.h"
 #include <cstdlib>
 #include "attn_launch.h"
 
@@ -13,30 +12,7 @@
 namespace fat5 {
 
 template <int D, bool BF16, int BIAS, int NW>
-static hipError_t launch_pipe(const AttnArgs& a, int grid, hipStream_t s) {
-  size_t smem = FwdPipeCfg<D, NW>::smem(a.R, BIAS);
-  if (const char* e = getenv("FAT5_FWD_LDS_PAD")) smem += (size_t)atoi(e) * 1024;  // developer knob: limit occupancy
-  auto kern = attn_fwd_pipe_kernel<D, BF16, BIAS, NW>;
-  static size_t configured = 0;  // per instantiation; benign race (idempotent call)
-  if (smem > 48 * 1024 && smem > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    configured = smem;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
-  return hipGetLastError();
-}
-
-// FAT5_FWD_PIPE=0 selects the phase-separated forward of attn_fwd.h (developer A/B); default: pipelined
-static bool use_pipe() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("FAT5_FWD_PIPE"); v = e ? atoi(e) : 0; }
-  return v != 0;
-}
-
-template <int D, bool BF16, int BIAS, int NW>
 static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
-  if (use_pipe()) return launch_pipe<D, BF16, BIAS, NW>(a, grid, s);
   size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
   if (const char* e = getenv("FAT5_FWD_LDS_PAD")) smem += (size_t)atoi(e) * 1024;  // developer knob: limit occupancy
   auto kern = attn_fwd_kernel<D, BF16, BIAS, NW>;
