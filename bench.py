@@ -146,11 +146,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    # developer dry run of the N > 1 control flow on a one-GPU box: FAT5_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # uses gloo (RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("FAT5_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import flasht5_amd  # noqa: F401  raises if libfat5.so is missing
     S, mode = args.seq, args.mode
