@@ -179,7 +179,8 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
 
 static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv) {
   static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
-  return fuse_env && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= 2 * 256;
+  static const long fuse_max = [] { const char* e = getenv("FAT5_BWD_FUSE_MAX"); return e ? atol(e) : 4L * 256; }();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
+  return fuse_env && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
 int fat5_attn_bwd_launches(const fat5_attn_params* p) {
