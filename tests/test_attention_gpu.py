@@ -433,3 +433,17 @@ def test_rpe_long_rows_far_and_near_tiles(M, N, causal, md, bidir, dtype):
     for got, key in ((o, "o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         assert maxdiff(got, ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), key
     assert maxdiff(dt.cpu(), tl.grad) <= 1e-2 * max(1.0, tl.grad.abs().max().item()) + 3e-2
+
+
+@pytest.mark.parametrize("scale", [-0.5, 0.0, 1e-3])
+@pytest.mark.parametrize("kind", [None, "1h"])
+def test_negative_zero_and_tiny_sm_scale(scale, kind):
+    """sm_scale is the caller's (reference :239-240 only fills the default): a negative scale disables the folded fast
+    tiles (max(s*c) = c*max(s) needs c > 0) and flips the sign of the staged -L/scale; an exact zero makes the softmax
+    depend on the bias alone, dq = dk = 0 (the backward substitutes 1e-30: |dq|, |dk| <= 1e-28)."""
+    q, k, v, b, do = make_inputs(2, 2, 200, 264, 64, torch.bfloat16, kind, seed=5)
+    ref = oracle_all(q, k, v, b, do, scale, True)
+    got = run_dense(q, k, v, b, do, scale, True)
+    for key in got:
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16), key
