@@ -116,3 +116,32 @@ def test_shard_units_partition():
             assert max(sizes) - min(sizes) <= 1
     assert heads_needing_reduction(4, 12, 4) == []           # 3 whole heads per rank: no communication
     assert heads_needing_reduction(4, 12, 8) == [1, 4, 7, 10]   # 1.5 heads per rank: every third head is split
+
+
+def test_fake_impls_trace_without_a_gpu():
+    """every custom op has a fake (meta) implementation, so FakeTensor / torch.compile tracing of a model
+    that calls the ops works -- shapes, dtypes and devices of the outputs, checked here on fake CUDA tensors (no GPU)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import flasht5_amd  # noqa: F401  registers the fat5:: ops
+    with FakeTensorMode():
+        bf = dict(dtype=torch.bfloat16, device="cuda")
+        q, k, v = torch.empty(2, 4, 128, 64, **bf), torch.empty(2, 4, 160, 64, **bf), torch.empty(2, 4, 160, 64, **bf)
+        for bias in (None, torch.empty(1, 4, 128, 160, **bf)):
+            o, L = torch.ops.fat5.flash_attn_v2_fwd(q, k, v, bias, True, 0.125)
+            assert o.shape == q.shape and o.dtype == q.dtype and o.device.type == "cuda"
+            assert L.shape == (2, 4, 128) and L.dtype == torch.float32
+            dq, dk, dv, ds = torch.ops.fat5.flash_attn_v2_bwd(o, o, q, k, v, bias, L, True, 0.125)
+            assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+            if bias is not None:
+                assert ds.shape == bias.shape and ds.dtype == bias.dtype
+        x, w = torch.empty(64, 768, **bf), torch.empty(768, **bf)
+        y, rstd = torch.ops.fat5.rmsnorm_fwd(x, w, 1e-6)
+        assert y.shape == x.shape and y.dtype == x.dtype and rstd.shape == (64,) and rstd.dtype == torch.float32
+        dx, dw = torch.ops.fat5.rmsnorm_bwd(y, x, w, rstd, 1e-6)
+        assert dx.shape == x.shape and dw.shape == w.shape and dw.dtype == w.dtype
+        logits = torch.empty(16, 1000, **bf)
+        labels = torch.empty(16, dtype=torch.long, device="cuda")
+        losses, z, lse = torch.ops.fat5.cross_entropy_fwd(logits, labels, None, 0.0, 1.0, 1e-4, -100)
+        assert losses.shape == (16,) and losses.dtype == torch.float32 and z.shape == (16,) and lse.shape == (16,)
+        dl = torch.ops.fat5.cross_entropy_bwd(losses, logits, lse, labels, False, 0.0, 1.0, 1e-4, -100)
+        assert dl.shape == logits.shape and dl.dtype == logits.dtype
