@@ -447,3 +447,24 @@ def test_negative_zero_and_tiny_sm_scale(scale, kind):
     for key in got:
         assert torch.isfinite(got[key].float()).all(), key
         assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16), key
+
+
+def test_torch_compile_aot_eager_traces_the_ops():
+    """The reference registers its kernels as custom ops with fake impls so `torch.compile` can trace through them
+    (flash_attention_v2_bias.py:27,:83-89); same here -- dynamo + AOT autograd (backend "aot_eager": no Triton needed)
+    captures forward and backward and reproduces the eager result bit for bit."""
+    from flasht5_amd import flash_attention_v2_bias
+    q, k, v, b, do = make_inputs(2, 2, 128, 160, 64, torch.bfloat16, "1h", seed=9)
+
+    def f(q, k, v, b):
+        return flash_attention_v2_bias(q, k, v, b, True, 0.125)
+
+    eager = [t.detach().clone().requires_grad_() for t in (q, k, v, b)]
+    oe = f(*eager)
+    ge = torch.autograd.grad(oe, eager, do)
+    comp = [t.detach().clone().requires_grad_() for t in (q, k, v, b)]
+    oc = torch.compile(f, backend="aot_eager", fullgraph=True)(*comp)
+    gc = torch.autograd.grad(oc, comp, do)
+    assert torch.equal(oe, oc)
+    for a, c in zip(ge, gc):
+        assert torch.equal(a, c)
