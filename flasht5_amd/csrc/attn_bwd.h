@@ -126,10 +126,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   const float nL2 = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
 
   const float* sTa = sT;  // this lane's aligned copy of the table
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
-    sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
-  }
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   const uint16_t* brow = nullptr;
   uint16_t* dsrow = nullptr;  // this lane's row of the rounded dS tile (dense bias gradient), or nullptr
   uint16_t* dstile = nullptr; // the (b, h) slice of the dS output
@@ -173,6 +170,8 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     if constexpr (BIAS == FAT5_BIAS_DENSE)
       if (bias_dma) bdm.issue(brs, 0, sB, tid);
   }
+  // (table after the first tile's DMA is in flight: one memory round trip for the prologue)
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   __syncthreads();
   // see attn_fwd.h: keep the compiler's waitcnt model from chaining the loop's MFMAs to the tile prefetch
 #pragma unroll
@@ -510,11 +509,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     return (t0 + t1) + (t2 + t3);
   };
   const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
-    for (int i = tid; i < n1 * NW; i += NT) sD0[i] = 0.f;
-    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
-  }
   const uint16_t* bbase = nullptr;
   // Dense bias: lane = key, registers = 16 query rows -> a direct read is sixteen 2-byte gathers from 16 rows (0.7 TB/s
   // measured).  Instead the (64 x BNK) tile of this workgroup goes global -> LDS in 16-byte pieces beside Q / dO (row
@@ -619,8 +613,14 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     if constexpr (BIAS == FAT5_BIAS_DENSE)
       if (bias_dma) bdm.issue(brs, (uint32_t)(mt0 * BMQ) * bstride_b, sB, tid);
     load_stats(mt0 * BMQ);
-    store_stats(smem);
   }
+  // (after the first tile's loads are in flight: ONE memory round trip for the whole prologue instead of two)
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    for (int i = tid; i < n1 * NW; i += NT) sD0[i] = 0.f;
+    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (ntile > 0) store_stats(smem);
   __syncthreads();
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(kf[kk]), "v"(vf[kk]));

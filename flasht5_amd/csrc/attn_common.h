@@ -192,9 +192,21 @@ FAT5_DEV constexpr int rpe_n1p(int R) { return (2 * R + 1 + 3) & ~3; }
 __host__ __device__ constexpr size_t rpe_table_bytes(int R) { return (size_t)4 * ((2 * R + 1 + 3) & ~3) * 4; }
 FAT5_DEV void rpe_table_fill(float* sT, const float* rpe1d_h, int R, int tid, int nthreads) {
   const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
-  for (int i = tid; i < 4 * n1p; i += nthreads) {
-    const int c = i / n1p, m = i - c * n1p;
-    sT[i] = (m + c < n1) ? rpe1d_h[m + c] * kLog2e : 0.f;
+  // eight global loads in flight per round (a prologue that waits for each load before the next costs a memory round
+  // trip per iteration: +4.6 k cycles measured at cfg2)
+  for (int i0 = tid; i0 < 4 * n1p; i0 += 8 * nthreads) {
+    float vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthreads;
+      const int c = i / n1p, m = i - c * n1p;
+      vv[u] = (i < 4 * n1p && m + c < n1) ? rpe1d_h[m + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nthreads;
+      if (i < 4 * n1p) sT[i] = vv[u] * kLog2e;
+    }
   }
 }
 

@@ -167,10 +167,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     qf[kk] = *reinterpret_cast<const u32x4*>(qb + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
 
   const float* sTa = sT;  // this lane's aligned copy of the table
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
-    sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
-  }
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
   const uint16_t* brow = nullptr;
   // dense bias: the (BM x 64) tile of this workgroup goes global -> LDS beside K / V in 16-byte pieces (a direct read is
   // 8 bytes per lane from 32 different rows per instruction); fallback for rows that are not 16-byte aligned
@@ -224,7 +221,25 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
 
-  __syncthreads();  // sT / sFlag visible
+  // first K/V tile (+ dense bias tile) in flight BEFORE the RPE table is fetched: one memory round trip for the prologue
+  auto stage_first = [&]() {
+    if (nt > 0) {
+#if FAT5_FWD_DMA
+      kst.issue(krs, 0, smem, tid);
+      vst.issue(vrs, 0, smem + Cfg::KBYTES, tid);
+      if constexpr (BIAS == FAT5_BIAS_DENSE)
+        if (bias_dma) bdm.issue(brs, 0, sB, tid);
+#else
+      kst.load_buf(krs, 0, tid);
+      vst.load_buf(vrs, 0, tid);
+      kst.store_rm(smem, tid);
+      vst.store_rm(smem + Cfg::KBYTES, tid);
+#endif
+    }
+  };
+  stage_first();
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  __syncthreads();  // tile 0, sT, sFlag visible
   // Touch the Q fragments here: their global loads are otherwise still "pending" in the compiler's waitcnt model at
   // the loop header, and every QK^T MFMA inside the loop then waits on vmcnt, i.e. on the K/V PREFETCH of its own tile.
 #pragma unroll
@@ -507,20 +522,10 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #else
     l_run = f32x2{0.f, 0.f};
 #endif
-    if (nt > 0) {
-#if FAT5_FWD_DMA
-      kst.issue(krs, 0, smem, tid);
-      vst.issue(vrs, 0, smem + Cfg::KBYTES, tid);
-      if constexpr (BIAS == FAT5_BIAS_DENSE)
-        if (bias_dma) bdm.issue(brs, 0, sB, tid);
-#else
-      kst.load_buf(krs, 0, tid);
-      vst.load_buf(vrs, 0, tid);
-      kst.store_rm(smem, tid);
-      vst.store_rm(smem + Cfg::KBYTES, tid);
-#endif
+    if (pass > 0) {  // (pass 0: staged before the loop)
+      stage_first();
+      __syncthreads();
     }
-    __syncthreads();
 
     int t = 0;
     // range A: exact (all of it, or just the baseline pair of an optimistic pass)
