@@ -942,8 +942,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64
 void attn_bwd_q_kernel(const AttnArgs a) {
   attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x);
 }
+// D = 128: 128 accumulator + 64 K/V fragment registers per lane -- the body needs ~370 VGPRs, so it runs one wave per
+// SIMD (512-register budget) instead of spilling 119 registers at two.
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_BWD_MINW : 1)))
 void attn_bwd_kv_kernel(const AttnArgs a) {
   attn_bwd_kv_body<D, BF16, BIAS, NW, false>(a, blockIdx.x);
 }
@@ -952,7 +954,7 @@ void attn_bwd_kv_kernel(const AttnArgs a) {
 // Neither half depends on the other (the dK/dV half forms delta itself), so a short-sequence backward costs
 // max(dQ, dK/dV) instead of their sum.
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FAT5_BWD_MINW)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_BWD_MINW : 1)))
 void attn_bwd_fused_kernel(const AttnArgs a) {
   if ((int)blockIdx.x < a.n_kv_blocks) attn_bwd_kv_body<D, BF16, BIAS, NW, true>(a, blockIdx.x);
   else attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x - a.n_kv_blocks);

@@ -177,7 +177,8 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
   return L.total;
 }
 
-static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv) {
+static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D) {
+  if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
   static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
   static const long fuse_max = [] { const char* e = getenv("FAT5_BWD_FUSE_MAX"); return e ? atol(e) : 4L * 256; }();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
   return fuse_env && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
@@ -189,7 +190,7 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  return bwd_fusable(L, grid_q, grid_kv) ? 1 : 2;
+  return bwd_fusable(L, grid_q, grid_kv, p->D) ? 1 : 2;
 }
 
 int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) { return fat5_attn_bwd_stages(p, FAT5_BWD_ALL, stream_); }
@@ -257,7 +258,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const long grid_q = bh * a.n_mblk, grid_kv = bh * a.n_nblk;
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
   // side by side (attn_bwd_fused_kernel).  FAT5_BWD_FUSE=0 disables (developer A/B).
-  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, grid_q, grid_kv);
+  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, grid_q, grid_kv, p->D);
   if (fuse) {
     a.n_kv_blocks = (int)grid_kv;
     launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
