@@ -107,7 +107,31 @@ def dtype_code(dt):
 
 
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """raw hipStream_t of torch's current stream on `device` (the C ABI launches there, asynchronously)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+class on_device:
+    """`with on_device(t.device):` -- make the tensor's device current for the C-ABI call (the reference wraps its launches
+    the same way, flash_attention_v2_bias.py:61,:128); a no-op, without touching the runtime, when it already is."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else -1
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx >= 0:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def strides3(t):

@@ -32,7 +32,7 @@ def cross_entropy_fwd(logits: torch.Tensor, labels: torch.Tensor, precomputed_ls
         lse = torch.empty(n_rows, dtype=torch.float32, device=logits.device)
     if n_rows == 0:
         return losses, z_losses, lse
-    with torch.cuda.device(logits.device):
+    with _lib.on_device(logits.device):
         _lib.check(_lib.load().fat5_ce_fwd(
             logits.data_ptr(), labels.data_ptr(), losses.data_ptr(), z_losses.data_ptr(), lse.data_ptr(), n_rows, n_cols,
             logits.stride(0), float(smoothing), float(logit_scale), float(lse_square_scale), int(ignore_index),
@@ -63,7 +63,7 @@ def cross_entropy_bwd(dlosses: torch.Tensor, logits: torch.Tensor, lse: torch.Te
     labels = labels.to(torch.int64).contiguous()
     dlosses = dlosses.to(torch.float32)
     if n_rows > 0:
-        with torch.cuda.device(logits.device):
+        with _lib.on_device(logits.device):
             _lib.check(_lib.load().fat5_ce_bwd(
                 dlosses.data_ptr(), dlosses.stride(0), src.data_ptr(), lse.data_ptr(), labels.data_ptr(), dlogits.data_ptr(),
                 n_rows, n_cols, src.stride(0), dlogits.stride(0), float(smoothing), float(logit_scale),

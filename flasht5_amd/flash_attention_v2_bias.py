@@ -78,7 +78,7 @@ def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
         p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
     elif rpe1d is not None:
         p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd")
     return o, L
 
@@ -119,7 +119,7 @@ def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbi
     nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd")
     return dq, dk, dv, dbias
 
@@ -299,7 +299,7 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max
     cq = cu_seqlens_q.to(torch.int32).contiguous()
     ck = cu_seqlens_k.to(torch.int32).contiguous()
     p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cq.data_ptr(), ck.data_ptr(), Tq, Tk
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
     return o, lse
 
@@ -337,7 +337,7 @@ def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_s
     nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd(varlen)")
     return dq, dk, dv
 

@@ -27,7 +27,7 @@ def rmsnorm_fwd(X: torch.Tensor, weight: torch.Tensor, eps: float) -> Tuple[torc
     rstd = torch.empty((M,), dtype=torch.float32, device=X.device)
     if M == 0:
         return Y, rstd
-    with torch.cuda.device(X.device):
+    with _lib.on_device(X.device):
         _lib.check(_lib.load().fat5_rmsnorm_fwd(
             X.data_ptr(), weight.data_ptr(), Y.data_ptr(), rstd.data_ptr(), M, N, X.stride(0), Y.stride(0),
             float(eps), _lib.dtype_code(X.dtype), _lib.dtype_code(weight.dtype), _lib.stream_ptr(X.device)),
@@ -61,7 +61,7 @@ def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, rstd: t
     lib = _lib.load()
     nbytes = lib.fat5_rmsnorm_bwd_workspace_bytes(M, N)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(lib.fat5_rmsnorm_bwd(
             dy.data_ptr(), x.data_ptr(), weight.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), M, N,
             dy.stride(0), x.stride(0), dx.stride(0), _lib.dtype_code(x.dtype), _lib.dtype_code(weight.dtype),
