@@ -20,4 +20,6 @@ from .cross_entropy_loss import cross_entropy_loss, CrossEntropyLoss  # noqa: E4
 from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_from_table,  # noqa: E402
                                   RelativePositionalEncoding)
 
+from .attention_module import FlashT5Attention  # noqa: E402
+
 __version__ = "0.1.0"

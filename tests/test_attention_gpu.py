@@ -468,3 +468,61 @@ def test_torch_compile_aot_eager_traces_the_ops():
     assert torch.equal(oe, oc)
     for a, c in zip(ge, gc):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("attention_type", ["triton", "fat5_rpe"])
+@pytest.mark.parametrize("decoder", [False, True])
+def test_flasht5_attention_module_two_blocks(attention_type, decoder):
+    """The `FlashT5Attention`-compatible module (reference modeling_flash_t5.py:166-287): block 0 builds the position
+    bias and hands it to block 1 (dense `(1,H,M,N)` tensor, or the `(H,2R+1)` generator in the linear-memory type);
+    outputs and the gradients of every parameter -- including the shared T5 table through both blocks -- against the
+    same computation in eager fp32 (`oracle.attn_ref`)."""
+    from types import SimpleNamespace
+    from flasht5_amd import FlashT5Attention
+    cfg = SimpleNamespace(d_model=128, d_kv=64, num_heads=2, relative_attention_num_buckets=32,
+                          relative_attention_max_distance=64, is_decoder=decoder, attention_type=attention_type,
+                          position_encoding_type="t5", attention_scale=None)
+    torch.manual_seed(31)
+    blk0 = FlashT5Attention(cfg, has_positional_encoding=True, is_causal=decoder).cuda().bfloat16()
+    blk1 = FlashT5Attention(cfg, has_positional_encoding=False, is_causal=decoder).cuda().bfloat16()
+    B, S = 2, 200
+    x = torch.randn(B, S, cfg.d_model, device="cuda").bfloat16()
+    gy = torch.randn(B, S, cfg.d_model, device="cuda").bfloat16()
+    y0, pb = blk0(x)
+    y1, pb1 = blk1(y0, position_bias=pb)
+    params = [p for m in (blk0, blk1) for p in m.parameters()]
+    grads = torch.autograd.grad(y1, params, gy)
+
+    # eager fp32 restatement with the same weights
+    def eager(blk, h, table):
+        H, Dh = cfg.num_heads, cfg.d_kv
+        q = (h @ blk.Wq.weight.float().t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        k = (h @ blk.Wk.weight.float().t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        v = (h @ blk.Wv.weight.float().t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        bias = oracle.compute_bias(table, S, S, not decoder, 32, 64)
+        o = oracle.attn_ref(q, k, v, bias, 1.0 / math.sqrt(H), causal=decoder, upcast=True)
+        return o.permute(0, 2, 1, 3).reshape(B, S, H * Dh) @ blk.o.weight.float().t()
+    ref_params = [p.detach().float().clone().requires_grad_() for p in params]
+    class _W:  # same attribute names, fp32 leaves
+        pass
+    def wrap(offset, has_table):
+        w = _W()
+        names = (["table"] if has_table else []) + ["Wq", "Wk", "Wv", "o"]
+        for i, n in enumerate(names):
+            setattr(w, n, SimpleNamespace(weight=ref_params[offset + i]))
+        return w
+    names0 = [n for n, _ in blk0.named_parameters()]
+    assert names0 == ["pe_encoding.relative_attention_bias.weight", "Wq.weight", "Wk.weight", "Wv.weight", "o.weight"]
+    w0, w1 = wrap(0, True), wrap(5, False)
+    table = ref_params[0]
+    r0 = eager(w0, x.float(), table)
+    r1 = eager(w1, r0, table)
+    ref_grads = torch.autograd.grad(r1, ref_params, gy.float())
+    assert maxdiff(y1, r1) <= 3e-2 * max(1.0, r1.abs().max().item())
+    for (n, _), g, rg in zip(list(blk0.named_parameters()) + list(blk1.named_parameters()), grads, ref_grads):
+        assert torch.isfinite(g.float()).all(), n
+        assert maxdiff(g, rg) <= 4e-2 * max(1.0, rg.abs().max().item()), (n, maxdiff(g, rg), rg.abs().max().item())
+    if attention_type == "fat5_rpe":
+        assert isinstance(pb, tuple) and pb[0].shape == (2, 2 * 64 + 1) and pb1 is pb
+    else:
+        assert pb.shape == (1, 2, S, S) and pb1 is pb
