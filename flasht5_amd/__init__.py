@@ -21,5 +21,6 @@ from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_
                                   RelativePositionalEncoding)
 
 from .attention_module import FlashT5Attention  # noqa: E402
+from .modules import FlashT5LayerNorm, FlashT5CrossEntropyLoss  # noqa: E402
 
 __version__ = "0.1.0"
