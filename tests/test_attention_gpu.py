@@ -526,3 +526,64 @@ def test_flasht5_attention_module_two_blocks(attention_type, decoder):
         assert isinstance(pb, tuple) and pb[0].shape == (2, 2 * 64 + 1) and pb1 is pb
     else:
         assert pb.shape == (1, 2, S, S) and pb1 is pb
+
+
+def test_mini_encoder_training_step_all_three_operators():
+    """A two-block pre-norm T5 encoder slice + LM head + loss built ONLY from the path's three operators (RMSNorm,
+    attention with the shared T5 bias, cross-entropy + z-loss) and plain Linear layers: one training step's loss and
+    parameter gradients against the same network in eager fp32.  (The shape of config 5 at toy size.)"""
+    from types import SimpleNamespace
+    from flasht5_amd import FlashT5Attention, FlashT5LayerNorm, FlashT5CrossEntropyLoss
+    torch.manual_seed(77)
+    B, S, dm, H, Dh, V = 2, 160, 128, 2, 64, 512
+    cfg = SimpleNamespace(d_model=dm, d_kv=Dh, num_heads=H, relative_attention_num_buckets=32,
+                          relative_attention_max_distance=128, is_decoder=False, attention_type="fat5_rpe",
+                          position_encoding_type="t5", attention_scale=None)
+    norms = [FlashT5LayerNorm(dm).cuda().bfloat16() for _ in range(3)]
+    attns = [FlashT5Attention(cfg, has_positional_encoding=(i == 0)).cuda().bfloat16() for i in range(2)]
+    head = torch.nn.Linear(dm, V, bias=False).cuda().bfloat16()
+    crit = FlashT5CrossEntropyLoss(z_loss_factor=1e-4, label_smoothing=0.0)
+    with torch.no_grad():
+        for n in norms:
+            n.weight.copy_(1.0 + 0.1 * torch.randn(dm))
+    x = (torch.randn(B, S, dm, device="cuda") * 0.5).bfloat16()
+    labels = torch.randint(0, V, (B, S), device="cuda")
+    labels[1, -7:] = -100
+
+    h, pb = x, None
+    for i in range(2):
+        a, pb = attns[i](norms[i](h), position_bias=pb)
+        h = h + a
+    loss = crit(head(norms[2](h)), labels)
+    params = [p for m in (*norms, *attns, head) for p in m.parameters()]
+    grads = torch.autograd.grad(loss, params)
+
+    # eager fp32 twin
+    rp = [p.detach().float().clone().requires_grad_() for p in params]
+    it = iter(rp)
+    nw = [next(it) for _ in range(3)]
+    a0 = {n: next(it) for n in ("table", "Wq", "Wk", "Wv", "o")}
+    a1 = {n: next(it) for n in ("Wq", "Wk", "Wv", "o")}
+    hw = next(it)
+    def rms(t, w):
+        return w * (t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6))
+    def att(t, w):
+        q = (t @ w["Wq"].t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        k = (t @ w["Wk"].t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        v = (t @ w["Wv"].t()).view(B, S, H, Dh).permute(0, 2, 1, 3)
+        bias = oracle.compute_bias(a0["table"], S, S, True, 32, 128)
+        o = oracle.attn_ref(q, k, v, bias, 1.0 / math.sqrt(H), causal=False, upcast=True)
+        return o.permute(0, 2, 1, 3).reshape(B, S, H * Dh) @ w["o"].t()
+    hr = x.float()
+    hr = hr + att(rms(hr, nw[0]), a0)
+    hr = hr + att(rms(hr, nw[1]), a1)
+    logits = rms(hr, nw[2]) @ hw.t()
+    flat, lab = logits.view(-1, V), labels.view(-1)
+    per = torch.nn.functional.cross_entropy(flat, lab, reduction="none", ignore_index=-100)
+    per = per + 1e-4 * torch.logsumexp(flat, -1).square() * (lab != -100)
+    rloss = per.mean()
+    rgrads = torch.autograd.grad(rloss, rp)
+    assert abs(loss.item() - rloss.item()) <= 2e-2 * max(1.0, abs(rloss.item())), (loss.item(), rloss.item())
+    for i, (g, rg) in enumerate(zip(grads, rgrads)):
+        assert torch.isfinite(g.float()).all(), i
+        assert maxdiff(g, rg) <= 6e-2 * max(rg.abs().max().item(), 1e-3) + 1e-5, (i, maxdiff(g, rg), rg.abs().max().item())
