@@ -21,7 +21,7 @@ plan.ws.zero_(); torch.cuda.synchronize()
 plan.backward(3); torch.cuda.synchronize()
 # delta scratch is the first region of the workspace
 n = plan.bwd_launches()
-raw = plan.ws[: 384 * 16 * 8]  # (delta scratch = first region of the workspace).view(torch.int64).cpu().numpy().reshape(384, 16)
+raw = plan.ws[: 384 * 16 * 8].view(torch.int64).cpu().numpy().reshape(384, 16)  # delta scratch = first region of the workspace
 t0 = raw[raw[:, 0] > 0, 0].min()
 def show(name, rows):
     r = rows.astype(np.float64)
