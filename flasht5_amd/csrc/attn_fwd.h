@@ -27,9 +27,12 @@ namespace fat5 {
 #define FAT5_DEFER_THR 6.0f  // log2 units: P <= 2^6 while the running max is stale
 #endif
 
-template <int D, int NW>
+// SPLIT: short sequences (grid smaller than the chip): TWO waves share 32 query rows, wave `half` takes the first / second
+// 32-key block of every staged 64-key tile; their (m, l, O) are merged through LDS at the end.  Twice the workgroups,
+// half the sequential blocks per wave, same staging traffic per key.
+template <int D, int NW, bool SPLIT = false>
 struct FwdCfg {
-  static constexpr int BM = 32 * NW;
+  static constexpr int BM = SPLIT ? 16 * NW : 32 * NW;
   static constexpr int BN = 64;
   static constexpr int NT = 64 * NW;
   static constexpr int KBYTES = rm_bytes<D, BN>();
@@ -116,9 +119,10 @@ FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
 #ifndef FAT5_FWD_MINW
 #define FAT5_FWD_MINW 3  // waves per SIMD the register allocator must leave room for at D <= 64 (D = 128: always 2)
 #endif
-template <int D, bool BF16, int BIAS, int NW>
+template <int D, bool BF16, int BIAS, int NW, bool SPLIT = false>
 FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
-  using Cfg = FwdCfg<D, NW>;
+  static_assert(!SPLIT || (FAT5_FWD_ONEBLK && FAT5_FWD_DMA && NW % 2 == 0), "SPLIT needs the one-block-at-a-time DMA body");
+  using Cfg = FwdCfg<D, NW, SPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,6 +130,9 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + 16);
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
+  constexpr int QG = SPLIT ? NW / 2 : NW;              // query groups (32 rows each) per workgroup
+  const int half = SPLIT ? w / QG : 0;                 // SPLIT: which 32-key block of every tile this wave owns
+  const int qg = SPLIT ? w - half * QG : w;
   int bh, mblk;
   decode_block(blockIdx.x, a.B * a.H, a.n_mblk, bh, mblk);
   const int b = bh / a.H, h = bh % a.H;
@@ -156,7 +163,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   if (a.causal) n_end = min(N, m0 + BM + P);
   const int nt = n_end > 0 ? (n_end + BN - 1) / BN : 0;
 
-  const int qrow0 = m0 + 32 * w;        // first query row of this wave
+  const int qrow0 = m0 + 32 * qg;       // first query row of this wave
   const int qrow = qrow0 + lq;          // this lane's query row
   const int qrow_c = min(qrow, M - 1);  // clamped for loads
 
@@ -181,7 +188,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     brow = a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)qrow_c * a.bs[2];
     if (bias_dma) {
       bdm.init(a.bs[2], tid);
-      brd.init(32 * w + lq, hi);
+      brd.init(32 * qg + lq, hi);
       brs = make_rows_rsrc(a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)m0 * a.bs[2], a.bs[2], M - m0, N);
     }
   }
@@ -296,16 +303,19 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     }
 #endif
     // ---- per block: online softmax -> O^T += V^T P^T ----
+    const char* sKb = sK + (SPLIT ? half * 64 * D : 0);  // (32 rows of 2*D bytes)
+    const char* sVb = sV + (SPLIT ? half * 64 * D : 0);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int nb = n0 + 32 * kb;
+    for (int kb = 0; kb < (SPLIT ? 1 : 2); ++kb) {
+      const int kbr = SPLIT ? half : kb;  // block index inside the tile
+      const int nb = n0 + 32 * kbr;
 #if FAT5_FWD_ONEBLK
       // one block at a time: 32 fewer live registers (fits three waves per SIMD); overlap comes from the other waves
       f32x16 s;
       {
         u32x4 kf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = ld_rm<D>(sK, fa, kb, kk);
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = ld_rm<D>(sKb, fa, kb, kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
       }
@@ -335,7 +345,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         if constexpr (BIAS == FAT5_BIAS_DENSE) {
           folded = false;
           float bv[16];
-          if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kb, bv);
+          if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kbr, bv);
           else load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bv[r] * kLog2e);
@@ -426,7 +436,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         if (FAT5_ABLATE & 8) { asm volatile("" ::"v"(pb)); continue; }
 #if FAT5_FWD_ONEBLK
 #pragma unroll
-        for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(ld_tr<D>(sV, fa, kb, t2, db), pb, oacc[db]);
+        for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(ld_tr<D>(sVb, fa, kb, t2, db), pb, oacc[db]);
 #else
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(vfr[t2][db], pb, oacc[db]);
@@ -583,6 +593,33 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     }
   }
 
+#if !FAT5_PSUM_MFMA
+  if constexpr (SPLIT) {
+    // merge the two key halves of every query group: wave (half 1) parks its state in LDS (the tile buffers are dead:
+    // every wave is past the last tile's barrier), wave (half 0) folds it in with the usual two-reference-point rule
+    float* sx = reinterpret_cast<float*>(smem) + qg * (2 + 16 * DB) * 64 + l;  // [2 + 16*DB][64 lanes] per query group
+    if (half == 1) {
+      sx[0] = m_run;
+      sx[64] = l_run[0] + l_run[1];
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sx[(2 + 16 * db + r) * 64] = oacc[db][r];
+    }
+    __syncthreads();
+    if (half == 1) return;
+    const float m_b = sx[0], l_b = sx[64];
+    const float m_n = fmaxf(m_run, m_b);
+    const float sa = (m_run == -INFINITY) ? 0.f : fast_exp2(m_run - m_n);
+    const float sb = (m_b == -INFINITY) ? 0.f : fast_exp2(m_b - m_n);
+    l_run = f32x2{(l_run[0] + l_run[1]) * sa + l_b * sb, 0.f};
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] = oacc[db][r] * sa + sx[(2 + 16 * db + r) * 64] * sb;
+    m_run = m_n;
+  }
+#endif
   // ---- epilogue: o = acc / l, L = m + ln(l) --------------------------------------------------
 #if FAT5_PSUM_MFMA
   const float l_tot = lacc[0];
@@ -609,6 +646,11 @@ template <int D, bool BF16, int BIAS, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
 void attn_fwd_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW>(a);
+}
+template <int D, bool BF16, int BIAS, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
+void attn_fwd_split_kernel(const AttnArgs a) {
+  attn_fwd_body<D, BF16, BIAS, NW, true>(a);
 }
 
 }  // namespace fat5

@@ -27,7 +27,22 @@ static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
 }
 
 template <int D, bool BF16, int BIAS>
+static hipError_t launch_split(const AttnArgs& a, int grid, hipStream_t s) {
+  size_t smem = FwdCfg<D, 4, true>::smem(a.R, BIAS);
+  auto kern = attn_fwd_split_kernel<D, BF16, BIAS, 4>;
+  static size_t configured = 0;
+  if (smem > 48 * 1024 && smem > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    configured = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+template <int D, bool BF16, int BIAS>
 static hipError_t launch_nw(const AttnArgs& a, int nw, int grid, hipStream_t s) {
+  if (nw == -4) return launch_split<D, BF16, BIAS>(a, grid, s);  // two waves per 32 query rows (short sequences)
   if (nw == 2) return launch_one<D, BF16, BIAS, 2>(a, grid, s);
   if (nw == 8) return launch_one<D, BF16, BIAS, 8>(a, grid, s);
   return launch_one<D, BF16, BIAS, 4>(a, grid, s);

@@ -135,8 +135,16 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   AttnArgs a;
   fill_common(p, a);
   const long bh = (long)p->B * p->H;
-  const int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW", true);
+  int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW", true);
   a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
+  // short sequences: with 4-wave tiles the grid is smaller than the chip and every wave walks all keys alone -> two
+  // waves per 32 query rows, each taking one 32-key block of every tile (attn_fwd_split_kernel; FAT5_FWD_SPLIT=0 disables)
+  static const int split_env = env_int("FAT5_FWD_SPLIT", 1);
+  const long ctas4 = bh * ((p->M + 127) / 128);
+  if (split_env && env_int("FAT5_FWD_NW", 0) == 0 && ctas4 <= 256 && bh * ((p->M + 63) / 64) >= 96 && p->N >= 128) {
+    nw = -4;
+    a.n_mblk = (p->M + 63) / 64;
+  }
   const long grid = bh * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
