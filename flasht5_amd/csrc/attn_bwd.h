@@ -473,11 +473,11 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   char* sG = smem + 2 * Cfg::STAGE + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
   // element r of this lane (row crow(r, hi), key lq): byte offset sk_w + 158 * ((r & 3) + 8 * (r >> 2))
   const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
-  int sk_r[2];  // transposing reads: rows 8*j2 + 4*hi + e (+16 per k-step), 16-column group g, 8-byte piece c
+  int sk_r[2];  // transposing reads of a 16x16x32 B fragment: rows 8*(l >> 4) + 4*u + e, 8-byte piece c (+32 bytes per 16 columns)
   {
-    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g = (l >> 4) & 1;
+    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g4 = l >> 4;
 #pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2) sk_r[j2] = (8 * j2 + 4 * hi + e) * Cfg::SKEW_ROW + 32 * g + 8 * c;
+    for (int u = 0; u < 2; ++u) sk_r[u] = (8 * g4 + 4 * u + e) * Cfg::SKEW_ROW + 8 * c;
   }
   const uint32_t one2s = pack2<BF16>(1.f, 1.f);
   const u32x4 ones = {one2s, one2s, one2s, one2s};
@@ -805,26 +805,30 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       }
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         if (near_blk) {
-          // column sums of the skew tile on the matrix pipe: C = ones(32x32) x tile; every row of C is the vector of
-          // column sums, lane l holds column (l & 31) of its half.  (The row order inside a fragment is irrelevant.)
+          // column sums of the skew tile on the matrix pipe: C = ones(16x32) x tile[32 rows][16 columns] per 16x16x32
+          // MFMA (all 32 rows in one k-step); every row of C is the vector of column sums, lane l holds column (l & 15)
+          // of its 16-column group.  (The row order inside a fragment is irrelevant.)  Tried and dropped: deferring
+          // this to the next block (issue behind its S / dP MFMAs, consume after its softmax) -- slower, the extra
+          // state and code in every tile variant cost more than the hidden latency.
           typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-          f32x16 clo, chi;
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          float cs[4];
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-              const char* p0 = sG + sk_r[0] + 16 * ks * Cfg::SKEW_ROW + 64 * ch;
-              const char* p1 = sG + sk_r[1] + 16 * ks * Cfg::SKEW_ROW + 64 * ch;
-              const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
-              const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
-              const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
-              if (ch == 0) clo = mfma32<BF16>(ones, fr, ks == 0 ? zero16 : clo);
-              else chi = mfma32<BF16>(ones, fr, ks == 0 ? zero16 : chi);
-            }
+          for (int cb = 0; cb < 4; ++cb) {
+            const char* p0 = sG + sk_r[0] + 32 * cb;
+            const char* p1 = sG + sk_r[1] + 32 * cb;
+            const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
+            const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
+            const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
+            cs[cb] = mfma16<BF16>(ones, fr, zero4)[0];
+          }
+          // lane c < 32: column c is in group c >> 4 (low half), column 32 + c in group 2 + (c >> 4)
+          const bool up = (lq & 16) != 0;
+          const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
           const int d_hi0 = krow0 - mb + 1;  // diagonal of column 32
           if (carry_valid && carry_d0 != d_hi0) flush_carry();
-          emit_diag(chi[0] + (carry_valid ? carry : 0.f), d_hi0 + lq);
-          carry = clo[0];
+          emit_diag(c_hi + (carry_valid ? carry : 0.f), d_hi0 + lq);
+          carry = c_lo;
           carry_d0 = krow0 - mb - 31;
           carry_valid = true;
         }

@@ -41,6 +41,18 @@ FAT5_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// MFMA 16x16x32 (A: 16x32, B: 32x16, C/D: 16x16 fp32): B lane l: col = l & 15, eight k values per lane, the four
+// 16-lane groups cover k = 0..31; C lane l: col = l & 15, rows 4*(l >> 4) + i.
+template <bool BF16>
+FAT5_DEV f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+}
+
 FAT5_DEV constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 template <bool BF16>
