@@ -71,9 +71,22 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   for (int wv = tid; wv < 4 * n1; wv += 1024) {
     const int i = wv % n1, g = wv / n1;
     float acc = 0.f;
-    for (int pidx = g; pidx < nparts; pidx += 4) {
-      const int b = pidx / nblk, blk = pidx % nblk;
-      acc += part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
+    // 16 partial rows per round, all loads in flight before the first add (each is a cross-XCD round trip: walking
+    // them one by one cost 39 us for the 256 partial rows per head of S = 8192); adds stay in the chain's fixed order
+    for (int p0 = g; p0 < nparts; p0 += 64) {
+      float vv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int pidx = p0 + 4 * u;
+        vv[u] = 0.f;
+        if (pidx < nparts) {
+          const int b = pidx / nblk, blk = pidx - b * nblk;
+          vv[u] = part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (p0 + 4 * u < nparts) acc += vv[u];
     }
     sv4[g * n1 + i] = acc;
   }
