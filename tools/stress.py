@@ -1,0 +1,34 @@
+"""race screen: the same problem many times, every output compared bit for bit with the first run (developer tool).
+LDS-DMA ordering mistakes show up as rare wrong tiles under load, not as a failing unit test."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from attn_helpers import make_inputs
+from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+from flasht5_amd import positional_encoding as pe
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+bad = 0
+for S, D, H in ((512, 64, 12), (2048, 64, 12), (777, 128, 3), (1024, 32, 6)):
+    for mode in ("none", "rpe", "dense"):
+        for causal in (False, True):
+            q, k, v, _, do = make_inputs(4, H, S, S, D, torch.bfloat16, None, seed=S + D, strided=True)
+            kw = {}
+            table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+            if mode == "rpe":
+                kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+            elif mode == "dense":
+                kw = dict(bias=pe.compute_bias(table, S, S).to(torch.bfloat16).contiguous())
+            plan = AttentionPlan(q, k, v, do, sm_scale=D ** -0.5, causal=causal, **kw)
+            plan.forward(); plan.backward(); torch.cuda.synchronize()
+            ref = [t.clone() for t in (plan.o, plan.lse, plan.dq, plan.dk, plan.dv)] + ([plan.dbias.clone()] if plan.dbias is not None else [])
+            n_bad = 0
+            for i in range(reps):
+                plan.forward(); plan.backward()
+                if i % 25 == 24 or i == reps - 1:
+                    torch.cuda.synchronize()
+                    cur = [plan.o, plan.lse, plan.dq, plan.dk, plan.dv] + ([plan.dbias] if plan.dbias is not None else [])
+                    n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, cur))
+            print(f"S={S} D={D} {mode:5s} causal={int(causal)}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
+            bad += n_bad
+print("TOTAL MISMATCHES", bad)
