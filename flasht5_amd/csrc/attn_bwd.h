@@ -895,25 +895,8 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   }
   if (i < ntile) tile.template operator()<false, 0, 0>(mt0 + i, 0.f);
 
-  if (krow < N) {
-    const float scale = a.scale;
-    uint16_t* dkrow = dkb + (int64_t)krow * a.dks[2];
-    uint16_t* dvrow = dvb + (int64_t)krow * a.dvs[2];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 wk, wv;
-        wk[0] = pack2<BF16>(dkacc[db][4 * g + 0] * scale, dkacc[db][4 * g + 1] * scale);
-        wk[1] = pack2<BF16>(dkacc[db][4 * g + 2] * scale, dkacc[db][4 * g + 3] * scale);
-        wv[0] = pack2<BF16>(dvacc[db][4 * g + 0], dvacc[db][4 * g + 1]);
-        wv[1] = pack2<BF16>(dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
-        *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * hi) = wk;
-        *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
-      }
-  }
-  FAT5_STAMP(14);
-
+  // the partial diagonal sums first: their workgroup barrier would otherwise also wait for the dK / dV stores below
+  // (stores count on vmcnt), i.e. for a full memory round trip on the critical path of the workgroup
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     if (want_drpe) {
       flush_carry();
@@ -933,6 +916,25 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         out[i2] = acc;
       }
     }
+  }
+  FAT5_STAMP(14);
+
+  if (krow < N) {
+    const float scale = a.scale;
+    uint16_t* dkrow = dkb + (int64_t)krow * a.dks[2];
+    uint16_t* dvrow = dvb + (int64_t)krow * a.dvs[2];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 wk, wv;
+        wk[0] = pack2<BF16>(dkacc[db][4 * g + 0] * scale, dkacc[db][4 * g + 1] * scale);
+        wk[1] = pack2<BF16>(dkacc[db][4 * g + 2] * scale, dkacc[db][4 * g + 3] * scale);
+        wv[0] = pack2<BF16>(dvacc[db][4 * g + 0], dvacc[db][4 * g + 1]);
+        wv[1] = pack2<BF16>(dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * hi) = wk;
+        *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
+      }
   }
   FAT5_STAMP(15);
 }
