@@ -96,9 +96,6 @@ FAT5_DEV uint16_t to16(float a) {
 FAT5_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FAT5_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-FAT5_DEV float xchg32(float v) {  // value held by the partner lane (lane ^ 32)
-  return __shfl_xor(v, 32, 64);
-}
 // max / sum over the lane pair (lane, lane ^ 32) with v_permlane32_swap: a VALU op (~2 issue slots) instead of a
 // ds_bpermute round trip through the LDS crossbar (~100+ cycles of exposed latency in front of the rescale branch)
 FAT5_DEV float pair_max(float v) {
@@ -153,22 +150,11 @@ FAT5_DEV int rm_off(int row, int chunk) {  // byte offset of 16-B chunk `chunk` 
   return row * (2 * D) + ((chunk ^ swz<D>(row)) << 4);
 }
 
-// Transposed image [D][ROWS + 4] 16-bit (row stride 2*ROWS + 8 bytes): element (d, r).
-// 8-byte reads of "32 different d, same 4 consecutive r" are conflict free (stride = 34 dwords
-// for ROWS = 64; odd multiple of 2 dwords in general).
-template <int ROWS>
-FAT5_DEV constexpr int tr_stride() { return 2 * ROWS + 8; }
-
 // global 16-byte load of 8 consecutive 16-bit elements; zero when !valid
 FAT5_DEV u32x4 gload16(const uint16_t* p, bool valid) {
   u32x4 z = {0, 0, 0, 0};
   return valid ? *reinterpret_cast<const u32x4*>(p) : z;
 }
-
-struct TensorView {  // one (b,h) slice: row pointer arithmetic in elements
-  const uint16_t* base;
-  int64_t row_stride;
-};
 
 // ------------------------------------------------------------------------------------------
 // XCD-aware work-item decode.  Workgroup `bid` lands on XCD bid % 8 (observed, speed only).
@@ -252,59 +238,6 @@ struct AttnArgs {
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
   float scale;
-};
-
-// ------------------------------------------------------------------------------------------
-// Tile staging: each work item = rows (2p, 2p+1) x one 16-byte chunk, loaded once from global
-// into registers and written to LDS as a row-major swizzled image and/or a transposed image.
-// ------------------------------------------------------------------------------------------
-template <int D, int ROWS, int NT>
-struct PairStage {
-  static constexpr int C = D / 8;
-  static constexpr int ITEMS = (ROWS / 2) * C;
-  static constexpr int PER = (ITEMS + NT - 1) / NT;
-  u32x4 r0[PER], r1[PER];
-
-  // rows [row0, row0 + ROWS) of a (rows, D) tensor; rows >= limit read as zero
-  FAT5_DEV void load(const uint16_t* base, int64_t row_stride, int row0, int limit, int tid) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int id = tid + NT * i;
-      const int c = id % C, p = id / C;
-      const int ra = row0 + 2 * p, rb = ra + 1;
-      const bool in = (ITEMS % NT == 0) || (id < ITEMS);
-      r0[i] = gload16(base + (int64_t)ra * row_stride + c * 8, in && ra < limit);
-      r1[i] = gload16(base + (int64_t)rb * row_stride + c * 8, in && rb < limit);
-    }
-  }
-  // row-major swizzled image [ROWS][D]
-  FAT5_DEV void store_rm(char* lds, int tid) const {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int id = tid + NT * i;
-      if ((ITEMS % NT != 0) && id >= ITEMS) continue;
-      const int c = id % C, p = id / C;
-      *reinterpret_cast<u32x4*>(lds + rm_off<D>(2 * p, c)) = r0[i];
-      *reinterpret_cast<u32x4*>(lds + rm_off<D>(2 * p + 1, c)) = r1[i];
-    }
-  }
-  // transposed image [D][ROWS + 4]: element (d, row)
-  FAT5_DEV void store_tr(char* lds, int tid) const {
-    constexpr int TRS = tr_stride<ROWS>();
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int id = tid + NT * i;
-      if ((ITEMS % NT != 0) && id >= ITEMS) continue;
-      const int c = id % C, p = id / C;
-      char* dst = lds + (8 * c) * TRS + 4 * p;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t a = r0[i][j >> 1], b = r1[i][j >> 1];
-        const uint32_t wv = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-        *reinterpret_cast<uint32_t*>(dst + j * TRS) = wv;
-      }
-    }
-  }
 };
 
 // Buffer resource over rows [0, nrows) of one (b,h) slice: bytes past the last row's D elements are out of range
@@ -509,43 +442,6 @@ FAT5_DEV u32x4 ld_tr(const char* img, const FragAddr<D>& fa, int blk, int t, int
   return r;
 }
 
-// fragment reads -----------------------------------------------------------------------------
-// row-major image: rows on lanes (lq), 16-bit k-slots 16*kk + 8*hi + j
-template <int D>
-FAT5_DEV u32x4 frag_rm(const char* lds, int row, int kk, int hi) {
-  return *reinterpret_cast<const u32x4*>(lds + rm_off<D>(row, 2 * kk + hi));
-}
-// transposed image: rows (d) on lanes, k-slots j <-> source row (j&3) + 8*(j>>2) + base
-template <int ROWS>
-FAT5_DEV u32x4 frag_tr(const char* lds, int d, int base) {
-  constexpr int TRS = tr_stride<ROWS>();
-  const char* p = lds + d * TRS + 2 * base;
-  const u32x2 a = *reinterpret_cast<const u32x2*>(p);
-  const u32x2 b = *reinterpret_cast<const u32x2*>(p + 16);
-  u32x4 r = {a[0], a[1], b[0], b[1]};
-  return r;
-}
-
-// Transposed fragment straight from a ROW-MAJOR image with ds_read_b64_tr_b16 (no transposed copy):
-// returns, for lane (d = 32*db + (lane&31), hi), the 8 k-slots j <-> rows  rbase + (j&3) + 8*(j>>2)
-// where rbase must be a multiple of 4 and already include the lane's 4*hi.
-// tr16_b64 semantics (probed on gfx950, tools/probe_layout.hip): inside each 16-lane group, lane 4e+c supplies
-// the address of row e, 8-byte piece c; lane i receives, for e = 0..3, the 16-bit element i of row e's 32 bytes.
-template <int D>
-FAT5_DEV u32x4 frag_tr_rm(const char* lds, int rbase, int db, int lane) {
-  const int i = lane & 15, e = i >> 2, c = i & 3, g = (lane >> 4) & 1;
-  const int chunk = 4 * db + 2 * g + (c >> 1);
-  const int r0 = rbase + e, r1 = r0 + 8;
-  const char* p0 = lds + r0 * (2 * D) + ((chunk ^ swz<D>(r0)) << 4) + 8 * (c & 1);
-  const char* p1 = lds + r1 * (2 * D) + ((chunk ^ swz<D>(r1)) << 4) + 8 * (c & 1);
-  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0);
-  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1);
-  const u32x2 a2 = __builtin_bit_cast(u32x2, a), b2 = __builtin_bit_cast(u32x2, b);
-  u32x4 r = {a2[0], a2[1], b2[0], b2[1]};
-  return r;
-}
-
 // pack 8 fp32 C-layout registers (r = 8t .. 8t+7) into one 16-bit operand fragment
 template <bool BF16>
 FAT5_DEV u32x4 pack8(const f32x16& x, int t) {
@@ -559,7 +455,5 @@ FAT5_DEV u32x4 pack8(const f32x16& x, int t) {
 
 template <int D, int ROWS>
 constexpr int rm_bytes() { return ROWS * 2 * D; }
-template <int D, int ROWS>
-constexpr int tr_bytes() { return D * tr_stride<ROWS>(); }
 
 }  // namespace fat5

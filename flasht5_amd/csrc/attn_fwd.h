@@ -88,18 +88,6 @@ FAT5_DEV float max16(const f32x16& s) {
   const float d = max3f(s[9], s[10], s[11]), e = max3f(s[12], s[13], s[14]);
   return max3f(max3f(a, b, c), max3f(d, e, s[15]), s[15]);
 }
-FAT5_DEV float max32(const f32x16& x, const f32x16& y) {
-  float t[11];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    t[2 * i] = max3f(x[3 * i], x[3 * i + 1], x[3 * i + 2]);
-    t[2 * i + 1] = max3f(y[3 * i], y[3 * i + 1], y[3 * i + 2]);
-  }
-  t[10] = max3f(x[15], y[15], t[0]);
-  const float u0 = max3f(t[1], t[2], t[3]), u1 = max3f(t[4], t[5], t[6]), u2 = max3f(t[7], t[8], t[9]);
-  return max3f(max3f(u0, u1, u2), t[10], t[10]);
-}
-
 #ifndef FAT5_PSUM_MFMA
 #define FAT5_PSUM_MFMA 0  // 1: row sums of P on the matrix pipe (A = ones).  0 (default): 8 v_pk_add_f32 per block -- the chip is power
                           // limited under this kernel (~1.95 GHz), two extra MFMAs per block cost more than the packed adds
