@@ -439,7 +439,16 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     stat_off = (int64_t)h * a.total_q + q0;
   }
   const int n0 = nblk * BNK;
-  if (n0 >= N) return;
+  if (n0 >= N) {
+    // (packed batches: key blocks past the end of a short sequence still own a partial row of the diagonal sums)
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      if (a.drpe_part) {
+        float* out = a.drpe_part + ((int64_t)bh * a.n_nblk + nblk) * (2 * a.R + 1);
+        for (int i2 = tid; i2 < 2 * a.R + 1; i2 += NT) out[i2] = 0.f;
+      }
+    }
+    return;
+  }
   const uint16_t* qb = a.q + qoff + (int64_t)h * a.qs[1];
   const uint16_t* kb_ = a.k + koff + (int64_t)h * a.ks[1];
   const uint16_t* vb = a.v + voff + (int64_t)h * a.vs[1];

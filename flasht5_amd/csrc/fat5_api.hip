@@ -63,7 +63,6 @@ int check_common(const fat5_attn_params* p) {
   if (p->bias_mode == FAT5_BIAS_RPE1D) {
     if (!p->rpe1d) return fail(FAT5_EINVAL, "rpe1d mode without table");
     if (p->rpe_radius < 1 || p->rpe_radius > 2048) return fail(FAT5_EINVAL, "rpe_radius %d out of range [1, 2048]", p->rpe_radius);
-    if (p->cu_seqlens_q) return fail(FAT5_EINVAL, "rpe1d + varlen unsupported");
   }
   return FAT5_OK;
 }
@@ -130,7 +129,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   if (!slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) || !slice_fits(p->M, p->q_stride[2], p->D))
     return fail(FAT5_EINVAL, "fwd: one (batch, head) slice must span less than 2 GiB");
   if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
-  if (p->cu_seqlens_q && p->bias_mode != FAT5_BIAS_NONE) return fail(FAT5_EINVAL, "varlen supports bias_mode none only");
+  if (p->cu_seqlens_q && p->bias_mode == FAT5_BIAS_DENSE) return fail(FAT5_EINVAL, "varlen: dense bias unsupported (none or rpe1d)");
 
   AttnArgs a;
   fill_common(p, a);
@@ -208,7 +207,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
-  if (p->cu_seqlens_q && p->bias_mode != FAT5_BIAS_NONE) return fail(FAT5_EINVAL, "varlen supports bias_mode none only");
+  if (p->cu_seqlens_q && p->bias_mode == FAT5_BIAS_DENSE) return fail(FAT5_EINVAL, "varlen: dense bias unsupported (none or rpe1d)");
   if (!p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv)
     return fail(FAT5_EINVAL, "bwd: null tensor pointer");
   if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||

@@ -276,8 +276,10 @@ def flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, causal=False, sm_scale=None
 # ------------------------------------------------------------------------------------------------
 # packed var-len forward (config 4: decoder cross-attention over cu_seqlens; forward only for now)
 # ------------------------------------------------------------------------------------------------
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None):
-    """q: (total_q, H, D); k, v: (total_k, H, D); cu_seqlens_*: int32 (nseq+1,) on device.
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None,
+                          rpe1d=None, radius=0):
+    """q: (total_q, H, D); k, v: (total_k, H, D); cu_seqlens_*: int32 (nseq+1,) on device; optional T5 bias generator
+    rpe1d (H, 2*radius+1) fp32 (positions count from each sequence's own start).
     Returns o (total_q, H, D) and lse (H, total_q)."""
     if q.dtype not in (torch.float16, torch.bfloat16):
         raise TypeError("q must be float16 or bfloat16")
@@ -299,6 +301,8 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max
     cq = cu_seqlens_q.to(torch.int32).contiguous()
     ck = cu_seqlens_k.to(torch.int32).contiguous()
     p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cq.data_ptr(), ck.data_ptr(), Tq, Tk
+    if rpe1d is not None:
+        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
     with _lib.on_device(q.device):
         _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
     return o, lse
@@ -321,8 +325,9 @@ def _varlen_ok(t):
 
 
 def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False,
-                          sm_scale=None):
-    """Backward of the packed (cu_seqlens) attention: returns dq (total_q, H, D), dk, dv (total_k, H, D)."""
+                          sm_scale=None, rpe1d=None, radius=0, need_drpe=False):
+    """Backward of the packed (cu_seqlens) attention: returns dq (total_q, H, D), dk, dv (total_k, H, D)
+    (and drpe1d (H, 2*radius+1) when `need_drpe`)."""
     q, k, v, o, do = (t if _varlen_ok(t) else t.contiguous() for t in (q, k, v, o, do))
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(q.shape[-1])
@@ -333,38 +338,54 @@ def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_s
     p.o, p.lse, p.dout, p.dq, p.dk, p.dv = (t.data_ptr() for t in (o, lse, do, dq, dk, dv))
     for name, t in (("o_stride", o), ("do_stride", do), ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
         setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
+    drpe = None
+    if rpe1d is not None:
+        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
+        if need_drpe:
+            drpe = torch.empty_like(rpe1d)
+            p.drpe1d = drpe.data_ptr()
     lib = _lib.load()
     nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     with _lib.on_device(q.device):
         _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd(varlen)")
-    return dq, dk, dv
+    return (dq, dk, dv, drpe) if rpe1d is not None else (dq, dk, dv)
 
 
 class FlashAttentionVarlen(torch.autograd.Function):
-    """Packed batches: q (total_q, H, D), k/v (total_k, H, D), int32 cu_seqlens on the device.
-    No bias (the reference has no cu_seqlens path at all: it pads, `data_collator_ul2.py:49-87`)."""
+    """Packed batches (SURVEY 8(f) n2 / config 4): q (total_q, H, D), k/v (total_k, H, D), int32 cu_seqlens on the device;
+    optionally the T5 bias generator `rpe1d (H, 2*radius+1)` (differentiable), positions local to each sequence.
+    (The reference has no cu_seqlens path at all: it pads, `data_collator_ul2.py:49-87`.)"""
 
     @staticmethod
-    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale):
-        o, lse = flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale)
-        ctx.save_for_backward(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k)
-        ctx.meta = (int(max_seqlen_q), int(max_seqlen_k), bool(causal), sm_scale)
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale, rpe1d, radius):
+        r1 = rpe1d.detach().float().contiguous() if rpe1d is not None else None
+        o, lse = flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale,
+                                       r1, radius)
+        ctx.save_for_backward(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, *([r1] if r1 is not None else []))
+        ctx.meta = (int(max_seqlen_q), int(max_seqlen_k), bool(causal), sm_scale, int(radius),
+                    rpe1d.dtype if rpe1d is not None else None)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, cq, ck = ctx.saved_tensors
-        mq, mk, causal, sm_scale = ctx.meta
+        q, k, v, o, lse, cq, ck, *rest = ctx.saved_tensors
+        mq, mk, causal, sm_scale, radius, rdtype = ctx.meta
+        if rest:
+            dq, dk, dv, d1 = flash_attn_varlen_bwd(do, q, k, v, o, lse, cq, ck, mq, mk, causal, sm_scale, rest[0], radius,
+                                                   ctx.needs_input_grad[9])
+            return dq, dk, dv, None, None, None, None, None, None, (d1.to(rdtype) if d1 is not None else None), None
         dq, dk, dv = flash_attn_varlen_bwd(do, q, k, v, o, lse, cq, ck, mq, mk, causal, sm_scale)
-        return dq, dk, dv, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
-def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None):
-    """Differentiable packed attention (same argument order as the flash_attn var-len entry point the reference's
-    `fa2` attention types would call)."""
-    return FlashAttentionVarlen.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale)
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None,
+                           rpe1d=None, radius=0):
+    """Differentiable packed attention (argument order of the flash_attn var-len entry point the reference's `fa2`
+    attention types would call), optionally with the in-kernel T5 bias of `flash_attention_v2_rpe1d`."""
+    return FlashAttentionVarlen.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale,
+                                      rpe1d, int(radius))
 
 
 # ------------------------------------------------------------------------------------------------

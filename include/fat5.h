@@ -78,7 +78,8 @@ typedef struct fat5_attn_params {
    * when cu_seqlens_q != NULL: B = number of sequences, q/o are (total_q, H, D) addressed as
    * base + (cu_seqlens_q[b] + m) * stride[2] + h * stride[1] (stride[0] ignored), k/v likewise
    * with cu_seqlens_k; M/N are the MAXIMUM lengths; lse is (H, total_q).  Forward and backward (dq like q, dk/dv like
-   * k/v, dout like o); bias_mode must be FAT5_BIAS_NONE. */
+   * k/v, dout like o); bias_mode FAT5_BIAS_NONE or FAT5_BIAS_RPE1D (relative positions count from each sequence's
+   * own start: bias[m][n] = rpe1d[h][clamp(n - m, -R, R) + R] with m, n local to the sequence). */
   const int32_t* cu_seqlens_q;
   const int32_t* cu_seqlens_k;
   int32_t total_q, total_k;

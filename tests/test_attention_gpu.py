@@ -587,3 +587,45 @@ def test_mini_encoder_training_step_all_three_operators():
     for i, (g, rg) in enumerate(zip(grads, rgrads)):
         assert torch.isfinite(g.float()).all(), i
         assert maxdiff(g, rg) <= 6e-2 * max(rg.abs().max().item(), 1e-3) + 1e-5, (i, maxdiff(g, rg), rg.abs().max().item())
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_with_rpe_bias(causal):
+    """Packed self-attention with the in-kernel T5 bias (positions local to each sequence) -- what a packed UL2 batch
+    needs instead of padding: o, dq, dk, dv and the generator gradient vs per-sequence eager fp32 attention whose dense
+    bias is gathered from the same generator."""
+    from flasht5_amd import flash_attn_varlen_func
+    H, D, R = 3, 64, 32
+    cu = [0, 200, 200, 331, 400, 912]          # an empty sequence, a long one (far tiles), short ones
+    T = cu[-1]
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(T, H, D, generator=g).bfloat16().cuda()
+    k = torch.randn(T, H, D, generator=g).bfloat16().cuda()
+    v = torch.randn(T, H, D, generator=g).bfloat16().cuda()
+    do = torch.randn(T, H, D, generator=g).bfloat16().cuda()
+    r1 = (torch.randn(H, 2 * R + 1, generator=g) * 0.5).cuda()
+    leaves = [t.clone().requires_grad_() for t in (q, k, v, r1)]
+    cu_t = torch.tensor(cu, dtype=torch.int32).cuda()
+    o = flash_attn_varlen_func(leaves[0], leaves[1], leaves[2], cu_t, cu_t, 512, 512, causal, 0.125, leaves[3], R)
+    dq, dk, dv, d1 = torch.autograd.grad(o, leaves, do)
+
+    ref_leaves = [t.float().clone().requires_grad_() for t in (q, k, v, r1)]
+    outs = []
+    for i in range(len(cu) - 1):
+        s, e = cu[i], cu[i + 1]
+        if e == s:
+            continue
+        n = e - s
+        idx = torch.clamp(torch.arange(n)[None, :] - torch.arange(n)[:, None], -R, R).cuda() + R
+        bias = ref_leaves[3][:, idx].unsqueeze(0)                       # (1, H, n, n)
+        qi, ki, vi = (ref_leaves[j][s:e].permute(1, 0, 2).unsqueeze(0) for j in range(3))
+        outs.append(oracle.attn_ref(qi, ki, vi, bias, 0.125, causal=causal, upcast=True)[0].permute(1, 0, 2))
+    ref_o = torch.zeros(T, H, D, device="cuda")
+    pos = [(cu[i], cu[i + 1]) for i in range(len(cu) - 1) if cu[i + 1] > cu[i]]
+    for (s, e), oi in zip(pos, outs):
+        ref_o[s:e] = oi
+    rdq, rdk, rdv, rd1 = torch.autograd.grad(sum((oi * do[s:e].float()).sum() for (s, e), oi in zip(pos, outs)), ref_leaves)
+    assert maxdiff(o, ref_o) <= bound(ref_o, torch.bfloat16)
+    for got, ref, key in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
+        assert maxdiff(got, ref) <= gbound(ref, torch.bfloat16), key
+    assert maxdiff(d1, rd1) <= 1e-2 * max(1.0, rd1.abs().max().item()) + 3e-2
