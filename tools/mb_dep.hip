@@ -139,6 +139,68 @@ double runp(int occ, int iters) {
   return ms * 1e6 / iters / occ;
 }
 
+// Ping-pong variant: 8 waves per workgroup = two groups of 4 (one wave of each group per SIMD), forced into opposite
+// phases with s_barrier: while group A runs its MFMA phase (P.V of the previous block + the score chain of the next),
+// group B runs its softmax VALU phase, then they swap.  Does the SIMD overlap wave A's MFMAs with wave B's VALU work?
+__global__ __launch_bounds__(512) void kpp(float* out, int iters) {
+  const int l = threadIdx.x & 63, grp = (threadIdx.x >> 6) >> 2;
+  u32x4 q[4], kf[4], vf[4];
+  for (int i = 0; i < 4; ++i) { q[i] = u32x4{0x3c003c00u, 0x3c003c00u + l, 0x3c003c00u, 0x3c003c00u}; kf[i] = u32x4{0x3c003c00u + i, 0x3c003c00u, 0x3c003c00u + l, 0x3c003c00u}; vf[i] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u + l + i, 0x3c003c00u}; }
+  f32x16 o0 = {0}, o1 = {0};
+  f32x2 lsum = {0.f, 0.f};
+  const f32x16 z = {0};
+  float m = 0.25f;
+  f32x16 s = z;
+  u32x4 pb[2] = {u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}, u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}};
+  auto mfma_phase = [&]() {
+    o0 = mf(vf[0], pb[0], o0);
+    o1 = mf(vf[1], pb[0], o1);
+    o0 = mf(vf[2], pb[1], o0);
+    o1 = mf(vf[3], pb[1], o1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) s = mf(kf[kk], q[kk], kk == 0 ? z : s);
+  };
+  auto valu_phase = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 x = {s[r], s[r + 1]};
+      x = x * 0.18f + (-m);
+      x[0] = __builtin_amdgcn_exp2f(x[0]);
+      x[1] = __builtin_amdgcn_exp2f(x[1]);
+      lsum += x;
+      s[r] = x[0]; s[r + 1] = x[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb[t][j] = pk(s[8 * t + 2 * j], s[8 * t + 2 * j + 1]);
+    q[0][0] ^= (pb[0][0] & 1);
+  };
+  if (grp == 1) { mfma_phase(); }   // group B starts one phase ahead
+  __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < iters; ++it) {
+    if (grp == 0) mfma_phase(); else valu_phase();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) valu_phase(); else mfma_phase();
+    __builtin_amdgcn_s_barrier();
+  }
+  float r = o0[0] + o1[1] + lsum[0] + lsum[1] + s[3];
+  if (r == 123.456f) out[threadIdx.x] = r;
+}
+double runpp(int iters) {
+  float* d; (void)hipMalloc(&d, 4096);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const size_t lds = 100 * 1024;  // one 8-wave workgroup per CU
+  (void)hipFuncSetAttribute((const void*)kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kpp, dim3(256), dim3(512), lds, 0, d, iters);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL(kpp, dim3(256), dim3(512), lds, 0, d, iters);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e6 / iters / 2;  // two blocks (one per group) per iteration per SIMD
+}
+
 template <int WHAT, bool LDSOPS>
 double run(int occ, int iters) {
   float* d; (void)hipMalloc(&d, 4096);
@@ -162,5 +224,6 @@ int main() {
            run<0, false>(occ, iters), run<1, false>(occ, iters), run<2, false>(occ, iters), run<0, true>(occ, iters), run<1, true>(occ, iters));
     printf("             | software-pipelined (regs): compiler order %.1f  forced 1:7 interleave %.1f\n", runp<0>(occ, iters), runp<1>(occ, iters));
   }
+  printf("ping-pong (2 waves/SIMD in forced opposite phases, s_barrier): %.1f ns per block\n", runpp(iters));
   return 0;
 }
