@@ -1,0 +1,38 @@
+// Instantiations of the 64-rows-per-wave pipelined forward (attn_fwd64.h) for one head_dim (-DFAT5_INST_D=64).
+#include "attn_fwd64.h"
+#include <cstdlib>
+#include "attn_launch.h"
+
+#ifndef FAT5_INST_D
+#error "FAT5_INST_D must be defined"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+namespace fat5 {
+
+template <int D, bool BF16, int BIAS>
+static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = Fwd64Cfg<D>::smem(a.R, BIAS);
+  auto kern = attn_fwd64_kernel<D, BF16, BIAS>;
+  if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  // One workgroup per item by default.  FAT5_F64_RESIDENT=n (developer knob) launches n persistent workgroups (a multiple of 8,
+  // so an item keeps its XCD) that walk the items with stride n: measured no faster at (4,12,8192,64) -- 1536 equal items over
+  // 512 slots balance by themselves.
+  int resident = 0;
+  if (const char* e = getenv("FAT5_F64_RESIDENT")) resident = atoi(e) / 8 * 8;
+  const int launch = resident <= 0 || grid < resident ? grid : resident;
+  hipLaunchKernelGGL(kern, dim3(launch), dim3(256), smem, s, a, grid);
+  return hipGetLastError();
+}
+
+hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+  if (bias == FAT5_BIAS_RPE1D)
+    return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
+  return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
+}
+
+}  // namespace fat5

@@ -17,4 +17,6 @@ FAT5_DECL_LAUNCH(32)
 FAT5_DECL_LAUNCH(64)
 FAT5_DECL_LAUNCH(128)
 #undef FAT5_DECL_LAUNCH
+// 64 query rows per wave, software-pipelined (attn_fwd64.h): bias none / rpe1d, no packed batches
+hipError_t launch_fwd64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 }  // namespace fat5

@@ -144,9 +144,19 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     nw = -4;
     a.n_mblk = (p->M + 63) / 64;
   }
+  launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
+  // long sequences: 64 query rows per wave, software-pipelined tile loop (attn_fwd64.h) once its 256-row workgroups fill
+  // the chip (FAT5_FWD64=0 disables, =1 forces wherever the body applies)
+  const int f64_env = env_int("FAT5_FWD64", -1);
+  const long ctas256 = bh * ((p->M + 255) / 256);
+  if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 && env_int("FAT5_FWD_NW", 0) == 0 &&
+      (f64_env == 1 || (p->dtype == FAT5_BF16 && ctas256 >= 512))) {
+    fn = launch_fwd64_d64;
+    nw = 4;
+    a.n_mblk = (p->M + 255) / 256;
+  }
   const long grid = bh * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
-  launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
   if (e != hipSuccess) return hip_fail(e, "attn_fwd launch");
   return FAT5_OK;

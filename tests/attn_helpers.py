@@ -25,12 +25,13 @@ def make_inputs(B, H, M, N, D, dtype, bias_kind, seed=0, device="cuda", std=1.0,
 
 
 def maxdiff(a, b):
+    """max |a - b|; positions where both hold the same value -- including the same +-inf (lse = -inf on fully masked rows) --
+    count as 0; a NaN on either side, or an infinity facing a finite value, gives +inf so that every bound fails."""
     a, b = a.float(), b.float()
-    d = (a - b)
-    d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
-    same_inf = (a == b)
-    d = torch.where(same_inf, torch.zeros_like(d), d)
-    return d.abs().max().item()
+    d = (a - b).abs()
+    d = torch.where(a == b, torch.zeros_like(d), d)
+    d = torch.where(torch.isnan(d), torch.full_like(d, float("inf")), d)
+    return d.max().item()
 
 
 def eager_lowprec_errors(q, k, v, b, do, sm_scale, causal, ref):

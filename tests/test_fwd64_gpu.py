@@ -1,0 +1,108 @@
+"""GPU parity tests of the long-sequence forward body (csrc/attn_fwd64.h: 64 query rows per wave, software-pipelined tile
+loop, 4-slot LDS rings) -- forced with FAT5_FWD64=1 at sizes the oracle finishes in seconds; at (4,12,8192,64) the default
+dispatch picks it by itself (test_attention_gpu.py::test_cfg3_properties_s8192)."""
+import pytest
+import torch
+
+import oracle
+from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
+from test_attention_gpu import bound, gbound, _rpe_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_fwd64(monkeypatch):
+    monkeypatch.setenv("FAT5_FWD64", "1")
+
+
+def _run(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
+    from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    if table is None:
+        o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], None, causal, scale)
+    else:
+        o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], table.cuda(), bidir, 32, md, causal, scale)
+    dq, dk, dv = torch.autograd.grad(o, leaves, do)
+    return {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv}
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,mode,dtype", [
+    (1, 2, 256, 256, False, "none", torch.bfloat16),      # one workgroup, exact tiles only
+    (2, 3, 1024, 1024, False, "none", torch.bfloat16),    # baseline tiles + pipelined range + remainder tiles
+    (2, 3, 1024, 1024, False, "rpe", torch.bfloat16),     # far-negative range, band, far-positive range
+    (1, 2, 2048, 2048, True, "rpe", torch.bfloat16),      # causal: diagonal tiles generic, ranges shortened per workgroup
+    (1, 2, 2048, 2048, True, "none", torch.bfloat16),
+    (1, 2, 1000, 1100, False, "rpe", torch.bfloat16),     # ragged M and N (row clamp, N tail)
+    (1, 2, 300, 2500, True, "rpe", torch.bfloat16),       # M << N, bottom-right causal
+    (1, 2, 2500, 300, True, "none", torch.bfloat16),      # M >> N: fully masked rows (o = 0, lse = -inf)
+    (1, 2, 1536, 1536, False, "rpe", torch.float16),      # fp16: exact body only (no optimistic loop)
+    (1, 1, 3072, 3072, False, "none", torch.bfloat16),    # several trips of the 4-tile steady-state loop
+])
+def test_fwd64_matches_oracle(B, H, M, N, causal, mode, dtype):
+    scale = 0.125
+    if mode == "rpe":
+        q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, True, 128, seed=M + 5 * N)
+    else:
+        q, k, v, _, do = make_inputs(B, H, M, N, 64, dtype, None, seed=M + 5 * N, strided=True)
+        table, bias = None, None
+    ref = oracle_all(q, k, v, bias, do, scale, causal)
+    got = _run(q, k, v, do, causal, scale, table)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], dtype)
+    # the backward consumes the lse this body wrote
+    for key in ("dq", "dk", "dv"):
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= gbound(ref[key], dtype), key
+
+
+@pytest.mark.parametrize("boost,rows,at", [(0.0, "all", 512), (40.0, "all", 512), (40.0, "all", 1111), (400.0, "all", 512),
+                                           (1000.0, "even", 768), (90.0, "all", 320)])
+def test_fwd64_optimistic_softmax_edge_cases(boost, rows, at):
+    """Scores rising by `boost` nats at key `at`, inside the pipelined optimistic range: nothing (0), the power-of-two
+    renormalisation with a pending product in flight (40 nats; `at` in the middle of a tile too), overflow -> exact second
+    pass (400 / 1000 nats; "even": only every other row overflows), growth inside the first pipelined tile (320)."""
+    B, H, S, D = 1, 2, 2048, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, S, D, generator=g).bfloat16()
+    k = torch.randn(B, H, S, D, generator=g).bfloat16()
+    v = torch.randn(B, H, S, D, generator=g).bfloat16()
+    q[..., 0] = 4.0
+    if rows == "even":
+        q[..., 1::2, 0] = 0.0
+    k[..., at:, 0] = boost / 4.0
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B, H, S, D, generator=g).bfloat16().cuda()
+    got = _run(q, k, v, do, False, 1.0)
+    ref = oracle_all(q, k, v, None, do, 1.0, False)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], torch.bfloat16)
+    lp = eager_lowprec_errors(q, k, v, None, do, 1.0, False, ref)
+    for key in ("dq", "dk", "dv"):
+        e = maxdiff(got[key], ref[key])
+        assert torch.isfinite(got[key].float()).all(), key
+        assert e <= max(gbound(ref[key], torch.bfloat16), 3 * lp[key]), (key, e, lp[key])
+
+
+def test_fwd64_agrees_with_32row_body(monkeypatch):
+    """Both forward bodies on the same inputs: o equal to one output rounding, lse to fp32 summation order."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    q, k, v, _, do = make_inputs(2, 4, 2048, 2048, 64, torch.bfloat16, None, seed=3, strided=True)
+    table = (torch.randn(32, 4, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    plan = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=False, rpe1d=pe.rpe1d_from_table(table, True, 32, 128), radius=128)
+    outs = []
+    for f in ("0", "1"):
+        monkeypatch.setenv("FAT5_FWD64", f)
+        plan.forward()
+        torch.cuda.synchronize()
+        outs.append((plan.o.float().clone(), plan.lse.clone()))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2.0 ** -7 * max(1.0, outs[0][0].abs().max().item())
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-5
+
+
+def test_fwd64_deterministic():
+    q, k, v, _, do = make_inputs(1, 4, 2048, 2048, 64, torch.bfloat16, None, seed=9, strided=True)
+    a = _run(q, k, v, do, False, 0.125)
+    b = _run(q, k, v, do, False, 0.125)
+    assert torch.equal(a["o"], b["o"])
