@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfat5" + ("_" + _VAR if _VAR else "") +
 
 FAT5_F32, FAT5_F16, FAT5_BF16 = 0, 1, 2
 BIAS_NONE, BIAS_DENSE, BIAS_RPE1D = 0, 1, 2
-MAX_RPE_RADIUS = 2048
+MAX_RPE_RADIUS = 1024  # forward alone takes 2048; the backward's per-wave diagonal accumulators must fit LDS (include/fat5.h)
 
 _DT = {torch.float32: FAT5_F32, torch.float16: FAT5_F16, torch.bfloat16: FAT5_BF16}
 

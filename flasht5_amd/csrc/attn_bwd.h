@@ -123,7 +123,9 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   if (a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;  // (not needed by the fused launch)
   const float Lq = a.lse[stat_off + qrow_c];
   // p = exp2(x - L2); rows with L = -inf (fully masked) contribute nothing
-  const float nL2 = (Lq == -INFINITY) ? -INFINITY : -Lq * kLog2e;
+  // rows without a visible key (lse = -inf) and rows whose every key is masked by a finfo.min bias (lse ~ -2e38: the
+  // reference's `use_masking`; p = exp(s - L) has no digits left there, in the reference kernels neither) contribute nothing
+  const float nL2 = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;
 
   const float* sTa = sT;  // this lane's aligned copy of the table
   if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
@@ -229,7 +231,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
           if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kb, bv);
           else load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, fmaf(bv[r], kLog2e, nL2));
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bias_log2(bv[r]) + nL2);
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           const int R = a.R;
           const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;
@@ -579,7 +581,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       st_d = 0.f;
       if (m < M) {
         const float L = a.lse[stat_off + m];
-        st_l = (L == -INFINITY) ? ninf_c : -L * inv_scale;
+        st_l = (L < kDeadRowLse) ? ninf_c : -L * inv_scale;  // (see kDeadRowLse; -L / scale would overflow for a masked row)
         if constexpr (!SELFD) st_d = -a.delta[stat_off + m];
       }
     }
@@ -704,13 +706,13 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
             const uint16_t* tb = reinterpret_cast<const uint16_t*>(sB + BUF * Cfg::BIASB) + (32 * qbk + 4 * hi) * BNK + 32 * w + lq;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              s[r] = fmaf(s[r], c2, cvt16<BF16>(tb[((r & 3) + 8 * (r >> 2)) * BNK]) * kLog2e);
+              s[r] = fmaf(s[r], c2, bias_log2(cvt16<BF16>(tb[((r & 3) + 8 * (r >> 2)) * BNK])));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int m = mb + crow(r, hi);
               const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
-              s[r] = fmaf(s[r], c2, bvl * kLog2e);
+              s[r] = fmaf(s[r], c2, bias_log2(bvl));
             }
           }
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {

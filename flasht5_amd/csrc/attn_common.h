@@ -93,6 +93,13 @@ FAT5_DEV uint16_t to16(float a) {
   return (uint16_t)(pack2<BF16>(a, 0.f) & 0xffffu);
 }
 
+// dense bias in log2 units.  A bias of finfo(bf16).min (what `use_masking` writes, reference modeling_flash_t5.py:266-270) times
+// log2e overflows fp32; the reference scales (s - m) instead and stays finite, so a fully masked row is a uniform softmax
+// there -- keep the product finite to give the same.
+FAT5_DEV float bias_log2(float b) { return fmaxf(b * kLog2e, -3.0e38f); }
+// backward: a query row with lse below this has every key masked (by the causal rule: -inf; by a finfo.min bias: ~ -2e38);
+// its probabilities are treated as zero (dq = 0 for the row, no contribution to dk / dv / dbias)
+constexpr float kDeadRowLse = -1.0e30f;
 FAT5_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FAT5_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 

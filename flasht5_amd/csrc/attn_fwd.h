@@ -336,7 +336,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
           if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kbr, bv);
           else load_bias_block<BF16>(brow, nb, hi, N, a.bias_vec4 && (nb + 32 <= N), bv);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bv[r] * kLog2e);
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bias_log2(bv[r]));
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           const int R = a.R;
           const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;  // wave-uniform

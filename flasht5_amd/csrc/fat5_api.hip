@@ -229,8 +229,20 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       return fail(FAT5_EINVAL, "bwd: dbias batch/heads (%d,%d) must be 1 or (B,H)", p->dbias_batch, p->dbias_heads);
     if (!aligned16(p->dbias)) return fail(FAT5_EINVAL, "bwd: dbias must be 16-byte aligned");
   }
+  // the kernels address one (b,h) slice of every tensor through a 32-bit buffer descriptor (like the forward)
+  if (!slice_fits(p->M, p->q_stride[2], p->D) || !slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) ||
+      !slice_fits(p->M, p->o_stride[2], p->D) || !slice_fits(p->M, p->do_stride[2], p->D) || !slice_fits(p->M, p->dq_stride[2], p->D) ||
+      !slice_fits(p->N, p->dk_stride[2], p->D) || !slice_fits(p->N, p->dv_stride[2], p->D))
+    return fail(FAT5_EINVAL, "bwd: one (batch, head) slice must span less than 2 GiB");
   BwdLayout L;
   bwd_layout(p, L);
+  if (p->bias_mode == FAT5_BIAS_RPE1D) {
+    // the dK/dV body keeps the table and one private diagonal accumulator per wave in LDS
+    const size_t lds = p->D == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
+                                  : (p->D == 64 ? smem_bwd_kv_d64(L.nw_kv, p->rpe_radius, p->bias_mode) : smem_bwd_kv_d128(L.nw_kv, p->rpe_radius, p->bias_mode));
+    if (lds > 160 * 1024)
+      return fail(FAT5_EINVAL, "bwd: rpe_radius %d needs %zu bytes of LDS (160 KiB per workgroup; radius <= 1024 fits every head_dim)", p->rpe_radius, lds);
+  }
   if (L.total > 0 && (!p->workspace || p->workspace_bytes < L.total))
     return fail(FAT5_EWORKSPACE, "bwd: workspace of %zu bytes required, got %zu", L.total, p->workspace_bytes);
   if ((reinterpret_cast<uintptr_t>(p->workspace) & 255) != 0) return fail(FAT5_EINVAL, "bwd: workspace must be 256-byte aligned");
@@ -311,6 +323,10 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   if (a.drpe_part && (stages & FAT5_BWD_REDUCE)) {
     const int n1 = 2 * p->rpe_radius + 1;
     const size_t smem = (size_t)n1 * 24;
+    if (smem > 48 * 1024) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(drpe_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (ea != hipSuccess) return hip_fail(ea, "drpe_reduce attribute");
+    }
     hipLaunchKernelGGL(drpe_reduce_kernel, dim3(p->H), dim3(1024), smem, stream, a.drpe_part, p->drpe1d, p->rpe_bucket,
                        p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets);
     hipError_t e = hipGetLastError();

@@ -58,6 +58,43 @@ def _check_inputs(q, k, v):
         raise TypeError("q, k, v must share dtype float16 or bfloat16")
     if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k, v must be (B, H, S, D)")
+    if k.shape != v.shape or k.shape[:2] != q.shape[:2] or k.shape[3] != q.shape[3] or k.device != q.device or v.device != q.device:
+        raise ValueError(f"q {tuple(q.shape)}, k {tuple(k.shape)}, v {tuple(v.shape)}: batch, heads, head_dim and device must agree")
+
+
+def _check_bias(bias, q, k):
+    """dense bias (B|1, H|1, M, N) in q's dtype on q's device (the kernels trust these: reference :45-52 broadcasts the same way)"""
+    B, H, M, _ = q.shape
+    N = k.shape[2]
+    if bias.dim() != 4 or bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H) or tuple(bias.shape[2:]) != (M, N):
+        raise ValueError(f"bias must be (1|{B}, 1|{H}, {M}, {N}), got {tuple(bias.shape)}")
+    if bias.dtype != q.dtype:
+        raise TypeError("bias must have the dtype of q")
+    if bias.device != q.device:
+        raise ValueError("bias must live on q's device")
+
+
+def _check_rpe1d(rpe1d, H, radius, device):
+    if rpe1d.dtype != torch.float32 or not rpe1d.is_contiguous() or rpe1d.device != device:
+        raise TypeError("rpe1d must be a contiguous float32 tensor on q's device")
+    if tuple(rpe1d.shape) != (H, 2 * int(radius) + 1) or radius < 1:
+        raise ValueError(f"rpe1d must be (n_heads, 2 * radius + 1) = ({H}, {2 * int(radius) + 1}), got {tuple(rpe1d.shape)}")
+
+
+# Backward scratch: one growing buffer per (device, stream).  Launches on one stream are ordered, so consecutive backward
+# calls can share it; a call on another stream gets its own.  (A torch.empty per call cost ~4 us of the ~14 us host time of
+# an eager call and made the caching allocator the busiest part of a 12 us kernel's launch.)
+_WS_CACHE = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device()))
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = ws
+    return ws
 
 
 def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
@@ -71,12 +108,12 @@ def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
     p = _base_params(q, k, v, causal, sm_scale)
     p.o, p.lse, p.o_stride = o.data_ptr(), L.data_ptr(), _lib.strides3(o)
     if bias is not None:
-        if bias.dtype != q.dtype:
-            raise TypeError("bias must have the dtype of q")
+        _check_bias(bias, q, k)
         if bias.stride(-1) != 1:
             bias = bias.contiguous()
         p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
     elif rpe1d is not None:
+        _check_rpe1d(rpe1d, H, radius, q.device)
         p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
     with _lib.on_device(q.device):
         _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd")
@@ -100,6 +137,7 @@ def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbi
     p.do_stride, p.dq_stride, p.dk_stride, p.dv_stride = (_lib.strides3(t) for t in (do, dq, dk, dv))
     dbias = None
     if bias is not None:
+        _check_bias(bias, q, k)
         if bias.stride(-1) != 1:
             bias = bias.contiguous()
         p.bias_mode, p.bias, p.bias_stride = _lib.BIAS_DENSE, bias.data_ptr(), _bias_strides(bias, B, H)
@@ -107,6 +145,7 @@ def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbi
             dbias = torch.empty(bias.shape, dtype=bias.dtype, device=bias.device)  # shape/dtype of bias (:149,:224)
             p.dbias, p.dbias_batch, p.dbias_heads = dbias.data_ptr(), bias.shape[0], bias.shape[1]
     elif rpe1d is not None:
+        _check_rpe1d(rpe1d, H, radius, q.device)
         p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), radius
         if need_dbias:
             if rpe_bucket is not None:  # table gradient straight from the reduction launch
@@ -116,10 +155,9 @@ def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbi
                 dbias = torch.empty_like(rpe1d)
                 p.drpe1d = dbias.data_ptr()
     lib = _lib.load()
-    nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
-    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
-    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     with _lib.on_device(q.device):
+        ws = _workspace(lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p)), q.device)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd")
     return dq, dk, dv, dbias
 
@@ -156,6 +194,18 @@ def _flash_attn_v2_bwd_fake(o, do, q, k, v, bias, L, causal, sm_scale):
     return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), ds
 
 
+def _tracing():
+    """a compiler / FakeTensor trace is recording: go through the registered custom ops (they carry the fake impls); plain
+    eager calls skip the dispatcher round trip (~10 us of host time per op, more than the S = 512 kernels take)"""
+    return torch.compiler.is_compiling()
+
+
+def _pad16(ts):
+    """head_dim 16 -> 32 by zero padding: scores and the first 16 output columns are unchanged (the kernels' smallest MFMA
+    block spans 32 head-dim rows of the P.V product)"""
+    return tuple(torch.nn.functional.pad(t, (0, 16)) for t in ts)
+
+
 class FlashAttentionAdditiveBias(torch.autograd.Function):
     """Same contract as the reference class (flash_attention_v2_bias.py:228-271)."""
 
@@ -167,9 +217,12 @@ class FlashAttentionAdditiveBias(torch.autograd.Function):
         if sm_scale is None:
             sm_scale = 1.0 / math.sqrt(Dq)
         pad16 = Dk == 16
-        if pad16:  # the kernels' smallest head_dim is 32: zero-pad (scores and outputs unchanged)
-            q, k, v = (torch.nn.functional.pad(t, (0, 16)) for t in (q, k, v))
-        o, L = torch.ops.fat5.flash_attn_v2_fwd(q, k, v, bias, bool(causal), float(sm_scale))
+        if pad16:
+            q, k, v = _pad16((q, k, v))
+        if _tracing():
+            o, L = torch.ops.fat5.flash_attn_v2_fwd(q, k, v, bias, bool(causal), float(sm_scale))
+        else:
+            o, L = _attn_fwd(q, k, v, bias, None, 0, bool(causal), float(sm_scale))
         ctx.save_for_backward(q, k, v, bias, o, L)
         ctx.sm_scale = sm_scale
         ctx.causal = causal
@@ -181,7 +234,10 @@ class FlashAttentionAdditiveBias(torch.autograd.Function):
         q, k, v, bias, o, L = ctx.saved_tensors
         if ctx.pad16:
             do = torch.nn.functional.pad(do, (0, 16))
-        dq, dk, dv, ds = torch.ops.fat5.flash_attn_v2_bwd(o, do, q, k, v, bias, L, bool(ctx.causal), float(ctx.sm_scale))
+        if _tracing():
+            dq, dk, dv, ds = torch.ops.fat5.flash_attn_v2_bwd(o, do, q, k, v, bias, L, bool(ctx.causal), float(ctx.sm_scale))
+        else:
+            dq, dk, dv, ds = _attn_bwd(o, do, q, k, v, bias, None, 0, L, bool(ctx.causal), float(ctx.sm_scale), bias is not None)
         if ctx.pad16:
             dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         return dq, dk, dv, (ds if bias is not None else None), None, None, None, None
@@ -198,11 +254,61 @@ def flash_attention_v2_bias(q, k, v, bias, causal=False, sm_scale=None):
 # ------------------------------------------------------------------------------------------------
 # linear-memory T5 RPE mode
 # ------------------------------------------------------------------------------------------------
+@torch.library.custom_op("fat5::flash_attn_rpe1d_fwd", mutates_args=(), device_types="cuda")
+def flash_attn_rpe1d_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rpe1d: torch.Tensor, radius: int, causal: bool,
+                         sm_scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _attn_fwd(q, k, v, None, rpe1d, int(radius), causal, sm_scale)
+
+
+@torch.library.register_fake("fat5::flash_attn_rpe1d_fwd")
+def _flash_attn_rpe1d_fwd_fake(q, k, v, rpe1d, radius, causal, sm_scale):
+    B, H, M, D = q.shape
+    return torch.empty_like(q), torch.empty((B, H, M), dtype=torch.float32, device=q.device)
+
+
+@torch.library.custom_op("fat5::flash_attn_rpe1d_bwd", mutates_args=(), device_types="cuda")
+def flash_attn_rpe1d_bwd(o: torch.Tensor, do: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rpe1d: torch.Tensor,
+                         L: torch.Tensor, radius: int, causal: bool, sm_scale: float, need_drpe: bool,
+                         rpe_bucket: Optional[torch.Tensor], num_buckets: int
+                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """dq, dk, dv and the bias gradient: (H, 2R+1) diagonal sums, or -- with `rpe_bucket` -- the (num_buckets, H) table
+    gradient scattered by the same reduction launch; empty when `need_drpe` is False"""
+    dq, dk, dv, d1 = _attn_bwd(o, do, q, k, v, None, rpe1d, int(radius), L, causal, sm_scale, need_drpe, rpe_bucket, int(num_buckets))
+    if d1 is None:
+        d1 = torch.empty(0, dtype=torch.float32, device=q.device)
+    return dq, dk, dv, d1
+
+
+@torch.library.register_fake("fat5::flash_attn_rpe1d_bwd")
+def _flash_attn_rpe1d_bwd_fake(o, do, q, k, v, rpe1d, L, radius, causal, sm_scale, need_drpe, rpe_bucket, num_buckets):
+    if not need_drpe:
+        d1 = torch.empty(0, dtype=torch.float32, device=q.device)
+    elif rpe_bucket is not None:
+        d1 = torch.empty((num_buckets, q.shape[1]), dtype=torch.float32, device=q.device)
+    else:
+        d1 = torch.empty_like(rpe1d)
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), d1
+
+
+def _rpe_fwd(q, k, v, r1, radius, causal, sm_scale):
+    if _tracing():
+        return torch.ops.fat5.flash_attn_rpe1d_fwd(q, k, v, r1, int(radius), bool(causal), float(sm_scale))
+    return _attn_fwd(q, k, v, None, r1, int(radius), bool(causal), float(sm_scale))
+
+
+def _rpe_bwd(o, do, q, k, v, r1, L, radius, causal, sm_scale, need, bucket=None, num_buckets=0):
+    if _tracing():
+        dq, dk, dv, d1 = torch.ops.fat5.flash_attn_rpe1d_bwd(o, do, q, k, v, r1, L, int(radius), bool(causal), float(sm_scale),
+                                                             bool(need), bucket, int(num_buckets))
+        return dq, dk, dv, (d1 if need else None)
+    return _attn_bwd(o, do, q, k, v, None, r1, int(radius), L, bool(causal), float(sm_scale), bool(need), bucket, int(num_buckets))
+
+
 class FlashAttentionRPE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale):
         D = q.shape[-1]
-        assert D in {32, 64, 128}
+        assert D in {16, 32, 64, 128}
         if sm_scale is None:
             sm_scale = 1.0 / math.sqrt(D)
         R = _pe.rpe_radius(max_distance)
@@ -210,20 +316,27 @@ class FlashAttentionRPE(torch.autograd.Function):
             raise ValueError(f"max_distance {max_distance} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
         if rpe_table.shape != (num_buckets, q.shape[1]):
             raise ValueError("rpe_table must be (num_buckets, n_heads)")
+        pad16 = D == 16
+        if pad16:
+            q, k, v = _pad16((q, k, v))
         idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, q.device)
         rpe1d = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
-        o, L = _attn_fwd(q, k, v, None, rpe1d, R, causal, sm_scale)
+        o, L = _rpe_fwd(q, k, v, rpe1d, R, causal, sm_scale)
         ctx.save_for_backward(q, k, v, o, L, rpe1d, _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device))
-        ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype)
-        return o
+        ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype, pad16)
+        return o[..., :16] if pad16 else o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, L, rpe1d, idx = ctx.saved_tensors
-        R, causal, sm_scale, num_buckets, tdtype = ctx.meta
+        R, causal, sm_scale, num_buckets, tdtype, pad16 = ctx.meta
         need = ctx.needs_input_grad[3]
+        if pad16:
+            do = torch.nn.functional.pad(do, (0, 16))
         # the (H, 2R+1) diagonal sums are scattered into the (num_buckets, H) table by the reduction launch itself
-        dq, dk, dv, dtable = _attn_bwd(o, do, q, k, v, None, rpe1d, R, L, causal, sm_scale, need, idx, num_buckets)
+        dq, dk, dv, dtable = _rpe_bwd(o, do, q, k, v, rpe1d, L, R, causal, sm_scale, need, idx, num_buckets)
+        if pad16:
+            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         if dtable is not None:
             dtable = dtable.to(tdtype)
         return dq, dk, dv, dtable, None, None, None, None, None
@@ -247,24 +360,31 @@ class FlashAttentionRPE1D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, rpe1d, radius, causal, sm_scale):
         D = q.shape[-1]
-        assert D in {32, 64, 128}
+        assert D in {16, 32, 64, 128}
         if sm_scale is None:
             sm_scale = 1.0 / math.sqrt(D)
         if radius > _lib.MAX_RPE_RADIUS:
             raise ValueError(f"radius {radius} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
         if rpe1d.shape != (q.shape[1], 2 * radius + 1):
             raise ValueError("rpe1d must be (n_heads, 2 * radius + 1)")
+        pad16 = D == 16
+        if pad16:
+            q, k, v = _pad16((q, k, v))
         r1 = rpe1d.detach().float().contiguous()
-        o, L = _attn_fwd(q, k, v, None, r1, radius, causal, sm_scale)
+        o, L = _rpe_fwd(q, k, v, r1, radius, causal, sm_scale)
         ctx.save_for_backward(q, k, v, o, L, r1)
-        ctx.meta = (radius, causal, sm_scale, rpe1d.dtype)
-        return o
+        ctx.meta = (radius, causal, sm_scale, rpe1d.dtype, pad16)
+        return o[..., :16] if pad16 else o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, L, r1 = ctx.saved_tensors
-        radius, causal, sm_scale, rdtype = ctx.meta
-        dq, dk, dv, d1 = _attn_bwd(o, do, q, k, v, None, r1, radius, L, causal, sm_scale, ctx.needs_input_grad[3])
+        radius, causal, sm_scale, rdtype, pad16 = ctx.meta
+        if pad16:
+            do = torch.nn.functional.pad(do, (0, 16))
+        dq, dk, dv, d1 = _rpe_bwd(o, do, q, k, v, r1, L, radius, causal, sm_scale, ctx.needs_input_grad[3])
+        if pad16:
+            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         return dq, dk, dv, (d1.to(rdtype) if d1 is not None else None), None, None, None
 
 
@@ -274,38 +394,29 @@ def flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, causal=False, sm_scale=None
 
 
 # ------------------------------------------------------------------------------------------------
-# packed var-len forward (config 4: decoder cross-attention over cu_seqlens; forward only for now)
+# packed var-len attention (config 4: decoder cross-attention over cu_seqlens), forward + backward
 # ------------------------------------------------------------------------------------------------
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None,
-                          rpe1d=None, radius=0):
-    """q: (total_q, H, D); k, v: (total_k, H, D); cu_seqlens_*: int32 (nseq+1,) on device; optional T5 bias generator
-    rpe1d (H, 2*radius+1) fp32 (positions count from each sequence's own start).
-    Returns o (total_q, H, D) and lse (H, total_q)."""
-    if q.dtype not in (torch.float16, torch.bfloat16):
-        raise TypeError("q must be float16 or bfloat16")
-    q, k, v = (t if (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0)
-               else t.contiguous() for t in (q, k, v))
-    Tq, H, D = q.shape
-    Tk = k.shape[0]
-    if sm_scale is None:
-        sm_scale = 1.0 / math.sqrt(D)
-    nseq = cu_seqlens_q.numel() - 1
-    o = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
-    lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
-    p = _lib.AttnParams()
-    p.B, p.H, p.M, p.N, p.D = nseq, H, int(max_seqlen_q), int(max_seqlen_k), D
-    p.dtype, p.causal, p.sm_scale = _lib.dtype_code(q.dtype), int(bool(causal)), float(sm_scale)
-    p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
-    for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
-        setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
-    cq = cu_seqlens_q.to(torch.int32).contiguous()
-    ck = cu_seqlens_k.to(torch.int32).contiguous()
-    p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cq.data_ptr(), ck.data_ptr(), Tq, Tk
+def _varlen_ok(t):
+    return t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
+
+
+def _check_varlen(q, k, v, cu_q, cu_k, rpe1d, radius):
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flasht5_amd attention needs tensors on the HIP device (no CPU fallback)")
+    if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError("q, k, v must share dtype float16 or bfloat16")
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3 or k.shape != v.shape or k.shape[1:] != q.shape[1:]:
+        raise ValueError("packed attention takes q (total_q, H, D) and k, v (total_k, H, D)")
+    if q.shape[-1] not in (32, 64, 128):
+        raise ValueError("head_dim must be 32, 64 or 128")
+    for name, cu in (("cu_seqlens_q", cu_q), ("cu_seqlens_k", cu_k)):
+        # the kernels dereference these on the device
+        if cu.device != q.device or cu.dtype != torch.int32 or cu.dim() != 1 or not cu.is_contiguous():
+            raise TypeError(f"{name} must be a contiguous int32 vector on q's device")
+    if cu_q.numel() != cu_k.numel() or cu_q.numel() < 2:
+        raise ValueError("cu_seqlens_q and cu_seqlens_k must both have (number of sequences + 1) entries")
     if rpe1d is not None:
-        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
-    with _lib.on_device(q.device):
-        _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
-    return o, lse
+        _check_rpe1d(rpe1d, q.shape[1], radius, q.device)
 
 
 def _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale):
@@ -320,21 +431,31 @@ def _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale):
     return p
 
 
-def _varlen_ok(t):
-    return t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
+def _as_cu(cu, device):
+    return cu if (cu.dtype == torch.int32 and cu.device == device and cu.is_contiguous()) else cu.to(device=device, dtype=torch.int32).contiguous()
 
 
-def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False,
-                          sm_scale=None, rpe1d=None, radius=0, need_drpe=False):
-    """Backward of the packed (cu_seqlens) attention: returns dq (total_q, H, D), dk, dv (total_k, H, D)
-    (and drpe1d (H, 2*radius+1) when `need_drpe`)."""
+def _varlen_fwd_impl(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale, rpe1d, radius):
+    _check_varlen(q, k, v, cu_q, cu_k, rpe1d, radius)
+    q, k, v = (t if _varlen_ok(t) else t.contiguous() for t in (q, k, v))
+    Tq, H, D = q.shape
+    o = torch.empty((Tq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((H, Tq), dtype=torch.float32, device=q.device)
+    p = _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale)
+    p.o, p.lse = o.data_ptr(), lse.data_ptr()
+    p.o_stride = _lib.c_i64x3(0, o.stride(1), o.stride(0))
+    if rpe1d is not None:
+        p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, rpe1d.data_ptr(), int(radius)
+    with _lib.on_device(q.device):
+        _lib.check(_lib.load().fat5_attn_fwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_fwd(varlen)")
+    return o, lse
+
+
+def _varlen_bwd_impl(do, q, k, v, o, lse, cu_q, cu_k, max_q, max_k, causal, sm_scale, rpe1d, radius, need_drpe):
+    _check_varlen(q, k, v, cu_q, cu_k, rpe1d, radius)
     q, k, v, o, do = (t if _varlen_ok(t) else t.contiguous() for t in (q, k, v, o, do))
-    if sm_scale is None:
-        sm_scale = 1.0 / math.sqrt(q.shape[-1])
-    cq = cu_seqlens_q.to(torch.int32).contiguous()
-    ck = cu_seqlens_k.to(torch.int32).contiguous()
     dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (q, k, v))
-    p = _varlen_params(q, k, v, cq, ck, max_seqlen_q, max_seqlen_k, causal, sm_scale)
+    p = _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale)
     p.o, p.lse, p.dout, p.dq, p.dk, p.dv = (t.data_ptr() for t in (o, lse, do, dq, dk, dv))
     for name, t in (("o_stride", o), ("do_stride", do), ("dq_stride", dq), ("dk_stride", dk), ("dv_stride", dv)):
         setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
@@ -345,12 +466,74 @@ def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_s
             drpe = torch.empty_like(rpe1d)
             p.drpe1d = drpe.data_ptr()
     lib = _lib.load()
-    nbytes = lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
-    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q.device)
-    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
     with _lib.on_device(q.device):
+        ws = _workspace(lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p)), q.device)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.fat5_attn_bwd(ctypes.byref(p), _lib.stream_ptr(q.device)), "fat5_attn_bwd(varlen)")
-    return (dq, dk, dv, drpe) if rpe1d is not None else (dq, dk, dv)
+    return dq, dk, dv, drpe
+
+
+@torch.library.custom_op("fat5::flash_attn_varlen_fwd", mutates_args=(), device_types="cuda")
+def _varlen_fwd_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
+                   max_seqlen_q: int, max_seqlen_k: int, causal: bool, sm_scale: float, rpe1d: Optional[torch.Tensor],
+                   radius: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _varlen_fwd_impl(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale, rpe1d, radius)
+
+
+@torch.library.register_fake("fat5::flash_attn_varlen_fwd")
+def _varlen_fwd_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale, rpe1d, radius):
+    Tq, H, D = q.shape
+    return torch.empty((Tq, H, D), dtype=q.dtype, device=q.device), torch.empty((H, Tq), dtype=torch.float32, device=q.device)
+
+
+@torch.library.custom_op("fat5::flash_attn_varlen_bwd", mutates_args=(), device_types="cuda")
+def _varlen_bwd_op(do: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, lse: torch.Tensor,
+                   cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int, max_seqlen_k: int, causal: bool,
+                   sm_scale: float, rpe1d: Optional[torch.Tensor], radius: int, need_drpe: bool
+                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    dq, dk, dv, d1 = _varlen_bwd_impl(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal,
+                                      sm_scale, rpe1d, radius, need_drpe)
+    if d1 is None:
+        d1 = torch.empty(0, dtype=torch.float32, device=q.device)
+    return dq, dk, dv, d1
+
+
+@torch.library.register_fake("fat5::flash_attn_varlen_bwd")
+def _varlen_bwd_fake(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale, rpe1d, radius,
+                     need_drpe):
+    d1 = torch.empty_like(rpe1d) if (need_drpe and rpe1d is not None) else torch.empty(0, dtype=torch.float32, device=q.device)
+    return torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), d1
+
+
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, sm_scale=None,
+                          rpe1d=None, radius=0):
+    """q: (total_q, H, D); k, v: (total_k, H, D); cu_seqlens_*: int32 (nseq+1,) on the device (other dtypes / devices are
+    converted); optional T5 bias generator rpe1d (H, 2*radius+1) fp32 (positions count from each sequence's own start).
+    Returns o (total_q, H, D) and lse (H, total_q)."""
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(q.shape[-1])
+    cq, ck = _as_cu(cu_seqlens_q, q.device), _as_cu(cu_seqlens_k, q.device)
+    if _tracing():
+        return torch.ops.fat5.flash_attn_varlen_fwd(q, k, v, cq, ck, int(max_seqlen_q), int(max_seqlen_k), bool(causal), float(sm_scale),
+                                                    rpe1d, int(radius))
+    return _varlen_fwd_impl(q, k, v, cq, ck, int(max_seqlen_q), int(max_seqlen_k), bool(causal), float(sm_scale), rpe1d, int(radius))
+
+
+def flash_attn_varlen_bwd(do, q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False,
+                          sm_scale=None, rpe1d=None, radius=0, need_drpe=False):
+    """Backward of the packed (cu_seqlens) attention: returns dq (total_q, H, D), dk, dv (total_k, H, D)
+    (and drpe1d (H, 2*radius+1) or None when a generator is given)."""
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(q.shape[-1])
+    cq, ck = _as_cu(cu_seqlens_q, q.device), _as_cu(cu_seqlens_k, q.device)
+    if _tracing():
+        dq, dk, dv, d1 = torch.ops.fat5.flash_attn_varlen_bwd(do, q, k, v, o, lse, cq, ck, int(max_seqlen_q), int(max_seqlen_k), bool(causal),
+                                                              float(sm_scale), rpe1d, int(radius), bool(need_drpe))
+        d1 = d1 if (need_drpe and rpe1d is not None) else None
+    else:
+        dq, dk, dv, d1 = _varlen_bwd_impl(do, q, k, v, o, lse, cq, ck, int(max_seqlen_q), int(max_seqlen_k), bool(causal),
+                                          float(sm_scale), rpe1d, int(radius), bool(need_drpe))
+    return (dq, dk, dv, d1) if rpe1d is not None else (dq, dk, dv)
 
 
 class FlashAttentionVarlen(torch.autograd.Function):
@@ -361,9 +544,9 @@ class FlashAttentionVarlen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale, rpe1d, radius):
         r1 = rpe1d.detach().float().contiguous() if rpe1d is not None else None
-        o, lse = flash_attn_varlen_fwd(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, sm_scale,
-                                       r1, radius)
-        ctx.save_for_backward(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, *([r1] if r1 is not None else []))
+        cq, ck = _as_cu(cu_seqlens_q, q.device), _as_cu(cu_seqlens_k, q.device)
+        o, lse = flash_attn_varlen_fwd(q, k, v, cq, ck, max_seqlen_q, max_seqlen_k, causal, sm_scale, r1, radius)
+        ctx.save_for_backward(q, k, v, o, lse, cq, ck, *([r1] if r1 is not None else []))
         ctx.meta = (int(max_seqlen_q), int(max_seqlen_k), bool(causal), sm_scale, int(radius),
                     rpe1d.dtype if rpe1d is not None else None)
         return o

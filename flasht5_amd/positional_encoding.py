@@ -30,13 +30,24 @@ def relative_position_bucket(relative_position, bidirectional=True, num_buckets=
     return relative_buckets + torch.where(is_small, relative_position, large)
 
 
-def compute_bias(table, query_length, key_length, bidirectional=True, num_buckets=32, max_distance=128):
-    """Dense bias `(1, H, M, N)` from the `(num_buckets, H)` table (positional_encoding.py:73-102)."""
+def compute_bias(table, query_length, key_length, bidirectional=True, num_buckets=32, max_distance=128,
+                 context_position=None, memory_position=None):
+    """Dense bias `(1, H, M, N)` from the `(num_buckets, H)` table (positional_encoding.py:73-102).
+    `context_position (M,)` / `memory_position (N,)`: explicit (e.g. randomized, :79-89) positions instead of 0..M-1 / 0..N-1."""
     device = table.device
-    ctx = torch.arange(query_length, dtype=torch.long, device=device)[:, None]
-    mem = torch.arange(key_length, dtype=torch.long, device=device)[None, :]
-    bucket = relative_position_bucket(mem - ctx, bidirectional, num_buckets, max_distance)
+    ctx = torch.arange(query_length, dtype=torch.long, device=device) if context_position is None else context_position.to(device)
+    mem = torch.arange(key_length, dtype=torch.long, device=device) if memory_position is None else memory_position.to(device)
+    bucket = relative_position_bucket(mem[None, :] - ctx[:, None], bidirectional, num_buckets, max_distance)
     return table[bucket].permute(2, 0, 1).unsqueeze(0)
+
+
+def randomized_positions(max_sequence_length, length):
+    """`length` sorted distinct positions out of `max_sequence_length`, the first rooted at 0 -- the reference's draw
+    (positional_encoding.py:80-88: `sort(randperm(max_len)[:length])`, element 0 overwritten with 0), same calls on the
+    same (global CPU) generator, so a seeded run reproduces the reference's positions exactly."""
+    idx, _ = torch.sort(torch.randperm(max_sequence_length)[:length])
+    idx[0] = 0
+    return idx
 
 
 @lru_cache(maxsize=64)
@@ -88,7 +99,8 @@ class RelativePositionalEncoding(torch.nn.Module):
     * `forward_1d()` -> `(rpe1d, radius)`: the `(H, 2R+1)` fp32 generator of the linear-memory mode.  Build it ONCE per
       step and hand it to every layer's `flash_attention_v2_rpe1d`; the table gradient is then one accumulated scatter.
 
-    `randomized_position` (reference :79-89) has no Toeplitz structure and is supported by the dense form only."""
+    `randomized_position` (reference :79-89: sorted random subsets of 0..max_sequence_length-1 as query / key positions)
+    has no Toeplitz structure and is therefore served by the dense form only."""
 
     def __init__(self, relative_attention_num_buckets, relative_attention_max_distance, n_heads, max_sequence_length=0,
                  bidirectional=True, randomized_position=False):
@@ -102,14 +114,15 @@ class RelativePositionalEncoding(torch.nn.Module):
         self.relative_attention_bias = torch.nn.Embedding(relative_attention_num_buckets, n_heads)
 
     def compute_bias(self, query_length, key_length, device=None):
-        if self.randomized_position:
-            raise NotImplementedError("randomized_position: build the dense bias with the reference formula and pass it "
-                                      "to flash_attention_v2_bias")
         w = self.relative_attention_bias.weight
         if device is not None and w.device != torch.device(device):
             w = w.to(device)
+        ctx = mem = None
+        if self.randomized_position:  # context first, then memory: the reference's order of draws (:80-88)
+            ctx = randomized_positions(self.max_sequence_length, query_length)
+            mem = randomized_positions(self.max_sequence_length, key_length)
         return compute_bias(w, query_length, key_length, self.bidirectional, self.relative_attention_num_buckets,
-                            self.relative_attention_max_distance)
+                            self.relative_attention_max_distance, ctx, mem)
 
     def forward(self, q, k=None, v=None):
         query_length = q.shape[1]

@@ -11,8 +11,10 @@
  * Conventions
  *  - plain pointers and sizes only; no torch / HIP C++ types (hipStream_t is passed as void*).
  *  - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or
- *    frees device memory and keeps no mutable global state.  All launches are asynchronous on
- *    the given stream; the library never synchronises.
+ *    frees device memory.  Its only process-wide state is idempotent launch configuration (the largest dynamic-LDS size
+ *    already requested per kernel, a few developer environment knobs read on first use): results never depend on call
+ *    history and every entry point is safe to call from several threads.  All launches are asynchronous on the given
+ *    stream; the library never synchronises.
  *  - return value: FAT5_OK (0) or a negative error; the message of the last error on the
  *    calling thread is available from fat5_last_error().  Nothing throws across the ABI.
  *  - strides are in ELEMENTS.  The innermost (head_dim / feature / vocab) stride must be 1.
@@ -63,7 +65,8 @@ typedef struct fat5_attn_params {
   int32_t causal;        /* bottom-right aligned: key n visible to query m iff m + (N-M) >= n */
   int32_t bias_mode;     /* enum fat5_bias_mode */
   float sm_scale;
-  int32_t rpe_radius;    /* R for FAT5_BIAS_RPE1D */
+  int32_t rpe_radius;    /* R for FAT5_BIAS_RPE1D: 1..2048 forward; the backward needs its per-wave accumulators in LDS
+                            and accepts what fits 160 KiB (R <= 1024 for every head_dim; FAT5_EINVAL beyond) */
   /* ---- forward tensors ---- */
   const void* q; /* (B,H,M,D) strides q_stride[b,h,m] */
   const void* k; /* (B,H,N,D) */

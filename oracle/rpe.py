@@ -35,11 +35,13 @@ def relative_position_bucket(relative_position, bidirectional=True, num_buckets=
     return buckets + np.where(is_small, rp, large)          # :70
 
 
-def compute_bias(table, M, N, bidirectional=True, num_buckets=32, max_distance=128):
-    """reference positional_encoding.py:73-102 (non-randomized positions).
-    table: (num_buckets, H) tensor.  Returns (1, H, M, N) in table dtype."""
-    ctx = np.arange(M, dtype=np.int64)[:, None]
-    mem = np.arange(N, dtype=np.int64)[None, :]
+def compute_bias(table, M, N, bidirectional=True, num_buckets=32, max_distance=128, context_position=None, memory_position=None):
+    """reference positional_encoding.py:73-102.  table: (num_buckets, H) tensor.  Returns (1, H, M, N) in table dtype.
+    context_position / memory_position: the query / key positions when they are not 0..M-1 / 0..N-1 (the reference's
+    `randomized_position` branch, :79-89, draws sorted random subsets rooted at 0; the draw itself is not restated here --
+    the fixtures carry the positions the reference drew)."""
+    ctx = (np.arange(M, dtype=np.int64) if context_position is None else np.asarray(context_position, dtype=np.int64))[:, None]
+    mem = (np.arange(N, dtype=np.int64) if memory_position is None else np.asarray(memory_position, dtype=np.int64))[None, :]
     bucket = relative_position_bucket(mem - ctx, bidirectional, num_buckets, max_distance)
     vals = table[torch.from_numpy(bucket)]          # (M, N, H)
     return vals.permute(2, 0, 1).unsqueeze(0)

@@ -91,6 +91,28 @@ def gen_rpe():
         out[f"bias1d_{int(bidir)}_{M}_{N}"] = npy(b1)
         out[f"bias_{int(bidir)}_{M}_{N}_row0"] = npy(ref_bias[0, :, 0, :])
         out[f"bias_{int(bidir)}_{M}_{N}_rowlast"] = npy(ref_bias[0, :, M - 1, :])
+    # randomized positions (reference :79-89): the mirror module draws the same positions from the same seeded generator
+    from flasht5_amd.positional_encoding import RelativePositionalEncoding as MirrorRPE, compute_bias as mirror_bias
+    for bidir, (M, N, L) in ((True, (48, 80, 512)), (False, (64, 64, 256))):
+        ref_pe = RelativePositionalEncoding(32, 128, H, L, bidirectional=bidir, randomized_position=True)
+        with torch.no_grad():
+            ref_pe.relative_attention_bias.weight.normal_(0, 0.5)
+        mine_pe = MirrorRPE(32, 128, H, L, bidirectional=bidir, randomized_position=True)
+        mine_pe.load_state_dict(ref_pe.state_dict())
+        torch.manual_seed(1234 + M)
+        ref_bias = ref_pe.compute_bias(M, N).detach()
+        torch.manual_seed(1234 + M)
+        assert torch.equal(mine_pe.compute_bias(M, N).detach(), ref_bias), ("randomized", bidir)
+        # the positions themselves, recovered with the same draws, for the CPU test of the functional form
+        torch.manual_seed(1234 + M)
+        ctx, _ = torch.sort(torch.randperm(L)[:M]); ctx[0] = 0
+        mem, _ = torch.sort(torch.randperm(L)[:N]); mem[0] = 0
+        table = ref_pe.relative_attention_bias.weight.detach().clone()
+        assert torch.equal(mirror_bias(table, M, N, bidir, 32, 128, ctx, mem), ref_bias)
+        out[f"rand_table_{int(bidir)}"] = npy(table)
+        out[f"rand_ctx_{int(bidir)}"] = ctx.numpy()
+        out[f"rand_mem_{int(bidir)}"] = mem.numpy()
+        out[f"rand_bias_{int(bidir)}"] = npy(ref_bias[0])
     out["deltas"] = deltas
     save("rpe_buckets", **out)
 
@@ -155,12 +177,13 @@ def gen_attn_case(name, seed, B, H, M, N, D, dtype, bias_kind, causal, sm_scale,
         assert maxdiff(o_mine[:, :, valid], o_ref.detach()[:, :, valid]) < 2e-5
     if fwd_only:
         save(name, q=npy(q.bfloat16()), k=npy(k.bfloat16()), v=npy(v.bfloat16()), bias=npy(b.bfloat16()),
-             o=npy(o_mine), L=npy(L_mine), eager_lp_err=np.array(lp_err, dtype=np.float64),
+             o=npy(o_mine), L=npy(L_mine), o_ref=npy(o_ref.detach()), eager_lp_err=np.array(lp_err, dtype=np.float64),
              meta=np.array([B, H, M, N, D, int(causal), 0]), sm_scale=np.array([sm_scale], dtype=np.float64))
         return
     save(name,
          q=npy(q), k=npy(k), v=npy(v), do=npy(do), bias=npy(b),
          o=npy(o_mine), L=npy(L_mine), eager_lp_err=np.array(lp_err, dtype=np.float64),
+         o_ref=(npy(o_ref.detach()) if not larger_m_causal else None),  # the reference's own eager fp32 output
          dq=npy(grads[0] if grads else dq), dk=npy(grads[1] if grads else dk), dv=npy(grads[2] if grads else dv),
          dbias=npy(grads[3] if (grads and b is not None) else dbias),
          meta=np.array([B, H, M, N, D, int(causal), {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]]),

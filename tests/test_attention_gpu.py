@@ -47,6 +47,8 @@ def test_golden_fixture(name):
         assert e <= (bound(c[key], dt) if key == "o" else gbound(c[key], dt)), (key, e)
         if lp[i] > 0:
             assert e <= 2 * lp[i] + 1e-5 + HALF_ULP[dt] * c[key].abs().max().item(), (key, e, lp[i])
+    if "o_ref" in c:  # the REFERENCE's own eager fp32 output (the `o` above is the oracle's, asserted < 2e-5 from it)
+        assert maxdiff(got["o"], c["o_ref"]) <= bound(c["o_ref"], dt) + 2e-5
     if c["bias"] is not None:
         e = maxdiff(got["db"], c["dbias"])
         # dS is rounded to the bias dtype BEFORE the batch/head sum, like the reference (:720,:214): one extra
@@ -629,3 +631,104 @@ def test_varlen_with_rpe_bias(causal):
     for got, ref, key in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
         assert maxdiff(got, ref) <= gbound(ref, torch.bfloat16), key
     assert maxdiff(d1, rd1) <= 1e-2 * max(1.0, rd1.abs().max().item()) + 3e-2
+
+
+# ---- round-2 edge cases ------------------------------------------------------------------------------------------
+def test_masked_bias_finfo_min_fully_masked_row():
+    """`use_masking` folds the attention mask into the bias as finfo(dtype).min (reference modeling_flash_t5.py:266-270).
+    finfo(bf16).min * log2e overflows fp32: the kernels keep the scaled bias finite, so a row whose keys are ALL masked is a
+    uniform softmax like in the reference (`attn_ref` / its Triton kernel scale (s - m), not s), and partially masked rows
+    ignore the masked keys.  Truth = autograd through the eager fp32 `attn_ref` restatement (softmax, not exp(s - L): with
+    |L| ~ 3e38 that formula has no digits left -- which is also why the BACKWARD of a fully masked row is defined here as
+    zero: FA2 recomputes p = exp(s - L); such rows are padding and carry do = 0 in the model)."""
+    for dtype in (torch.bfloat16, torch.float16):
+        B, H, M, N, D = 2, 2, 96, 160, 64
+        q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=21)
+        bias = (torch.randn(B, H, M, N, generator=torch.Generator().manual_seed(2)) * 0.5).to(dtype).cuda()
+        fmin = torch.finfo(dtype).min
+        bias[:, :, :, 100:] = fmin          # padded keys
+        bias[0, :, 5, :] = fmin             # query rows with every key masked
+        bias[1, 1, 40:44, :] = fmin
+        do[0, :, 5] = 0
+        do[1, 1, 40:44] = 0
+        leaves = [t.detach().float().requires_grad_() for t in (q, k, v)]
+        o_ref = oracle.attn_ref(leaves[0], leaves[1], leaves[2], bias.float(), 0.125, causal=False, upcast=True)
+        g_ref = torch.autograd.grad(o_ref, leaves, do.float())
+        ref = {"o": o_ref.detach(), "dq": g_ref[0], "dk": g_ref[1], "dv": g_ref[2]}
+        assert torch.isfinite(ref["o"]).all()
+        got = run_dense(q, k, v, bias, do, 0.125, False)
+        for key in ("o", "dq", "dk", "dv"):
+            assert torch.isfinite(got[key].float()).all(), (dtype, key)
+            assert maxdiff(got[key], ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), (dtype, key)
+        assert torch.isfinite(got["db"].float()).all()
+        if dtype == torch.bfloat16:  # -3.4e38 absorbs the scores entirely: the fully masked row is the plain mean of v
+            assert maxdiff(got["o"][0, :, 5], v[0].float().mean(1)) <= bound(ref["o"], dtype)  # (fp16: -65504 does not)
+
+
+@pytest.mark.parametrize("M,N,md", [(600, 600, 1024), (2304, 2304, 1024), (700, 900, 512)])
+def test_rpe_large_radius(M, N, md):
+    """max_distance up to the limit of the linear-memory mode (R = 1024: 98 KiB of per-wave accumulators in the dK/dV
+    body, 49 KiB of dynamic LDS in the reduction launch)."""
+    from flasht5_amd import flash_attention_v2_rpe
+    dtype, B, H, causal, bidir = torch.bfloat16, 1, 2, False, True
+    q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, bidir, md, seed=M + N + md)
+    ref = oracle_all(q, k, v, bias, do, 0.125, causal)
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    tb = table.cuda().requires_grad_()
+    o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, 0.125)
+    dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+    _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, bias, o.detach(), ref["L"], do, 0.125, causal)
+    tl = table.clone().requires_grad_()
+    oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db_alg.cpu())
+    for got, key in ((o, "o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert maxdiff(got, ref[key]) <= (bound if key == "o" else gbound)(ref[key], dtype), key
+    assert maxdiff(dt.cpu(), tl.grad) <= 1e-2 * max(1.0, tl.grad.abs().max().item()) + 3e-2
+    with pytest.raises(ValueError):
+        flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, 2048, causal, 0.125)  # beyond the mode's limit
+
+
+def test_head_dim_16_rpe_entry_points():
+    """head_dim 16 (reference :234 accepts it) through the linear-memory entry points as well"""
+    from flasht5_amd import flash_attention_v2_rpe, flash_attention_v2_rpe1d
+    from flasht5_amd import positional_encoding as pe
+    B, H, M, N, D = 2, 3, 130, 200, 16
+    q, k, v, _, do = make_inputs(B, H, M, N, D, torch.bfloat16, None, seed=5)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(6)) * 0.5)
+    bias = oracle.compute_bias(table, M, N, True, 32, 128).contiguous().cuda()
+    ref = oracle_all(q, k, v, bias, do, 0.25, False)
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    tb = table.cuda().requires_grad_()
+    o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, True, 32, 128, False, 0.25)
+    dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+    assert o.shape == q.shape and dq.shape == q.shape and dk.shape == k.shape
+    for got, key in ((o, "o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert maxdiff(got, ref[key]) <= (bound if key == "o" else gbound)(ref[key], torch.bfloat16), key
+    r1 = pe.rpe1d_from_table(tb.detach(), True, 32, 128)
+    o1 = flash_attention_v2_rpe1d(q, k, v, r1, 128, False, 0.25)
+    assert torch.equal(o1, o.detach())
+
+
+def test_bad_arguments_raise_round2():
+    """shape / dtype / device mistakes are refused by the host mirror instead of reaching the kernels as wild pointers"""
+    from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe1d, flash_attn_varlen_func
+    q, k, v, b, _ = make_inputs(2, 2, 64, 96, 64, torch.bfloat16, "1h")
+    with pytest.raises(ValueError):
+        flash_attention_v2_bias(q, k, v, b[:, :, :, :64].contiguous())       # bias N too short
+    with pytest.raises(ValueError):
+        flash_attention_v2_bias(q, k, v, b[:, :1].expand(3, 2, 64, 96))       # batch 3 is neither 1 nor B
+    with pytest.raises(TypeError):
+        flash_attention_v2_bias(q, k, v, b.float())
+    with pytest.raises(ValueError):
+        flash_attention_v2_bias(q, k[:, :1], v[:, :1], None)                  # head count mismatch
+    r1 = torch.zeros(2, 257, device="cuda")
+    with pytest.raises(ValueError):
+        flash_attention_v2_rpe1d(q, k, v, r1[:, :200], 128)
+    qp, kp = torch.zeros(64, 2, 64, device="cuda", dtype=torch.bfloat16), torch.zeros(96, 2, 64, device="cuda", dtype=torch.bfloat16)
+    cu_q = torch.tensor([0, 32, 64], dtype=torch.int64)          # CPU int64: converted, not dereferenced on the host
+    cu_k = torch.tensor([0, 40, 96], dtype=torch.int32, device="cuda")
+    o = flash_attn_varlen_func(qp, kp, kp, cu_q, cu_k, 32, 56)
+    assert o.shape == qp.shape
+    with pytest.raises(ValueError):
+        flash_attn_varlen_func(qp, kp, kp, cu_q[:2], cu_k, 32, 56)
+    with pytest.raises(ValueError):
+        flash_attn_varlen_func(qp, kp, kp, cu_q, cu_k, 32, 56, rpe1d=r1[:, :100], radius=128)

@@ -55,6 +55,20 @@ def test_bad_descriptors_are_rejected_without_gpu(lib):
     p.bias_mode = _lib.BIAS_NONE
     p.B, p.H, p.M, p.N = 4, 12, 512, 512
     assert lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p)) >= 4 * 12 * 512 * 4
+    # backward: every tensor's (b, h) slice must fit a 32-bit buffer descriptor, and the RPE radius the LDS of the dK/dV body
+    # (both rejected before anything is launched: fake, aligned, non-null pointers are enough)
+    for name in ("q", "k", "v", "o", "lse", "dout", "dq", "dk", "dv", "workspace"):
+        setattr(p, name, 0x10000)
+    p.workspace_bytes = 1 << 40
+    ok = _lib.c_i64x3(12 * 512 * 64, 64, 12 * 64)
+    for name in ("q_stride", "k_stride", "v_stride", "o_stride", "do_stride", "dq_stride", "dk_stride", "dv_stride"):
+        setattr(p, name, ok)
+    p.dk_stride = _lib.c_i64x3(0, 64, 1 << 22)  # 512 rows x 8 MiB: 4 GiB per slice
+    assert lib.fat5_attn_bwd(ctypes.byref(p), None) == -1 and b"2 GiB" in lib.fat5_last_error()
+    p.dk_stride = ok
+    p.bias_mode, p.rpe1d, p.rpe_radius = _lib.BIAS_RPE1D, 0x10000, 2048
+    assert lib.fat5_attn_bwd(ctypes.byref(p), None) == -1 and b"LDS" in lib.fat5_last_error()
+    p.bias_mode = _lib.BIAS_NONE
     assert lib.fat5_rmsnorm_fwd(None, None, None, None, 4, 8, 8, 8, 1e-6, 0, 0, None) == -1
     assert lib.fat5_ce_fwd(None, None, None, None, None, 4, 8, 8, 0.0, 1.0, 0.0, -100, 0, 0, None) == -1
 
@@ -77,6 +91,27 @@ def test_host_bucket_and_bias_match_oracle():
         idx = torch.clamp(torch.arange(N)[None, :] - torch.arange(M)[:, None], -R, R) + R
         assert torch.equal(r1[:, idx].unsqueeze(0), oracle.compute_bias(table, M, N, bidir, 32, 128).float())
 
+
+
+def test_rpe_module_randomized_position():
+    """`randomized_position=True` (reference positional_encoding.py:79-89): the functional form reproduces the reference's
+    bias from the reference's positions (fixture); the module draws sorted distinct positions rooted at 0 from the global
+    generator (reproducible under torch.manual_seed) and refuses the 1-D form, which needs a Toeplitz bias."""
+    from flasht5_amd import positional_encoding as pe
+    z = load("rpe_buckets")
+    for b in (0, 1):
+        table, ctx, mem, want = (torch.from_numpy(z[f"rand_{k}_{b}"]) for k in ("table", "ctx", "mem", "bias"))
+        got = pe.compute_bias(table, len(ctx), len(mem), bool(b), 32, 128, ctx, mem)
+        assert torch.equal(got[0], want)
+    mod = pe.RelativePositionalEncoding(32, 128, 2, max_sequence_length=512, randomized_position=True)
+    torch.manual_seed(5)
+    b1 = mod.compute_bias(48, 80)
+    torch.manual_seed(5)
+    ctx, mem = pe.randomized_positions(512, 48), pe.randomized_positions(512, 80)
+    assert ctx[0] == 0 and bool((ctx[1:] > ctx[:-1]).all()) and ctx.max() < 512
+    assert torch.equal(b1, oracle.compute_bias(mod.relative_attention_bias.weight.detach(), 48, 80, True, 32, 128, ctx.numpy(), mem.numpy()))
+    with pytest.raises(NotImplementedError):
+        mod.forward_1d()
 
 
 def test_rpe_module_mirror_dense_and_1d():
@@ -134,6 +169,23 @@ def test_fake_impls_trace_without_a_gpu():
             assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
             if bias is not None:
                 assert ds.shape == bias.shape and ds.dtype == bias.dtype
+        # linear-memory RPE mode and packed batches (the generator / table gradient / no gradient forms)
+        r1 = torch.empty(4, 257, dtype=torch.float32, device="cuda")
+        o, L = torch.ops.fat5.flash_attn_rpe1d_fwd(q, k, v, r1, 128, False, 0.125)
+        assert o.shape == q.shape and L.shape == (2, 4, 128)
+        idx = torch.empty(257, dtype=torch.int32, device="cuda")
+        for need, bucket, want in ((True, None, (4, 257)), (True, idx, (32, 4)), (False, None, (0,))):
+            dq, dk, dv, d1 = torch.ops.fat5.flash_attn_rpe1d_bwd(o, o, q, k, v, r1, L, 128, False, 0.125, need, bucket, 32)
+            assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+            assert tuple(d1.shape) == want and d1.dtype == torch.float32
+        qp, kp = torch.empty(300, 4, 64, **bf), torch.empty(500, 4, 64, **bf)
+        cu = torch.empty(4, dtype=torch.int32, device="cuda")
+        for rp in (None, r1):
+            o2, lse2 = torch.ops.fat5.flash_attn_varlen_fwd(qp, kp, kp, cu, cu, 128, 256, False, 0.125, rp, 128)
+            assert o2.shape == qp.shape and o2.dtype == qp.dtype and lse2.shape == (4, 300) and lse2.dtype == torch.float32
+            dq, dk, dv, d1 = torch.ops.fat5.flash_attn_varlen_bwd(o2, qp, kp, kp, o2, lse2, cu, cu, 128, 256, False, 0.125, rp, 128, rp is not None)
+            assert dq.shape == qp.shape and dk.shape == kp.shape and dv.shape == kp.shape
+            assert tuple(d1.shape) == ((4, 257) if rp is not None else (0,))
         x, w = torch.empty(64, 768, **bf), torch.empty(768, **bf)
         y, rstd = torch.ops.fat5.rmsnorm_fwd(x, w, 1e-6)
         assert y.shape == x.shape and y.dtype == x.dtype and rstd.shape == (64,) and rstd.dtype == torch.float32

@@ -59,6 +59,18 @@ def test_bias1d_golden(bidir, M, N):
     assert md(tg, tl.grad) < 1e-3
 
 
+@pytest.mark.parametrize("bidir", [True, False])
+def test_randomized_position_bias_golden(bidir):
+    """reference `randomized_position` branch (positional_encoding.py:79-89): positions drawn BY the reference (fixture),
+    bias rebuilt by the oracle bit for bit"""
+    z = load("rpe_buckets")
+    b = int(bidir)
+    table, ctx, mem, want = (torch.from_numpy(z[f"rand_{k}_{b}"]) for k in ("table", "ctx", "mem", "bias"))
+    got = oracle.compute_bias(table, len(ctx), len(mem), bidir, 32, 128, ctx.numpy(), mem.numpy())
+    assert torch.equal(got[0], want)
+    assert ctx[0] == 0 and mem[0] == 0 and bool((ctx[1:] > ctx[:-1]).all()) and bool((mem[1:] > mem[:-1]).all())
+
+
 def test_attn_cfg1_golden():
     c = load_attn("attn_cfg1_fp32")
     o, L = oracle.attn_fwd_oracle(c["q"], c["k"], c["v"], c["bias"], c["sm_scale"], c["causal"])
