@@ -73,12 +73,14 @@ class FlashT5Attention(nn.Module):
         v = self.Wv(src).view(B, N, self.n_heads, self.key_value_proj_dim).permute(0, 2, 1, 3)
 
         if self.attention_type == "fat5_rpe":
-            if position_bias is None:
-                if self.pe_encoding is None:
-                    raise ValueError("fat5_rpe: block 0 needs has_positional_encoding=True (or pass (rpe1d, radius))")
+            if position_bias is None and self.pe_encoding is not None:
                 position_bias = self.pe_encoding.forward_1d()
-            rpe1d, radius = position_bias
-            out = flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, self.is_causal, self.softmax_scale)
+            if position_bias is None:
+                # no producer and nothing handed on: T5 cross-attention (reference :207,:324 -> bias=None, HAS_BIAS=False)
+                out = flash_attention_v2_bias(q, k, v, None, self.is_causal, self.softmax_scale)
+            else:
+                rpe1d, radius = position_bias
+                out = flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, self.is_causal, self.softmax_scale)
         else:
             if position_bias is None and self.pe_encoding is not None:
                 position_bias = self.pe_encoding.compute_bias(M, N, device=q.device).contiguous().to(q.dtype)

@@ -1,0 +1,230 @@
+"""Config 5 of BASELINE.json: a FAT5-base UL2 training step (seq 1024, data parallel) built from the path's three operators.
+
+A minimal encoder-decoder with the reference's structure (src/model/modeling_flash_t5.py: `FlashT5LayerFF` :148-164,
+`FlashT5LayerSelfAttention` / `FlashT5LayerCrossAttention` :297-349, `FlashT5Block` :352-392, `FlashT5Stack` :394-464,
+`FlashT5ForConditionalGeneration` :604-736) and its parameter names, so a reference checkpoint's state dict loads:
+
+  * RMSNorm        -> `FlashT5LayerNorm`        (fast_rms_layernorm, HIP)
+  * attention      -> `FlashT5Attention`        (flash_attention_v2_rpe1d / flash_attention_v2_bias, HIP); the T5 relative-position
+                      bias is produced by block 0 of each stack and handed to the following blocks (:403-405, :452-455);
+                      cross-attention has no bias (`bias=None`, :207,:324)
+  * loss           -> `FlashT5CrossEntropyLoss` (cross_entropy_loss with z-loss and label smoothing, HIP)
+  * everything else is plain torch-ROCm: `nn.Linear` (hipBLASLt), `nn.Embedding`, tanh-GELU gating, residual adds.
+
+This is the step DRIVER of the hot path, not a model zoo: no generation, heads, dropout (0 in every reference config),
+HF plumbing or checkpoint conversion.  Data parallelism = one process per GPU; `allreduce_gradients` is the step's one
+exchange (RCCL over xGMI): a single flat fp32 all-reduce that carries the two `(32, H)` relative-position tables first.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .attention_module import FlashT5Attention
+from .modules import FlashT5LayerNorm, FlashT5CrossEntropyLoss
+
+
+@dataclass
+class FAT5Config:
+    """model_args of configs/flan/fat5-flan-base.yaml (vocabulary: the 32768-entry tokenizer of examples/minipile)"""
+    vocab_size: int = 32768
+    d_model: int = 768
+    d_kv: int = 64
+    d_ff: int = 2048
+    num_heads: int = 12
+    num_layers: int = 12
+    num_decoder_layers: int = 12
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    max_sequence_length: int = 1024
+    layer_norm_epsilon: float = 1e-6
+    z_loss: float = 1e-4
+    label_smoothing: float = 0.1
+    attention_scale: float = 1.0
+    attention_type: str = "fat5_rpe"      # "fat5_rpe": O(S) bias memory; "triton": the reference's dense-bias operator
+    position_encoding_type: str = "t5"
+    use_glu_mlp: bool = True
+    use_gelu_act: bool = True
+    decoder_start_token_id: int = 0
+    pad_token_id: int = 0
+    crossentropy_inplace_backward: bool = True
+    is_decoder: bool = False
+
+
+class FAT5GatedAct(nn.Module):  # reference FlashT5DenseGatedAct / FlashT5DenseAct (:114-146)
+    def __init__(self, c):
+        super().__init__()
+        self.glu = c.use_glu_mlp
+        if self.glu:
+            self.wi_0 = nn.Linear(c.d_model, c.d_ff, bias=False)
+            self.wi_1 = nn.Linear(c.d_model, c.d_ff, bias=False)
+        else:
+            self.wi = nn.Linear(c.d_model, c.d_ff, bias=False)
+        self.act = nn.GELU(approximate="tanh") if c.use_gelu_act else nn.ReLU()
+
+    def forward(self, x):
+        if self.glu:
+            return self.act(self.wi_0(x)) * self.wi_1(x)
+        return self.act(self.wi(x))
+
+
+class FAT5LayerFF(nn.Module):  # :148-164
+    def __init__(self, c):
+        super().__init__()
+        self.act = FAT5GatedAct(c)
+        self.layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
+        self.wo = nn.Linear(c.d_ff, c.d_model, bias=False)
+
+    def forward(self, h):
+        return h + self.wo(self.act(self.layer_norm(h)))
+
+
+class FAT5LayerSelfAttention(nn.Module):  # :297-318
+    def __init__(self, c, has_positional_encoding):
+        super().__init__()
+        self.self_attention = FlashT5Attention(c, has_positional_encoding=has_positional_encoding, is_causal=c.is_decoder)
+        self.layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
+
+    def forward(self, h, position_bias=None):
+        a, position_bias = self.self_attention(self.layer_norm(h), position_bias=position_bias)
+        return h + a, position_bias
+
+
+class FAT5LayerCrossAttention(nn.Module):  # :321-349
+    def __init__(self, c):
+        super().__init__()
+        self.cross_attention = FlashT5Attention(c, has_positional_encoding=False)
+        self.layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
+
+    def forward(self, h, key_value_states):
+        a, _ = self.cross_attention(self.layer_norm(h), key_value_states=key_value_states)
+        return h + a
+
+
+class FAT5Block(nn.Module):  # :352-392
+    def __init__(self, c, has_positional_encoding):
+        super().__init__()
+        self.is_decoder = c.is_decoder
+        self.self_attention_layer = FAT5LayerSelfAttention(c, has_positional_encoding)
+        if self.is_decoder:
+            self.cross_attention_layer = FAT5LayerCrossAttention(c)
+        self.ff_layer = FAT5LayerFF(c)
+
+    def forward(self, h, position_bias=None, encoder_hidden_states=None):
+        h, position_bias = self.self_attention_layer(h, position_bias)
+        if self.is_decoder and encoder_hidden_states is not None:
+            h = self.cross_attention_layer(h, encoder_hidden_states)
+        return self.ff_layer(h), position_bias
+
+
+class FAT5Stack(nn.Module):  # :394-464
+    def __init__(self, c, embed_tokens, n_layers):
+        super().__init__()
+        self.embed_tokens = embed_tokens
+        self.block = nn.ModuleList([FAT5Block(c, has_positional_encoding=(i == 0)) for i in range(n_layers)])
+        self.final_layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
+
+    def forward(self, input_ids, encoder_hidden_states=None):
+        h = self.embed_tokens(input_ids)
+        if torch.is_autocast_enabled() and h.is_cuda:  # :424-425
+            h = h.to(torch.get_autocast_gpu_dtype())
+        position_bias = None  # produced by block 0, shared by the others (:452-455)
+        for blk in self.block:
+            h, position_bias = blk(h, position_bias, encoder_hidden_states)
+        return self.final_layer_norm(h)
+
+
+class FAT5ForConditionalGeneration(nn.Module):  # :604-736 (training forward only)
+    def __init__(self, config: FAT5Config):
+        super().__init__()
+        import copy
+        self.config = config
+        self.shared = nn.Embedding(config.vocab_size, config.d_model)
+        enc = copy.copy(config)
+        enc.is_decoder = False
+        dec = copy.copy(config)
+        dec.is_decoder = True
+        self.encoder = FAT5Stack(enc, self.shared, config.num_layers)
+        self.decoder = FAT5Stack(dec, self.shared, config.num_decoder_layers)
+        self.lm_head = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.loss_fct = FlashT5CrossEntropyLoss(z_loss_factor=config.z_loss, label_smoothing=config.label_smoothing,
+                                                inplace_backward=config.crossentropy_inplace_backward)
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """the reference's `_init_weights` (:482-517): Mesh-TF style, factor 1.0"""
+        c = self.config
+        self.shared.weight.normal_(0.0, 1.0)
+        self.lm_head.weight.normal_(0.0, c.d_model ** -0.5)
+        for m in self.modules():
+            if isinstance(m, FlashT5LayerNorm):
+                m.weight.fill_(1.0)
+            elif isinstance(m, FAT5GatedAct):
+                for w in ((m.wi_0, m.wi_1) if m.glu else (m.wi,)):
+                    w.weight.normal_(0.0, c.d_model ** -0.5)
+            elif isinstance(m, FAT5LayerFF):
+                m.wo.weight.normal_(0.0, c.d_ff ** -0.5)
+            elif isinstance(m, FlashT5Attention):
+                m.Wq.weight.normal_(0.0, (c.d_model * c.d_kv) ** -0.5)
+                m.Wk.weight.normal_(0.0, c.d_model ** -0.5)
+                m.Wv.weight.normal_(0.0, c.d_model ** -0.5)
+                m.o.weight.normal_(0.0, (c.num_heads * c.d_kv) ** -0.5)
+                if m.pe_encoding is not None:
+                    m.pe_encoding.relative_attention_bias.weight.normal_(0.0, c.d_model ** -0.5)
+
+    def _shift_right(self, labels):  # HF T5 convention used by the reference (:713-714)
+        c = self.config
+        shifted = labels.new_zeros(labels.shape)
+        shifted[..., 1:] = labels[..., :-1]
+        shifted[..., 0] = c.decoder_start_token_id
+        return shifted.masked_fill(shifted == -100, c.pad_token_id)
+
+    def rpe_tables(self):
+        """the two (num_buckets, H) relative-position tables (encoder, decoder): the bias gradients of the step"""
+        return [self.encoder.block[0].self_attention_layer.self_attention.pe_encoding.relative_attention_bias.weight,
+                self.decoder.block[0].self_attention_layer.self_attention.pe_encoding.relative_attention_bias.weight]
+
+    def forward(self, input_ids, labels):
+        enc = self.encoder(input_ids)
+        dec = self.decoder(self._shift_right(labels), encoder_hidden_states=enc)
+        return self.loss_fct(self.lm_head(dec), labels)
+
+
+def allreduce_gradients(model: nn.Module, group=None, average=True):
+    """The data-parallel exchange of one step: ONE flat fp32 all-reduce (SUM, then 1/world) of every parameter gradient,
+    the `(32, H)` bias tables at the front of the buffer (what DDP's first bucket carries in the reference's runs,
+    SURVEY 2 #14a).  In place; returns the flat reduced buffer (tests look at its head)."""
+    params = [p for p in model.parameters() if p.grad is not None]
+    if hasattr(model, "rpe_tables"):
+        head = [p for p in model.rpe_tables() if p.grad is not None]
+        ids = {id(p) for p in head}
+        params = head + [p for p in params if id(p) not in ids]
+    if not params:
+        return None
+    flat = torch.cat([p.grad.detach().reshape(-1).float() for p in params])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    return flat
+
+
+def train_step(model, input_ids, labels, optimizer=None, group=None, max_grad_norm=1.0):
+    """forward + backward (+ gradient all-reduce, clip like the reference's `max_grad_norm: 1.0`, optimizer step)"""
+    loss = model(input_ids, labels)
+    loss.backward()
+    allreduce_gradients(model, group)
+    if optimizer is not None:
+        if max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach()

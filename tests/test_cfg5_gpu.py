@@ -1,0 +1,112 @@
+"""Config 5 of BASELINE.json at single-rank size: one FAT5-base training step (12 + 12 layers, d_model 768, 12 heads x 64,
+GLU d_ff 2048, vocab 32768, z-loss 1e-4, label smoothing 0.1; encoder seq 1024, B = 4) through flasht5_amd.fat5_step --
+loss and the two (32, 12) relative-position table gradients (the step's bias gradients, what the data-parallel all-reduce
+carries first) against the same network in eager fp32 (oracle attention / norm / loss restatements, autograd)."""
+import math
+
+import pytest
+import torch
+
+import oracle
+from attn_helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _twin_loss(sd, cfg, input_ids, labels, dec_ids):
+    """eager fp32 restatement of FAT5ForConditionalGeneration.forward over the fp32 leaves `sd` (name -> tensor)"""
+    H, Dh, eps = cfg.num_heads, cfg.d_kv, cfg.layer_norm_epsilon
+    scale = cfg.attention_scale if cfg.attention_scale is not None else 1.0 / math.sqrt(H)
+
+    def rms(x, w):  # reference FlashT5LayerNorm eager branch (modeling_flash_t5.py:105-112)
+        return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+    def attn(x, kv, pre, bias, causal):
+        B, M, N = x.shape[0], x.shape[1], kv.shape[1]
+        q = (x @ sd[pre + "Wq.weight"].t()).view(B, M, H, Dh).permute(0, 2, 1, 3)
+        k = (kv @ sd[pre + "Wk.weight"].t()).view(B, N, H, Dh).permute(0, 2, 1, 3)
+        v = (kv @ sd[pre + "Wv.weight"].t()).view(B, N, H, Dh).permute(0, 2, 1, 3)
+        o = oracle.attn_ref(q, k, v, bias, scale, causal=causal, upcast=True)
+        return o.permute(0, 2, 1, 3).reshape(B, M, H * Dh) @ sd[pre + "o.weight"].t()
+
+    def stack(ids, pre, n, dec, enc_h):
+        h = sd["shared.weight"][ids]
+        S = ids.shape[1]
+        table = sd[pre + "block.0.self_attention_layer.self_attention.pe_encoding.relative_attention_bias.weight"]
+        bias = oracle.compute_bias(table, S, S, not dec, cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance)
+        for i in range(n):
+            b = f"{pre}block.{i}."
+            h = h + attn(rms(h, sd[b + "self_attention_layer.layer_norm.weight"]), rms(h, sd[b + "self_attention_layer.layer_norm.weight"]),
+                         b + "self_attention_layer.self_attention.", bias, dec)
+            if dec:
+                h = h + attn(rms(h, sd[b + "cross_attention_layer.layer_norm.weight"]), enc_h, b + "cross_attention_layer.cross_attention.", None, False)
+            x = rms(h, sd[b + "ff_layer.layer_norm.weight"])
+            g = torch.nn.functional.gelu(x @ sd[b + "ff_layer.act.wi_0.weight"].t(), approximate="tanh") * (x @ sd[b + "ff_layer.act.wi_1.weight"].t())
+            h = h + g @ sd[b + "ff_layer.wo.weight"].t()
+        return rms(h, sd[pre + "final_layer_norm.weight"])
+
+    enc = stack(input_ids, "encoder.", cfg.num_layers, False, None)
+    dec = stack(dec_ids, "decoder.", cfg.num_decoder_layers, True, enc)
+    logits = (dec @ sd["lm_head.weight"].t()).view(-1, cfg.vocab_size)
+    lab = labels.view(-1)
+    per, z, _ = oracle.ce_fwd_oracle(logits, lab, cfg.label_smoothing, 1.0, cfg.z_loss, -100)
+    return per.mean()  # the operator's per-row loss already holds the z-loss; mean over ALL rows (reference :64-68)
+
+
+@pytest.mark.parametrize("attention_type", ["fat5_rpe", "triton"])
+def test_cfg5_fat5_base_training_step(attention_type):
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
+    if attention_type == "triton":  # the reference's dense-bias operator: same step at a quarter of the depth (memory of the twin)
+        cfg = FAT5Config(attention_type="triton", num_layers=3, num_decoder_layers=3)
+    else:
+        cfg = FAT5Config()
+    B, S, T = 4, 1024, 512
+    torch.manual_seed(2026)
+    model = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+    g = torch.Generator().manual_seed(5)
+    input_ids = torch.randint(0, cfg.vocab_size, (B, S), generator=g).cuda()
+    labels = torch.randint(0, cfg.vocab_size, (B, T), generator=g)
+    labels[1, -37:] = -100   # padded targets
+    labels[3, -5:] = -100
+    labels = labels.cuda()
+
+    loss = model(input_ids, labels)
+    loss.backward()
+    tables = model.rpe_tables()
+    assert all(t.grad is not None and t.grad.shape == (32, 12) for t in tables)
+    assert all(torch.isfinite(p.grad.float()).all() for p in model.parameters())
+
+    sd = {n: p.detach().float().requires_grad_() for n, p in model.named_parameters()}
+    rloss = _twin_loss(sd, cfg, input_ids, labels, model._shift_right(labels))
+    names = [n for n, _ in model.named_parameters()]
+    rgrads = dict(zip(names, torch.autograd.grad(rloss, [sd[n] for n in names])))
+    assert abs(loss.item() - rloss.item()) <= 1e-2 * abs(rloss.item()), (loss.item(), rloss.item())
+    checked = [n for n in names if "relative_attention_bias" in n] + ["lm_head.weight", "shared.weight",
+               "encoder.block.0.self_attention_layer.self_attention.Wq.weight", "decoder.block.0.cross_attention_layer.cross_attention.Wk.weight",
+               "encoder.final_layer_norm.weight", f"decoder.block.{cfg.num_decoder_layers - 1}.ff_layer.wo.weight"]
+    got = dict(model.named_parameters())
+    for n in checked:
+        gg, rg = got[n].grad, rgrads[n]
+        # bf16 storage of every activation and weight gradient through 2 x 12 layers: a few 1e-2 of the largest entry
+        assert maxdiff(gg, rg) <= 8e-2 * rg.abs().max().item() + 1e-6, (n, maxdiff(gg, rg), rg.abs().max().item())
+    assert len([n for n in checked if "relative_attention_bias" in n]) == 2
+
+
+def test_cfg5_train_step_updates_and_repeats():
+    """three optimizer steps (fwd, bwd, clip, AdamW) twice from the same state: the first loss is bit-identical (the forward is
+    deterministic), later ones agree to summation-order noise (torch's embedding backward accumulates with atomics), the loss falls"""
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration, train_step
+    cfg = FAT5Config(num_layers=2, num_decoder_layers=2, vocab_size=4096)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, cfg.vocab_size, (2, 1024), generator=g).cuda()
+    labels = torch.randint(0, cfg.vocab_size, (2, 256), generator=g).cuda()
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        model = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        losses = [train_step(model, ids, labels, opt).item() for _ in range(3)]
+        runs.append((losses, [p.detach().clone() for p in model.parameters()]))
+    assert runs[0][0][0] == runs[1][0][0]
+    assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(runs[0][0], runs[1][0])), runs
+    assert runs[0][0][2] < runs[0][0][0]
