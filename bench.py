@@ -5,9 +5,14 @@
 
 A step = one forward + one backward of the attention hot path over one synthetic batch
 (B,H,S,D) = (4,12,S,64), bias = 32-bucket T5 relative-position bias, inputs resident in HBM, every kernel
-launched through the C ABI of libfat5.so and replayed from a HIP graph.  At N > 1 every rank owns its own
-batch (weak scaling, data parallel) and the step ends with ONE all-reduce (RCCL) of the bias-table gradient.
-Prints ONE JSON line on rank 0 (see the repo task contract); extra keys: by_seq, kernels, roofline, cpu_baseline.
+launched through the C ABI of libfat5.so and replayed from a HIP graph.  At N > 1:
+  --scaling weak   (default) every rank owns its own (4,12,S,64) batch (data parallel);
+  --scaling strong the ONE (4,12,S,64) batch is split over the ranks by (batch, head) units (head-major chunks):
+                   a rank runs its unit range in one forward and one backward call (fat5_attn_params.unit_begin/unit_count);
+either way the step ends with ONE all-reduce (RCCL over xGMI) of the (32,12) bias-table gradient.
+Prints ONE JSON line on rank 0 (see the repo task contract); extra keys: by_seq, kernels, roofline, cpu_baseline,
+eager_autograd (the drop-in autograd.Function path, no plan / graph), rowwise (RMSNorm, CE bandwidth), reference_shape
+(the reference's own published benchmark shape).
 """
 import argparse
 import json
@@ -32,7 +37,7 @@ def fwd_flops(S, causal=False):
     return 4.0 * B * H * S * S * D / (2 if causal else 1)  # reference benchmarks/bench_fa2_bias.py:10-13
 
 
-def make_plan(S, mode, device, seed):
+def make_plan(S, mode, device, seed, units=None):
     from flasht5_amd.flash_attention_v2_bias import AttentionPlan
     from flasht5_amd import positional_encoding as pe
     g = torch.Generator().manual_seed(seed)
@@ -46,9 +51,115 @@ def make_plan(S, mode, device, seed):
                   rpe_bucket=pe.bucket_index32(MAX_DISTANCE, True, NUM_BUCKETS, MAX_DISTANCE, device), num_buckets=NUM_BUCKETS)
     elif mode == "dense":
         kw = dict(bias=pe.compute_bias(table, S, S, True, NUM_BUCKETS, MAX_DISTANCE).to(torch.bfloat16).contiguous())
-    plan = AttentionPlan(q, k, v, do, causal=False, sm_scale=0.125, **kw)
+    plan = AttentionPlan(q, k, v, do, causal=False, sm_scale=0.125, units=units, **kw)
     idx = pe.bucket_index(MAX_DISTANCE, True, NUM_BUCKETS, MAX_DISTANCE, device)
     return plan, table, idx
+
+
+def eager_autograd(S, device, iters=200):
+    """The drop-in path a FAT5 model calls: flash_attention_v2_rpe(...) (autograd.Function) + autograd.grad on fresh leaves,
+    eager, no AttentionPlan, no graph -- wall clock per step (host-bound at S = 512)."""
+    from flasht5_amd import flash_attention_v2_rpe
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: torch.randn(B, S, H, D, generator=g).to(torch.bfloat16).to(device).permute(0, 2, 1, 3).requires_grad_()  # noqa: E731
+    q, k, v = mk(), mk(), mk()
+    do = torch.randn(B, S, H, D, generator=g).to(torch.bfloat16).to(device).permute(0, 2, 1, 3)
+    table = (torch.randn(NUM_BUCKETS, H, generator=g) * 0.5).to(device).requires_grad_()
+
+    def step():
+        o = flash_attention_v2_rpe(q, k, v, table, True, NUM_BUCKETS, MAX_DISTANCE, False, 0.125)
+        return torch.autograd.grad(o, (q, k, v, table), do)
+    for _ in range(50):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    return {"ms_per_step": round(t / iters * 1e3, 5), "host_enqueue_ms_per_step": round(t_host / iters * 1e3, 5),
+            "tflops": round(3.5 * fwd_flops(S) / (t / iters) / 1e12, 2),
+            "what": "flash_attention_v2_rpe + torch.autograd.grad (q, k, v, table), eager, no plan, no graph"}
+
+
+def graph_time(fn, it=20):
+    """average seconds per call with the calls captured in a HIP graph (kernel-side time: no Python / ctypes time)"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(it):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e-3
+
+
+def rowwise_bench(device):
+    """RMSNorm / cross-entropy + z-loss bandwidth (bf16): algorithmic bytes of SURVEY 8(d) / kernel time, vs 8 TB/s"""
+    from flasht5_amd.rms_norm import rmsnorm_fwd, rmsnorm_bwd
+    from flasht5_amd.cross_entropy_loss import cross_entropy_fwd, cross_entropy_bwd
+    out = {}
+    for rows, n in ((4096, 768), (65536, 1024)):
+        x = torch.randn(rows, n, device=device).bfloat16()
+        w = torch.ones(n, device=device).bfloat16()
+        dy = torch.randn_like(x)
+        _, rstd = rmsnorm_fwd(x, w, 1e-6)
+        tf = graph_time(lambda: rmsnorm_fwd(x, w, 1e-6))
+        tb = graph_time(lambda: rmsnorm_bwd(dy, x, w, rstd, 1e-6))
+        bf, bb = 2 * rows * n * 2, 3 * rows * n * 2
+        out[f"rmsnorm_{rows}x{n}"] = {"fwd_us": round(tf * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "fwd_frac": round(bf / tf / 1e9 / PEAK_HBM_GBS, 3),
+                                      "bwd_us": round(tb * 1e6, 2), "bwd_GBs": round(bb / tb / 1e9, 1), "bwd_frac": round(bb / tb / 1e9 / PEAK_HBM_GBS, 3)}
+        del x, dy
+    for rows, V in ((4096, 32768), (16384, 32768)):
+        lg = torch.randn(rows, V, device=device).bfloat16()
+        lab = torch.randint(0, V, (rows,), device=device)
+        dl = torch.randn(rows, device=device)
+        _, _, lse = cross_entropy_fwd(lg, lab, None, 0.1, 1.0, 1e-4, -100)
+        tf = graph_time(lambda: cross_entropy_fwd(lg, lab, None, 0.1, 1.0, 1e-4, -100), 10)
+        dst = torch.empty_like(lg)
+        tb = graph_time(lambda: cross_entropy_bwd(dl, lg, lse, lab, False, 0.1, 1.0, 1e-4, -100), 10)
+        bf, bb = rows * V * 2, 2 * rows * V * 2
+        out[f"ce_{rows}x{V}"] = {"fwd_us": round(tf * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "fwd_frac": round(bf / tf / 1e9 / PEAK_HBM_GBS, 3),
+                                 "bwd_us": round(tb * 1e6, 2), "bwd_GBs": round(bb / tb / 1e9, 1), "bwd_frac": round(bb / tb / 1e9 / PEAK_HBM_GBS, 3)}
+        del lg, dst
+    out["bytes_model"] = "rmsnorm fwd 2RNe, bwd 3RNe; ce fwd RVe, bwd 2RVe (e = 2); label smoothing 0.1, z-loss 1e-4"
+    return out
+
+
+def reference_shape_bench(device):
+    """The shape the reference publishes (benchmarks/bench_fa2_bias.py:10-40: B=16, H=12, causal, dense (1,H,S,S) bias,
+    sm_scale 1.3; FLOPs = 4*B*S^2*H*D/2 fwd, x2.5 bwd) -- a same-shape row for BASELINE.md's A100 table."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    out = {}
+    for dtype, dn in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        for Dh in (64, 128):
+            for S in (512, 1024):
+                g = torch.Generator().manual_seed(S + Dh)
+                q, k, v, do = (torch.randn(16, 12, S, Dh, generator=g).to(dtype).to(device) for _ in range(4))
+                bias = torch.randn(1, 12, S, S, generator=g).to(dtype).to(device)
+                plan = AttentionPlan(q, k, v, do, bias=bias, causal=True, sm_scale=1.3)
+                plan.forward()
+                tf = graph_time(plan.forward, 10)
+                tb = graph_time(plan.backward, 10)
+                f = 4.0 * 16 * 12 * S * S * Dh / 2
+                out[f"{dn}_d{Dh}_s{S}"] = {"fwd_tflops": round(f / tf / 1e12, 1), "bwd_tflops": round(2.5 * f / tb / 1e12, 1),
+                                           "fwd_us": round(tf * 1e6, 1), "bwd_us": round(tb * 1e6, 1)}
+                del plan, q, k, v, do, bias
+    out["what"] = "B=16, H=12, causal, dense (1,12,S,S) bias + dbias, sm_scale 1.3 (reference benchmarks/bench_fa2_bias.py)"
+    return out
 
 
 def event_time(fn, iters, warmup=3, prewarm_s=0.2):
@@ -150,6 +261,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--mode", default="rpe", choices=["rpe", "dense", "none"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one (4,12,S,64) batch per rank; strong = ONE batch split over the ranks by (batch, head) units")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
     args = ap.parse_args()
@@ -175,7 +288,13 @@ def main():
 
     import flasht5_amd  # noqa: F401  raises if libfat5.so is missing
     S, mode = args.seq, args.mode
-    plan, table, idx = make_plan(S, mode, device, seed=rank)
+    strong = args.scaling == "strong" and world > 1
+    units = None
+    if strong:
+        # every rank describes the SAME batch (same seed) and runs only its head-major unit range of it
+        from flasht5_amd.sharding import unit_range, heads_needing_reduction
+        units = unit_range(B, H, world, rank)
+    plan, table, idx = make_plan(S, mode, device, seed=0 if strong else rank, units=units)
 
     def step_local():
         plan.forward()
@@ -244,20 +363,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
-    flops_step = 3.5 * fwd_flops(S) * world
+    flops_step = 3.5 * fwd_flops(S) * (1 if strong else world)
     value = flops_step / (ms_per_step * 1e-3) / 1e12
+    ar_ms = None
+    if world > 1 and plan.dbias is not None:  # the all-reduce alone (blocking), reported beside the step time
+        buf = plan.dbias.float().clone()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t1) / 20 * 1e3
 
     if rank == 0:
         out = {
             "metric": "FA2+T5-bias fwd+bwd TFLOP/s (bf16, d_head=64)", "value": round(value, 2), "unit": "TFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"encoder self-attn fwd+bwd, (B,H,S,d)=({B},{H},{S},{D}) per GPU, non-causal, "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"encoder self-attn fwd+bwd, (B,H,S,d)=({B},{H},{S},{D}) "
+                                   f"{'in total, (batch, head) units split over the GPUs' if strong else 'per GPU'}, non-causal, "
                                    f"32-bucket T5 RPE bias ({mode} mode), sm_scale 0.125, (B,S,H,D)-strided inputs",
-                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}", "bias_mode": mode,
-                       "launch": "hipGraph replay" if graph is not None else "eager C-ABI calls"},
+                       "global_batch": B if strong else B * world, "seq_len": S,
+                       "parallelism": (f"units{world} ({units[1]} of {B * H} (batch, head) units per GPU)" if strong else f"dp{world}"),
+                       "bias_mode": mode, "launch": "hipGraph replay" if graph is not None else "eager C-ABI calls"},
             "frac_of_peak": round(value / (PEAK_BF16_TFLOPS * world), 4),
+            "per_gpu_tflops": round(value / world, 2),
         }
+        if ar_ms is not None:
+            out["bias_grad_allreduce_ms"] = round(ar_ms, 4)
+            if strong:
+                out["heads_needing_reduction"] = heads_needing_reduction(B, H, world)
         if not args.no_extras:
             iters = max(10, min(args.steps, 50))
             kern, timed = kernel_breakdown(plan, S, iters)
@@ -268,7 +405,7 @@ def main():
                                "avg_launch_us": round(kern[dom]["us"], 3), "traffic": load_traffic(dom, S, mode)}
             by_seq = {}
             for s2 in (512, 2048, 8192):
-                p2 = plan if s2 == S else make_plan(s2, mode, device, seed=rank)[0]
+                p2 = plan if (s2 == S and not strong) else make_plan(s2, mode, device, seed=rank)[0]
                 it = 50 if s2 <= 2048 else 20
                 tf = event_time(p2.forward, it)
                 p2.forward()
@@ -281,6 +418,9 @@ def main():
                 del p2
             out["by_seq"] = by_seq
             if world == 1:
+                out["eager_autograd"] = eager_autograd(S, device)
+                out["rowwise"] = rowwise_bench(device)
+                out["reference_shape"] = reference_shape_bench(device)
                 out["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(out), flush=True)
     if world > 1:

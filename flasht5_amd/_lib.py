@@ -38,7 +38,8 @@ class AttnParams(ctypes.Structure):
         ("do_stride", c_i64x3), ("dq_stride", c_i64x3), ("dk_stride", c_i64x3), ("dv_stride", c_i64x3),
         ("dbias", ctypes.c_void_p), ("dbias_batch", ctypes.c_int32), ("dbias_heads", ctypes.c_int32),
         ("drpe1d", ctypes.c_void_p), ("rpe_bucket", ctypes.c_void_p), ("drpe_table", ctypes.c_void_p),
-        ("rpe_num_buckets", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("rpe_num_buckets", ctypes.c_int32), ("unit_begin", ctypes.c_int32), ("unit_count", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
     ]
 

@@ -68,9 +68,8 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 
   FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
-  int bh, mblk;
-  decode_block(bid, a.B * a.H, a.n_mblk, bh, mblk);
-  const int b = bh / a.H, h = bh % a.H;
+  int b, h, mblk;
+  decode_unit(a, bid, a.n_mblk, b, h, mblk);
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],
           dooff = (int64_t)b * a.dos[0], dqoff = (int64_t)b * a.dqs[0];
@@ -420,9 +419,9 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
 
   FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
-  int bh, nblk;
-  decode_block(bid, a.B * a.H, a.n_nblk, bh, nblk);
-  const int b = bh / a.H, h = bh % a.H;
+  int b, h, nblk;
+  decode_unit(a, bid, a.n_nblk, b, h, nblk);
+  const int bh = b * a.H + h;  // (row of this (batch, head) in the partial-sum workspace)
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],
           dooff = (int64_t)b * a.dos[0], dkoff = (int64_t)b * a.dks[0], dvoff = (int64_t)b * a.dvs[0];

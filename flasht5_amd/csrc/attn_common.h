@@ -244,8 +244,23 @@ struct AttnArgs {
   int32_t bias_dma;         // dense bias rows are 16-byte aligned: tiles can go global -> LDS directly
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
+  int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   float scale;
 };
+
+// workgroup index -> (batch, head, tile).  The grid covers the call's units x tiles (all B * H units, or a unit range).
+FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h, int& tile) {
+  int ui;
+  decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile);
+  if (a.unit_count > 0) {
+    const int u = a.unit_begin + ui;
+    h = u / a.B;
+    b = u - h * a.B;
+  } else {
+    b = ui / a.H;
+    h = ui - b * a.H;
+  }
+}
 
 // Buffer resource over rows [0, nrows) of one (b,h) slice: bytes past the last row's D elements are out of range
 // (hardware returns 0).  Inputs are made provably wave-uniform so no waterfall loop is generated around the loads.

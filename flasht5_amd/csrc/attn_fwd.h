@@ -121,9 +121,8 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   constexpr int QG = SPLIT ? NW / 2 : NW;              // query groups (32 rows each) per workgroup
   const int half = SPLIT ? w / QG : 0;                 // SPLIT: which 32-key block of every tile this wave owns
   const int qg = SPLIT ? w - half * QG : w;
-  int bh, mblk;
-  decode_block(blockIdx.x, a.B * a.H, a.n_mblk, bh, mblk);
-  const int b = bh / a.H, h = bh % a.H;
+  int b, h, mblk;
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
 
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0],

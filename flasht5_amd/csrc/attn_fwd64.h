@@ -101,9 +101,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   float* sT = reinterpret_cast<float*>(smem + Cfg::TAB);
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
-  int bh, mblk;
-  decode_block(item, a.B * a.H, a.n_mblk, bh, mblk);
-  const int b = bh / a.H, h = bh % a.H;
+  int b, h, mblk;
+  decode_unit(a, item, a.n_mblk, b, h, mblk);
   const int M = a.M, N = a.N;
   const int m0 = mblk * BM;
   if (m0 >= M) return;

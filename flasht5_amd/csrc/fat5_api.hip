@@ -64,8 +64,12 @@ int check_common(const fat5_attn_params* p) {
     if (!p->rpe1d) return fail(FAT5_EINVAL, "rpe1d mode without table");
     if (p->rpe_radius < 1 || p->rpe_radius > 2048) return fail(FAT5_EINVAL, "rpe_radius %d out of range [1, 2048]", p->rpe_radius);
   }
+  if (p->unit_count < 0 || p->unit_begin < 0 || (p->unit_count > 0 && (long)p->unit_begin + p->unit_count > (long)p->B * p->H))
+    return fail(FAT5_EINVAL, "unit range [%d, +%d) outside the %ld units of the problem", p->unit_begin, p->unit_count, (long)p->B * p->H);
+  if (p->unit_count > 0 && p->cu_seqlens_q) return fail(FAT5_EINVAL, "unit ranges are not available for packed (cu_seqlens) batches");
   return FAT5_OK;
 }
+inline long n_units(const fat5_attn_params* p) { return p->unit_count > 0 ? p->unit_count : (long)p->B * p->H; }
 
 bool strides_ok(const void* ptr, const int64_t* s) {
   return aligned16(ptr) && (s[0] % 8 == 0) && (s[1] % 8 == 0) && (s[2] % 8 == 0) && s[2] > 0;
@@ -88,6 +92,7 @@ void fill_common(const fat5_attn_params* p, AttnArgs& a) {
   a.bias = (const uint16_t*)p->bias; a.rpe1d = p->rpe1d;
   a.cu_q = p->cu_seqlens_q; a.cu_k = p->cu_seqlens_k;
   a.total_q = p->total_q; a.total_k = p->total_k;
+  a.unit_begin = p->unit_begin; a.unit_count = p->unit_count;
   if (p->bias_mode == FAT5_BIAS_DENSE) {
     a.bias_vec4 = ((reinterpret_cast<uintptr_t>(p->bias) & 7) == 0) && (p->bias_stride[0] % 4 == 0) &&
                   (p->bias_stride[1] % 4 == 0) && (p->bias_stride[2] % 4 == 0);
@@ -133,6 +138,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
 
   AttnArgs a;
   fill_common(p, a);
+  // Kernel variants (waves per workgroup, split / pipelined bodies) are chosen from the FULL problem, the grid from this call's
+  // units: a unit-range call runs exactly the code the whole-problem call would run on those units, so sharded and unsharded
+  // results are bit-identical.
   const long bh = (long)p->B * p->H;
   int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW", true);
   a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
@@ -155,7 +163,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     nw = 4;
     a.n_mblk = (p->M + 255) / 256;
   }
-  const long grid = bh * a.n_mblk;
+  const long grid = n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
   if (e != hipSuccess) return hip_fail(e, "attn_fwd launch");
@@ -163,7 +171,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
 }
 
 static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
-  const long bh = (long)p->B * p->H;
+  const long bh = (long)p->B * p->H;  // workspace layout and kernel variants follow the full problem also for a unit range
   L.nw_q = pick_nw(bh * ((p->M + 127) / 128), "FAT5_BWDQ_NW");
   L.nw_kv = pick_nw(bh * ((p->N + 127) / 128), "FAT5_BWDKV_NW");
   L.n_nblk = (p->N + 32 * L.nw_kv - 1) / (32 * L.nw_kv);
@@ -228,6 +236,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     if (!((p->dbias_batch == 1 || p->dbias_batch == p->B) && (p->dbias_heads == 1 || p->dbias_heads == p->H)))
       return fail(FAT5_EINVAL, "bwd: dbias batch/heads (%d,%d) must be 1 or (B,H)", p->dbias_batch, p->dbias_heads);
     if (!aligned16(p->dbias)) return fail(FAT5_EINVAL, "bwd: dbias must be 16-byte aligned");
+    if (p->unit_count > 0 && (p->dbias_batch != p->B || p->dbias_heads != p->H))
+      return fail(FAT5_EINVAL, "bwd: a unit range writes dense dbias only in its unreduced (B, H, M, N) form");
   }
   // the kernels address one (b,h) slice of every tensor through a 32-bit buffer descriptor (like the forward)
   if (!slice_fits(p->M, p->q_stride[2], p->D) || !slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) ||
@@ -271,8 +281,17 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.ds_vec4 = (p->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 7) == 0);
     a.ds_vec8 = (p->N % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 15) == 0);
     if (p->causal && (stages & FAT5_BWD_DQ)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
-      hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
-      if (e != hipSuccess) return hip_fail(e, "memset ds");
+      // (unit u = h * B + b occupies row b * H + h of the (B, H, M, N) tensor: a range is not contiguous there -> per unit)
+      if (p->unit_count > 0) {
+        for (int u = p->unit_begin; u < p->unit_begin + p->unit_count; ++u) {
+          const int hh = u / p->B, bb = u - hh * p->B;
+          hipError_t e = hipMemsetAsync(a.ds_out + ((size_t)bb * p->H + hh) * MN, 0, (size_t)MN * 2, stream);
+          if (e != hipSuccess) return hip_fail(e, "memset ds");
+        }
+      } else {
+        hipError_t e = hipMemsetAsync(a.ds_out, 0, (size_t)bh * MN * 2, stream);
+        if (e != hipSuccess) return hip_fail(e, "memset ds");
+      }
     }
   }
   if (p->bias_mode == FAT5_BIAS_RPE1D && (p->drpe1d || p->drpe_table)) {
@@ -284,10 +303,11 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
   a.n_nblk = L.n_nblk;
   a.n_kv_blocks = 0;
-  const long grid_q = bh * a.n_mblk, grid_kv = bh * a.n_nblk;
+  const long grid_q = n_units(p) * a.n_mblk, grid_kv = n_units(p) * a.n_nblk;
+  const long full_q = bh * a.n_mblk, full_kv = bh * a.n_nblk;  // (variant choice: see fat5_attn_fwd)
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
   // side by side (attn_bwd_fused_kernel).  FAT5_BWD_FUSE=0 disables (developer A/B).
-  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, grid_q, grid_kv, p->D);
+  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, p->D);
   if (fuse) {
     a.n_kv_blocks = (int)grid_kv;
     launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
@@ -328,7 +348,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       if (ea != hipSuccess) return hip_fail(ea, "drpe_reduce attribute");
     }
     hipLaunchKernelGGL(drpe_reduce_kernel, dim3(p->H), dim3(1024), smem, stream, a.drpe_part, p->drpe1d, p->rpe_bucket,
-                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets);
+                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets, p->unit_begin, p->unit_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
   }

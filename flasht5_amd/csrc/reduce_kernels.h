@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
 // dtable[bucket][h] = sum_{i: bucket[i] == bucket} drpe1d[h][i] in the same launch (8 lanes per bucket, fixed order).
 __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restrict__ part, float* __restrict__ out1d,
                                                            const int32_t* __restrict__ bucket, float* __restrict__ dtable,
-                                                           int B, int H, int nblk, int n1, int nbuckets) {
+                                                           int B, int H, int nblk, int n1, int nbuckets, int unit_begin,
+                                                           int unit_count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sv4 = reinterpret_cast<float*>(smem);          // [4][n1] partial chains
   float* sv = sv4 + 4 * n1;                             // [n1] reduced diagonal sums of this head
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
         vv[u] = 0.f;
         if (pidx < nparts) {
           const int b = pidx / nblk, blk = pidx - b * nblk;
-          vv[u] = part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
+          // a unit-range call wrote the partial rows of its own units only (u = h * B + b): the others stay out of the sum
+          const bool mine = unit_count <= 0 || (unsigned)(h * B + b - unit_begin) < (unsigned)unit_count;
+          if (mine) vv[u] = part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
         }
       }
 #pragma unroll

@@ -304,6 +304,25 @@ def _rpe_bwd(o, do, q, k, v, r1, L, radius, causal, sm_scale, need, bucket=None,
     return _attn_bwd(o, do, q, k, v, None, r1, int(radius), L, bool(causal), float(sm_scale), bool(need), bucket, int(num_buckets))
 
 
+# (H, 2R+1) generator of a table, remembered until the table changes (its autograd version counter moves on every in-place
+# update, e.g. an optimizer step): a 12-layer stack that calls flash_attention_v2_rpe with one table builds it once per step
+_RPE1D_CACHE = {}
+
+
+def _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance):
+    import weakref
+    key = (R, bool(bidirectional), num_buckets, max_distance, rpe_table.device, rpe_table.dtype)
+    hit = _RPE1D_CACHE.get(id(rpe_table))
+    if hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version and hit[2] == key:
+        return hit[3]
+    idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, rpe_table.device)
+    r1 = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
+    if len(_RPE1D_CACHE) > 64:
+        _RPE1D_CACHE.clear()
+    _RPE1D_CACHE[id(rpe_table)] = (weakref.ref(rpe_table), rpe_table._version, key, r1)
+    return r1
+
+
 class FlashAttentionRPE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale):
@@ -319,8 +338,7 @@ class FlashAttentionRPE(torch.autograd.Function):
         pad16 = D == 16
         if pad16:
             q, k, v = _pad16((q, k, v))
-        idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, q.device)
-        rpe1d = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
+        rpe1d = _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance)
         o, L = _rpe_fwd(q, k, v, rpe1d, R, causal, sm_scale)
         ctx.save_for_backward(q, k, v, o, L, rpe1d, _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device))
         ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype, pad16)
@@ -581,7 +599,9 @@ class AttentionPlan:
     mode: "none" | "dense" (bias tensor) | "rpe" (rpe1d (H, 2R+1) fp32 + radius)."""
 
     def __init__(self, q, k, v, do, *, bias=None, rpe1d=None, radius=0, causal=False, sm_scale=None, need_dbias=True,
-                 rpe_bucket=None, num_buckets=0):
+                 rpe_bucket=None, num_buckets=0, units=None):
+        """units = (begin, count): run only the head-major unit range u = h * B + b in [begin, begin + count) (a rank's shard,
+        `flasht5_amd.sharding.unit_range`); the bias gradient then holds this range's partial sums."""
         _check_inputs(q, k, v)
         self.q, self.k, self.v, self.do = _prep(q), _prep(k), _prep(v), _prep(do)
         B, H, M, D = q.shape
@@ -610,6 +630,8 @@ class AttentionPlan:
             elif need_dbias:
                 self.dbias = torch.empty_like(rpe1d)
                 p.drpe1d = self.dbias.data_ptr()
+        if units is not None:
+            p.unit_begin, p.unit_count = int(units[0]), int(units[1])
         self.lib = _lib.load()
         nbytes = self.lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
         self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)

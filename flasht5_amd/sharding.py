@@ -26,6 +26,15 @@ def shard_units(B: int, H: int, world: int, rank: int) -> List[Tuple[int, int]]:
     return [(u % B, u // B) for u in range(start, stop)]
 
 
+def unit_range(B: int, H: int, world: int, rank: int) -> Tuple[int, int]:
+    """(unit_begin, unit_count) of this rank's chunk in head-major unit order -- what `fat5_attn_params.unit_begin/unit_count`
+    (and `AttentionPlan(units=...)`) take: the shard of `shard_units` runs in ONE forward and ONE backward call."""
+    total = B * H
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
 def heads_needing_reduction(B: int, H: int, world: int) -> List[int]:
     """heads whose B batch elements are spread over more than one rank (their dbias needs the all-reduce)."""
     owners = {}

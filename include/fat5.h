@@ -102,6 +102,15 @@ typedef struct fat5_attn_params {
   const int32_t* rpe_bucket;
   float* drpe_table;
   int32_t rpe_num_buckets;
+  /* ---- unit range (optional): the B*H independent (batch, head) problems in head-major order, u = h * B + b -- the order in
+   * which SURVEY 8(e) deals them to ranks (the reference's grid axes 1, 2: flash_attention_v2_bias.py:57,164,192).
+   * unit_count > 0: forward and backward touch ONLY units [unit_begin, unit_begin + unit_count): every tensor keeps the full
+   * (B, H, ...) geometry and strides, other units' slices are neither read nor written; lse and the workspace keep their
+   * full-problem layout; drpe1d / drpe_table receive the partial sums over this range's units (heads without a unit in the
+   * range get zeros) -- ranks then add their partial tables with ONE all-reduce.  Not with cu_seqlens; dense dbias only in
+   * its unreduced (B, H, M, N) form.  unit_count == 0: the whole problem. */
+  int32_t unit_begin;
+  int32_t unit_count;
   int32_t reserved0;
   void* workspace;          /* size from fat5_attn_bwd_workspace_bytes(); 256-B aligned */
   size_t workspace_bytes;

@@ -732,3 +732,73 @@ def test_bad_arguments_raise_round2():
         flash_attn_varlen_func(qp, kp, kp, cu_q[:2], cu_k, 32, 56)
     with pytest.raises(ValueError):
         flash_attn_varlen_func(qp, kp, kp, cu_q, cu_k, 32, 56, rpe1d=r1[:, :100], radius=128)
+
+
+@pytest.mark.parametrize("S,mode,world", [(512, "rpe", 8), (512, "rpe", 5), (1024, "none", 4), (2048, "rpe", 8), (512, "dense", 8)])
+def test_unit_range_shards_match_unsharded(S, mode, world):
+    """the B*H (batch, head) units dealt to `world` ranks in head-major chunks, every chunk as ONE forward and ONE
+    backward call on this device (`AttentionPlan(units=...)` -> fat5_attn_params.unit_begin / unit_count): o, dq, dk, dv of
+    the assembled shards equal the unsharded run BIT FOR BIT, and the shards' partial bias-table gradients add up (fp32 order)
+    to the unsharded table gradient -- what the ranks' single all-reduce computes."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    from flasht5_amd.sharding import unit_range, shard_units
+    B, H, D = 4, 12, 64
+    q, k, v, _, do = make_inputs(B, H, S, S, D, torch.bfloat16, None, seed=S + world, strided=True)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(3)) * 0.5).cuda()
+    kw = {}
+    if mode == "rpe":
+        kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+    elif mode == "dense":
+        kw = dict(bias=pe.compute_bias(table, S, S).expand(B, H, S, S).to(torch.bfloat16).contiguous())
+    full = AttentionPlan(q, k, v, do, sm_scale=0.125, **kw)
+    o = full.forward().clone()
+    dq, dk, dv, db = (t.clone() if t is not None else None for t in full.backward())
+    torch.cuda.synchronize()
+    poison = lambda t: torch.full_like(t, float("nan"))  # noqa: E731  (a unit outside every range would stay NaN)
+    so, sdq, sdk, sdv = poison(o), poison(dq), poison(dk), poison(dv)
+    sdb = torch.zeros_like(db) if mode == "rpe" else (poison(db) if db is not None else None)
+    for r in range(world):
+        ub, uc = unit_range(B, H, world, r)
+        assert [(u % B, u // B) for u in range(ub, ub + uc)] == shard_units(B, H, world, r)
+        plan = AttentionPlan(q, k, v, do, sm_scale=0.125, units=(ub, uc), **kw)
+        for t in (plan.o, plan.dq, plan.dk, plan.dv):
+            t.fill_(float("nan"))
+        if mode == "dense":
+            plan.dbias.fill_(float("nan"))
+        po = plan.forward()
+        pdq, pdk, pdv, pdb = plan.backward()
+        torch.cuda.synchronize()
+        for (b, h) in shard_units(B, H, world, r):
+            so[b, h], sdq[b, h], sdk[b, h], sdv[b, h] = po[b, h], pdq[b, h], pdk[b, h], pdv[b, h]
+            if mode == "dense":
+                sdb[b, h] = pdb[b, h]
+        # nothing outside the range was written
+        mask = torch.ones(B, H, dtype=torch.bool)
+        for (b, h) in shard_units(B, H, world, r):
+            mask[b, h] = False
+        assert torch.isnan(po.float()[mask.cuda()]).all() and torch.isnan(pdk.float()[mask.cuda()]).all()
+        if mode == "rpe":
+            heads = sorted({h for _, h in shard_units(B, H, world, r)})
+            other = [h for h in range(H) if h not in heads]
+            assert (pdb[:, other] == 0).all()  # heads without a unit in the range: zero partial gradient
+            sdb += pdb                          # the all-reduce
+    assert torch.equal(so, o) and torch.equal(sdq, dq) and torch.equal(sdk, dk) and torch.equal(sdv, dv)
+    if mode == "rpe":
+        assert maxdiff(sdb, db) <= 1e-5 * max(1.0, db.abs().max().item())
+    elif mode == "dense":
+        assert torch.equal(sdb, db)
+
+
+def test_rpe_generator_cache_follows_table_updates():
+    """flash_attention_v2_rpe remembers the (H, 2R+1) generator of a table until the table is modified in place"""
+    from flasht5_amd import flash_attention_v2_rpe
+    q, k, v, _, _ = make_inputs(1, 2, 128, 128, 64, torch.bfloat16, None, seed=3)
+    table = (torch.randn(32, 2, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    o1 = flash_attention_v2_rpe(q, k, v, table)
+    assert torch.equal(flash_attention_v2_rpe(q, k, v, table), o1)
+    with torch.no_grad():
+        table.add_(1.0)[:, 0].mul_(-3.0)     # what an optimizer step does
+    o2 = flash_attention_v2_rpe(q, k, v, table)
+    o2_ref = flash_attention_v2_rpe(q, k, v, table.clone())
+    assert torch.equal(o2, o2_ref) and not torch.equal(o2, o1)
