@@ -705,12 +705,12 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
             const uint16_t* tb = reinterpret_cast<const uint16_t*>(sB + BUF * Cfg::BIASB) + (32 * qbk + 4 * hi) * BNK + 32 * w + lq;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              s[r] = fmaf(s[r], c2, bias_log2(cvt16<BF16>(tb[((r & 3) + 8 * (r >> 2)) * BNK])));
+              s[r] = fmaf(s[r], c2, bias_log2(cvt16<BF16>(bias_clamp1<BF16>(tb[((r & 3) + 8 * (r >> 2)) * BNK]))));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int m = mb + crow(r, hi);
-              const float bvl = (m < M && krow < N) ? cvt16<BF16>(bbase[(int64_t)m * a.bs[2] + krow]) : 0.f;
+              const float bvl = (m < M && krow < N) ? cvt16<BF16>(bias_clamp1<BF16>(bbase[(int64_t)m * a.bs[2] + krow])) : 0.f;
               s[r] = fmaf(s[r], c2, bias_log2(bvl));
             }
           }

@@ -96,7 +96,21 @@ FAT5_DEV uint16_t to16(float a) {
 // dense bias in log2 units.  A bias of finfo(bf16).min (what `use_masking` writes, reference modeling_flash_t5.py:266-270) times
 // log2e overflows fp32; the reference scales (s - m) instead and stays finite, so a fully masked row is a uniform softmax
 // there -- keep the product finite to give the same.
-FAT5_DEV float bias_log2(float b) { return fmaxf(b * kLog2e, -3.0e38f); }
+// The clamp is applied to the PACKED 16-bit words (one v_pk_min_u16 per two values: a bf16 below -1.99e38 = 0xFF16 has a larger
+// unsigned pattern; positive values and every fp16 value -- finfo.min = -65504 -- are unaffected), then one multiply per value.
+typedef __attribute__((ext_vector_type(2))) uint16_t u16x2_t;
+template <bool BF16>
+FAT5_DEV uint32_t bias_clamp2(uint32_t w) {  // two packed bias values
+  if constexpr (BF16) {
+    const u16x2_t lim = {(uint16_t)0xFF16u, (uint16_t)0xFF16u};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, w), lim));
+  } else {
+    return w;
+  }
+}
+template <bool BF16>
+FAT5_DEV uint16_t bias_clamp1(uint16_t h) { return BF16 ? (h < (uint16_t)0xFF16u ? h : (uint16_t)0xFF16u) : h; }
+FAT5_DEV float bias_log2(float b) { return b * kLog2e; }  // (b already clamped in its 16-bit form)
 // backward: a query row with lse below this has every key masked (by the causal rule: -inf; by a finfo.min bias: ~ -2e38);
 // its probabilities are treated as zero (dq = 0 for the row, no contribution to dk / dv / dbias)
 constexpr float kDeadRowLse = -1.0e30f;
@@ -245,11 +259,31 @@ struct AttnArgs {
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
+  int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
   float scale;
 };
 
 // workgroup index -> (batch, head, tile).  The grid covers the call's units x tiles (all B * H units, or a unit range).
 FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h, int& tile) {
+  if (a.batch_inner) {
+    // A batch-broadcast dense bias tile (1, h, m-tile, n-tile) is read by all B batch elements: give the B workgroups of one
+    // (head, tile) consecutive slots of ONE XCD, so the tile crosses the fabric once and is then served by that XCD's L2
+    // (with the per-(b,h) mapping below each batch element sits on another XCD: B x the bias traffic, the dominant stream
+    // of the dense mode).  K/V (or Q/dO) of one (b, h) are then read by several XCDs instead: 1/8 of the bias bytes at most.
+    const int groups = a.H * ntile;
+    int gid;
+    if ((groups & 7) == 0) {
+      const int xcd = bid & 7, idx = bid >> 3;
+      b = idx % a.B;
+      gid = (idx / a.B) * 8 + xcd;
+    } else {
+      b = bid % a.B;
+      gid = bid / a.B;
+    }
+    h = gid / ntile;
+    tile = gid - h * ntile;
+    return;
+  }
   int ui;
   decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile);
   if (a.unit_count > 0) {
@@ -415,7 +449,9 @@ struct BiasTileReader {
   FAT5_DEV void load(const char* tile, int kb, float (&bv)[16]) const {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 w = *reinterpret_cast<const u32x2*>(tile + base[kb] + goff[g]);
+      u32x2 w = *reinterpret_cast<const u32x2*>(tile + base[kb] + goff[g]);
+      w[0] = bias_clamp2<BF16>(w[0]);
+      w[1] = bias_clamp2<BF16>(w[1]);
       bv[4 * g + 0] = cvt_lo<BF16>(w[0]);
       bv[4 * g + 1] = cvt_hi<BF16>(w[0]);
       bv[4 * g + 2] = cvt_lo<BF16>(w[1]);

@@ -55,7 +55,9 @@ FAT5_DEV void load_bias_block(const uint16_t* brow, int nb, int hi, int N, bool 
   if (fast) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 w = *reinterpret_cast<const u32x2*>(brow + nb + 8 * g + 4 * hi);
+      u32x2 w = *reinterpret_cast<const u32x2*>(brow + nb + 8 * g + 4 * hi);
+      w[0] = bias_clamp2<BF16>(w[0]);
+      w[1] = bias_clamp2<BF16>(w[1]);
       bv[4 * g + 0] = cvt_lo<BF16>(w[0]);
       bv[4 * g + 1] = cvt_hi<BF16>(w[0]);
       bv[4 * g + 2] = cvt_lo<BF16>(w[1]);
@@ -65,7 +67,7 @@ FAT5_DEV void load_bias_block(const uint16_t* brow, int nb, int hi, int N, bool 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = nb + crow(r, hi);
-      bv[r] = (n < N) ? cvt16<BF16>(brow[n]) : 0.f;
+      bv[r] = (n < N) ? cvt16<BF16>(bias_clamp1<BF16>(brow[n])) : 0.f;
     }
   }
 }
