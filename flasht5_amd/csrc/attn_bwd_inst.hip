@@ -1,5 +1,6 @@
 // Instantiations of the backward kernels for one head_dim (compile with -DFAT5_INST_D=32|64|128).
 #include "attn_bwd.h"
+#include "attn_bwd_dbias.h"
 #include "attn_launch.h"
 #include <algorithm>
 
@@ -50,6 +51,25 @@ static hipError_t launch_fused(const AttnArgs& a, int grid, hipStream_t s) {
   hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  return hipGetLastError();
+}
+
+// dense bias gradient by in-kernel batch reduction (attn_bwd_dbias.h): grid = H x ceil(M / 128)
+hipError_t CAT(launch_bwd_dbias_d, FAT5_INST_D)(const AttnArgs& a, int bf16, void* dbias, float* scratch, int grid, hipStream_t s) {
+  const size_t smem = BwdDbiasCfg<FAT5_INST_D, 4>::smem();
+  static size_t configured = 0;
+  if (bf16) {
+    auto kern = attn_bwd_dbias_kernel<FAT5_INST_D, true, 4>;
+    hipError_t e = set_smem(kern, smem, configured);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, (uint16_t*)dbias, scratch);
+  } else {
+    static size_t configured16 = 0;
+    auto kern = attn_bwd_dbias_kernel<FAT5_INST_D, false, 4>;
+    hipError_t e = set_smem(kern, smem, configured16);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, (uint16_t*)dbias, scratch);
+  }
   return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ namespace fat5 {
   hipError_t launch_bwd_q_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
   hipError_t launch_bwd_kv_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
   hipError_t launch_bwd_fused_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
+  hipError_t launch_bwd_dbias_d##D(const AttnArgs& a, int bf16, void* dbias, float* scratch, int grid, hipStream_t s); \
   size_t smem_fwd_d##D(int nw, int R, int bias);                                                      \
   size_t smem_bwd_q_d##D(int nw, int R, int bias);                                                    \
   size_t smem_bwd_kv_d##D(int nw, int R, int bias);

@@ -802,3 +802,38 @@ def test_rpe_generator_cache_follows_table_updates():
     o2 = flash_attention_v2_rpe(q, k, v, table)
     o2_ref = flash_attention_v2_rpe(q, k, v, table.clone())
     assert torch.equal(o2, o2_ref) and not torch.equal(o2, o1)
+
+
+@pytest.mark.parametrize("B,H,M,N,D,causal,dtype", [
+    (4, 3, 256, 256, 64, False, torch.bfloat16), (2, 2, 200, 333, 64, False, torch.bfloat16), (3, 2, 300, 300, 64, True, torch.bfloat16),
+    (6, 2, 192, 256, 64, False, torch.bfloat16),   # batch beyond the kernel's 4-element register chunk: fp32 pass-through scratch
+    (9, 1, 130, 70, 32, True, torch.float16), (4, 2, 128, 192, 128, False, torch.bfloat16), (5, 2, 520, 77, 64, True, torch.bfloat16)])
+def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatch):
+    """(1, H, M, N) bias shared by the batch: the bias gradient comes from the batch-inner dBias kernel (attn_bwd_dbias.h) --
+    no (B, H, M, N) staging (workspace O(B*H*M)), each term rounded to the bias dtype before the sum like the reference
+    (flash_attention_v2_bias.py:720, :214).  Against the oracle, and against the staged + reduced path it replaces."""
+    import ctypes
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import _lib
+    q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, "1h", seed=B * M + N)
+    ref = oracle_all(q, k, v, b, do, 0.25, causal)
+    res = {}
+    for mode in ("2", "0"):  # 2: the batch-inner kernel also below its size threshold; 0: the staged path
+        monkeypatch.setenv("FAT5_DBIAS_INKERNEL", mode)
+        plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=0.25)
+        plan.forward()
+        plan.dbias.fill_(float("nan"))
+        dq, dk, dv, db = (t.clone() for t in plan.backward())
+        torch.cuda.synchronize()
+        res[mode] = (dq, dk, dv, db, plan.ws.numel())
+    dq, dk, dv, db, ws = res["2"]
+    assert torch.isfinite(db.float()).all()
+    assert maxdiff(db, ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
+    for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    # workspace: delta (+ the fp32 (H, M, N) pass-through for B > 4), nothing of size B*H*M*N*2
+    assert ws <= B * H * M * 4 + (H * M * N * 4 if B > 4 else 0) + 4096
+    assert res["0"][4] >= B * H * M * N * 2
+    # same terms, same rounding, same order as the staged path: equal up to one rounding of the sum
+    assert maxdiff(db, res["0"][3]) <= 2.0 ** -7 * max(1.0, ref["db"].abs().max().item())
+    assert torch.equal(dq, res["0"][0]) and torch.equal(dk, res["0"][1]) and torch.equal(dv, res["0"][2])
