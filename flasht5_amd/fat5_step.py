@@ -50,6 +50,7 @@ class FAT5Config:
     decoder_start_token_id: int = 0
     pad_token_id: int = 0
     crossentropy_inplace_backward: bool = True
+    fuse_lm_head_ce: bool = False          # lm_head + loss in row chunks: the (B*T, vocab) logits are never materialised
     is_decoder: bool = False
 
 
@@ -190,6 +191,11 @@ class FAT5ForConditionalGeneration(nn.Module):  # :604-736 (training forward onl
     def forward(self, input_ids, labels):
         enc = self.encoder(input_ids)
         dec = self.decoder(self._shift_right(labels), encoder_hidden_states=enc)
+        if self.config.fuse_lm_head_ce:
+            from .lm_head_cross_entropy import lm_head_cross_entropy
+            c = self.config
+            return lm_head_cross_entropy(dec, self.lm_head.weight, labels, label_smoothing=c.label_smoothing,
+                                         lse_square_scale=c.z_loss)[0].mean()
         return self.loss_fct(self.lm_head(dec), labels)
 
 

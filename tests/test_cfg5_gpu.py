@@ -110,3 +110,28 @@ def test_cfg5_train_step_updates_and_repeats():
     assert runs[0][0][0] == runs[1][0][0]
     assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(runs[0][0], runs[1][0])), runs
     assert runs[0][0][2] < runs[0][0][0]
+
+
+def test_cfg5_fused_lm_head_ce_matches_unfused():
+    """the step with lm_head + loss fused in row chunks (the (B*T, vocab) logits never exist): same loss to the
+    last bit (same GEMM rows, same kernels), same gradients up to the fp32 accumulation order of d lm_head.weight"""
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
+    import copy
+    cfg = FAT5Config(num_layers=2, num_decoder_layers=2)
+    torch.manual_seed(9)
+    m0 = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+    m1 = copy.deepcopy(m0)
+    m1.config = copy.copy(cfg)
+    m1.config.fuse_lm_head_ce = True
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, cfg.vocab_size, (2, 1024), generator=g).cuda()
+    labels = torch.randint(0, cfg.vocab_size, (2, 512), generator=g)
+    labels[0, -9:] = -100
+    labels = labels.cuda()
+    l0, l1 = m0(ids, labels), m1(ids, labels)
+    assert l0.item() == l1.item()
+    l0.backward()
+    l1.backward()
+    for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        tol = 2.0 ** -7 * max(p0.grad.float().abs().max().item(), 1e-6)
+        assert maxdiff(p1.grad, p0.grad) <= tol, (n, maxdiff(p1.grad, p0.grad), tol)

@@ -181,3 +181,40 @@ def test_module_mirrors_match_the_reference_modules_eager_branches():
     (rgl,) = torch.autograd.grad(ref, lf)
     assert abs(loss.item() - ref.item()) <= 2e-3 * max(1.0, abs(ref.item()))
     assert (gl.float() - rgl).abs().max() <= 1e-2 * max(1e-3, rgl.abs().max().item()) + 1e-6
+
+
+@pytest.mark.parametrize("rows,d,V,dtype,chunk", [(1000, 256, 4096, torch.bfloat16, 256), (777, 128, 32128, torch.bfloat16, 300),
+                                                  (512, 64, 1000, torch.float32, 128), (8192, 768, 32768, torch.bfloat16, None)])
+def test_lm_head_cross_entropy_chunked(rows, d, V, dtype, chunk):
+    """lm_head GEMM + cross-entropy (+ smoothing, z-loss) in row chunks -- the (rows, V) logits are never
+    materialised -- equals the unfused `cross_entropy_loss(hidden @ W^T)` (same kernels, same GEMM inputs): losses, z-losses,
+    d hidden, d weight; peak memory stays below one full logits tensor."""
+    from flasht5_amd import cross_entropy_loss, lm_head_cross_entropy
+    g = torch.Generator().manual_seed(rows + V)
+    h = (torch.randn(rows, d, generator=g) * 0.5).to(dtype).cuda().requires_grad_()
+    w = (torch.randn(V, d, generator=g) * d ** -0.5).to(dtype).cuda().requires_grad_()
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::17] = -100
+    labels = labels.cuda()
+    dl = torch.randn(rows, generator=g).cuda()
+    kw = dict(label_smoothing=0.1, lse_square_scale=1e-4)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base0 = torch.cuda.memory_allocated()
+    l0, z0 = cross_entropy_loss(h @ w.t(), labels, inplace_backward=True, **kw)  # the reference's leanest form (:247)
+    gh0, gw0 = torch.autograd.grad(l0, (h, w), dl)
+    torch.cuda.synchronize()
+    peak0 = torch.cuda.max_memory_allocated() - base0
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    l1, z1 = lm_head_cross_entropy(h, w, labels, chunk_rows=chunk, **kw)
+    gh1, gw1 = torch.autograd.grad(l1, (h, w), dl)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert torch.equal(l1, l0) and torch.equal(z1, z0)              # same GEMM rows -> same logits -> same kernel results
+    assert md(gh1, gh0) <= 1e-6 + 2.0 ** -8 * gh0.float().abs().max().item() * (dtype != torch.float32)
+    # d weight: chunk partial products accumulate in fp32 (the unfused GEMM accumulates the whole K = rows in one pass)
+    assert md(gw1, gw0) <= (2.0 ** -7 if dtype != torch.float32 else 1e-5) * max(1.0, gw0.float().abs().max().item())
+    assert not z1.requires_grad
+    if chunk is None:  # FAT5-base head, 8 x 1024 target tokens: 537 MB of logits never exist; what remains is weight-sized
+        assert peak <= peak0 - 0.5 * rows * V * h.element_size(), (peak, peak0)  # (the fp32 dW accumulator + one 64 MB chunk)
