@@ -136,6 +136,32 @@ def rowwise_bench(device):
                                  "bwd_us": round(tb * 1e6, 2), "bwd_GBs": round(bb / tb / 1e9, 1), "bwd_frac": round(bb / tb / 1e9 / PEAK_HBM_GBS, 3)}
         del lg, dst
     out["bytes_model"] = "rmsnorm fwd 2RNe, bwd 3RNe; ce fwd RVe, bwd 2RVe (e = 2); label smoothing 0.1, z-loss 1e-4"
+    # fused AdamWScale step over a FAT5-base sized parameter set (bf16 parameters + Kahan compensation): two launches
+    from flasht5_amd import AdamWScale
+    shapes = [(32768, 768)] * 2 + [(768, 768)] * (4 * 36) + [(2048, 768)] * (3 * 24) + [(768,)] * 62 + [(32, 12)] * 2
+    params = [torch.nn.Parameter((torch.randn(*sh, device=device) * 0.02).bfloat16()) for sh in shapes]
+    for p_ in params:
+        p_.grad = (torch.randn_like(p_) * 0.01)
+    opt = AdamWScale(params, lr=1e-3, weight_decay=0.01, kahan_sum=True)
+    for _ in range(3):
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_.record()
+    for _ in range(5):
+        opt.step()
+    e_.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 5
+    n_el = sum(p_.numel() for p_ in params)
+    byt = n_el * 2 * 10  # sumsq pass reads p; update reads p, g, m, v, k and writes p, m, v, k
+    dev_s = s_.elapsed_time(e_) / 5 * 1e-3
+    out["adamw_scale_fat5_base"] = {"params_M": round(n_el / 1e6, 1), "tensors": len(params), "ms_per_step_wall": round(wall * 1e3, 3),
+                                    "ms_per_step_device": round(dev_s * 1e3, 3), "GBs": round(byt / dev_s / 1e9, 1),
+                                    "frac": round(byt / dev_s / 1e9 / PEAK_HBM_GBS, 3),
+                                    "bytes_model": "10 x 2 B per element (bf16 + Kahan): p twice, g, m, v, k read; p, m, v, k written"}
+    del params, opt
     return out
 
 

@@ -48,6 +48,7 @@ EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_ce_fwd", "fat5_ce_bwd",
+    "fat5_adamw_scale_step", "fat5_sizeof_adamw_tensor",
 )
 
 _lib = None
@@ -86,6 +87,10 @@ def load():
     lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
     lib.fat5_ce_bwd.restype = ctypes.c_int
     lib.fat5_ce_bwd.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, f32, f32, i64, i32, vp]
+    lib.fat5_adamw_scale_step.restype = ctypes.c_int
+    f64 = ctypes.c_double
+    lib.fat5_adamw_scale_step.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, vp]
+    lib.fat5_sizeof_adamw_tensor.restype = ctypes.c_size_t
     lib.fat5_sizeof_attn_params.restype = ctypes.c_size_t
     if lib.fat5_sizeof_attn_params() != ctypes.sizeof(AttnParams):
         raise ImportError(f"fat5_attn_params layout mismatch: library {lib.fat5_sizeof_attn_params()} B, "

@@ -1,0 +1,114 @@
+"""`AdamWScale` on MI355X: the reference optimizer (src/utils/adamw_scaled.py:10-281 -- AdamW whose step is scaled by
+max(1e-3, rms(p)), optional Kahan-compensated updates for 16-bit parameters, decoupled weight decay) with the same constructor
+and state (`step`, `exp_avg`, `exp_avg_sq`, `kahan_comp`: reference checkpoints of the optimizer load), its whole step fused into
+two HIP launches per (device, dtype) group of parameters through the C ABI (`fat5_adamw_scale_step`, csrc/adamw_kernels.h)
+instead of ~14 elementwise launches per tensor.  Arithmetic and intermediate roundings follow the reference's per-tensor path
+op by op (oracle/adamw_scale.py is its CPU restatement, pinned against the reference class)."""
+import ctypes
+import math
+from typing import Iterable, Tuple
+
+import torch
+from torch import nn
+from torch.optim import Optimizer
+
+from . import _lib
+
+__all__ = ["AdamWScale"]
+
+CHUNK = 8192  # elements per workgroup (csrc/adamw_kernels.h kAdamChunk)
+
+
+class _Desc(ctypes.Structure):
+    """mirror of `fat5_adamw_tensor` (include/fat5.h)"""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("k", ctypes.c_void_p),
+                ("numel", ctypes.c_int64), ("chunk_begin", ctypes.c_int32), ("step_prefactor", ctypes.c_float)]
+
+
+class AdamWScale(Optimizer):
+    """Same arguments as the reference class (:40-66).  `foreach` is accepted and ignored (the fused step replaces both of the
+    reference's paths); `use_state_dtype` other than None is not supported by the fused kernels."""
+
+    def __init__(self, params: Iterable[nn.parameter.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-6, weight_decay: float = 0.0, kahan_sum: bool = False, foreach: bool = False,
+                 correct_bias: bool = True, use_state_dtype: torch.dtype = None):
+        if lr < 0.0:
+            raise ValueError(f"Invalid learning rate: {lr} - should be >= 0.0")
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError(f"Invalid beta parameter: {betas[0]} - should be in [0.0, 1.0)")
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid beta parameter: {betas[1]} - should be in [0.0, 1.0)")
+        if not 0.0 <= eps:
+            raise ValueError(f"Invalid epsilon value: {eps} - should be >= 0.0")
+        if use_state_dtype is not None:
+            raise NotImplementedError("use_state_dtype: the fused step keeps m, v in the parameter dtype (the reference's default)")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=foreach, kahan_sum=kahan_sum,
+                        correct_bias=correct_bias, use_state_dtype=use_state_dtype)
+        super().__init__(params, defaults)
+        if ctypes.sizeof(_Desc) != _lib.load().fat5_sizeof_adamw_tensor():
+            raise ImportError("fat5_adamw_tensor layout mismatch between libfat5.so and its binding")
+
+    @staticmethod
+    def _prefactor(lr, beta1, beta2, step, correct_bias):
+        """lr [* sqrt(1 - beta2^t) / (1 - beta1^t)] with the reference's types (:177-181): `step` is an int32 tensor there, so the
+        bias corrections are float32 tensors and the product is float32"""
+        if not correct_bias:
+            return float(lr)
+        st = torch.as_tensor(step, dtype=torch.int32)
+        bc1 = 1.0 - beta1 ** st
+        bc2 = 1.0 - beta2 ** st
+        return float(lr * math.sqrt(bc2) / bc1)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            buckets = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("AdamWScale does not support sparse gradients")
+                if not p.is_cuda:
+                    raise RuntimeError("flasht5_amd.AdamWScale needs parameters on the HIP device (no CPU fallback)")
+                state = self.state[p]
+                if "kahan_comp" not in state:  # reference :96-113
+                    state["step"] = torch.tensor(0, dtype=torch.int32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    kah = group["kahan_sum"] and p.dtype in (torch.float16, torch.bfloat16)
+                    state["kahan_comp"] = torch.zeros_like(p, memory_format=torch.preserve_format) if kah else None
+                state["step"] += 1
+                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("AdamWScale: parameters and gradients must be contiguous")
+                g = p.grad if p.grad.dtype == p.dtype else p.grad.to(p.dtype)
+                buckets.setdefault((p.device, p.dtype, state["kahan_comp"] is not None), []).append((p, g, state))
+            for (device, dtype, kahan), items in buckets.items():
+                table = (_Desc * (len(items) + 1))()
+                chunk = 0
+                keep = []
+                for i, (p, g, state) in enumerate(items):
+                    d = table[i]
+                    d.p, d.g, d.m, d.v = p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr()
+                    d.k = state["kahan_comp"].data_ptr() if kahan else None
+                    d.numel, d.chunk_begin = p.numel(), chunk
+                    d.step_prefactor = self._prefactor(group["lr"], beta1, beta2, int(state["step"]), group["correct_bias"])
+                    chunk += (p.numel() + CHUNK - 1) // CHUNK
+                    keep.append(g)
+                table[len(items)].chunk_begin = chunk
+                if chunk == 0:
+                    continue
+                raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
+                partials = torch.empty(chunk, dtype=torch.float32, device=device)
+                with _lib.on_device(device):
+                    _lib.check(lib.fat5_adamw_scale_step(raw.data_ptr(), len(items), chunk, partials.data_ptr(), float(group["lr"]),
+                                                         float(beta1), float(beta2), float(group["weight_decay"]), float(group["eps"]),
+                                                         _lib.dtype_code(dtype), int(kahan), _lib.stream_ptr(device)),
+                               "fat5_adamw_scale_step")
+                del keep
+        return loss

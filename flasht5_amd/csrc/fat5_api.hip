@@ -11,6 +11,7 @@
 #include "attn_launch.h"
 #include "reduce_kernels.h"
 #include "rowwise_kernels.h"
+#include "adamw_kernels.h"
 
 using namespace fat5;
 
@@ -528,6 +529,39 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
   })
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "ce_bwd launch");
+  return FAT5_OK;
+}
+
+// ============================================================================================
+// AdamWScale
+// ============================================================================================
+size_t fat5_sizeof_adamw_tensor(void) { return sizeof(fat5_adamw_tensor); }
+
+int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr_, double beta1_,
+                          double beta2_, double weight_decay_, double eps_, int dtype, int kahan, void* stream_) {
+  // scalars reach the kernels as the fp32 "opmath" values the reference's ops see: each Python double is cast once
+  const float beta1 = (float)beta1_, beta2 = (float)beta2_, eps = (float)eps_;
+  const float a1 = (float)(1.0 - beta1_), a2 = (float)(1.0 - beta2_), wdf = (float)(-lr_ * weight_decay_);
+  if (!table || !partials) return fail(FAT5_EINVAL, "adamw: null table / partials");
+  if (n_tensors <= 0 || n_chunks <= 0) return fail(FAT5_EINVAL, "adamw: empty group");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "adamw: bad dtype");
+  if (kahan && dtype == FAT5_F32) return fail(FAT5_EINVAL, "adamw: Kahan compensation is for 16-bit parameters (reference :107-113)");
+  hipStream_t stream = (hipStream_t)stream_;
+  dispatch_dtype(dtype, [&](auto dt_) {
+    constexpr int DT = decltype(dt_)::value;
+    hipLaunchKernelGGL((adamw_sumsq_kernel<DT>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials);
+    if constexpr (DT != FAT5_F32) {
+      if (kahan) {
+        hipLaunchKernelGGL((adamw_update_kernel<DT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2,
+                           a1, a2, wdf, eps);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((adamw_update_kernel<DT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2, a1,
+                       a2, wdf, eps);
+  });
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "adamw launch");
   return FAT5_OK;
 }
 

@@ -171,6 +171,32 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
                 int64_t row_stride, int64_t dlogits_row_stride, float smoothing, float logit_scale,
                 float lse_square_scale, int64_t ignore_index, int dtype, void* hip_stream);
 
+/*
+ * AdamWScale step over a group of tensors.  Replaces the reference optimizer's per-tensor / foreach op
+ * sequences (src/utils/adamw_scaled.py:154-211, :213-281) with two launches for the whole group.
+ *   m = beta1 m + (1-beta1) g;  v = beta2 v + (1-beta2) g^2;  denom = sqrt(v) + eps
+ *   step = step_prefactor * max(1e-3, rms(p));     step_prefactor = lr [* sqrt(1-beta2^t) / (1-beta1^t)], computed by the caller
+ *   p -= step * m / denom   (with `kahan`: through the compensation tensor k, :188-198);   p += -lr * weight_decay * p
+ * Intermediate roundings are the reference's (every in-place op rounds to the tensor dtype; fp32 math inside an op).
+ * All tensors of one call share `dtype` (parameters, gradients, m, v, k alike, as in the reference's default state dtype);
+ * `table` is a DEVICE array of n_tensors descriptors (+ one terminator whose chunk_begin is the total chunk count);
+ * chunk_begin[i] = sum over j < i of ceil(numel[j] / 8192);  `partials` = device scratch of total-chunks floats.
+ */
+typedef struct fat5_adamw_tensor {
+  void* p;              /* parameters, updated in place */
+  const void* g;        /* gradients */
+  void* m;              /* exp_avg */
+  void* v;              /* exp_avg_sq */
+  void* k;              /* Kahan compensation (kahan != 0), else NULL */
+  int64_t numel;
+  int32_t chunk_begin;
+  float step_prefactor;
+} fat5_adamw_tensor;
+/* hyper-parameters as doubles: the reference passes Python floats, and e.g. (1 - beta2) is formed in double before the op casts it */
+int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
+                          double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan, void* hip_stream);
+size_t fat5_sizeof_adamw_tensor(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,3 +9,4 @@ from .rpe import (relative_position_bucket, compute_bias, bias1d_from_table,
                   table_grad_from_dbias1d, toeplitz_from_bias1d)
 from .rmsnorm import rmsnorm_fwd_oracle, rmsnorm_bwd_oracle, rmsnorm_eager
 from .cross_entropy import ce_fwd_oracle, ce_bwd_oracle
+from .adamw_scale import adamw_scale_step

@@ -345,6 +345,53 @@ def gen_ce():
     save("cross_entropy", **out)
 
 
+# ----------------------------------------------------------------------------------------------
+# 6. AdamWScale optimizer step: the reference class on CPU vs the oracle restatement
+# ----------------------------------------------------------------------------------------------
+def gen_adamw():
+    from src.utils.adamw_scaled import AdamWScale
+    out = {}
+    cases = [("fp32", torch.float32, False, 0.0), ("fp32_wd", torch.float32, False, 0.03), ("bf16", torch.bfloat16, False, 0.0),
+             ("bf16_kahan_wd", torch.bfloat16, True, 0.03), ("fp16_kahan", torch.float16, True, 0.0)]
+    for name, dtype, kahan, wd in cases:
+        g = torch.Generator().manual_seed(len(name) * 7 + 1)
+        shapes = [(257, 33), (64,), (1, 12), (1000, 8)]
+        p0 = [(torch.randn(*s, generator=g) * (0.02 if i != 2 else 1e-5)).to(dtype) for i, s in enumerate(shapes)]  # tensor 2: rms below the 1e-3 floor
+        grads = [[(torch.randn(*s, generator=g) * 0.1).to(dtype) for s in shapes] for _ in range(3)]
+        # the reference
+        rp = [torch.nn.Parameter(t.clone()) for t in p0]
+        opt = AdamWScale(rp, lr=0.01, betas=(0.9, 0.999), eps=1e-6, weight_decay=wd, kahan_sum=kahan, foreach=False)
+        for step in range(3):
+            for t, gr in zip(rp, grads[step]):
+                t.grad = gr.clone()
+            opt.step()
+        # the oracle
+        mp = [t.clone() for t in p0]
+        m = [torch.zeros_like(t) for t in p0]
+        v = [torch.zeros_like(t) for t in p0]
+        use_k = kahan and dtype in (torch.float16, torch.bfloat16)
+        kc = [torch.zeros_like(t) if use_k else None for t in p0]
+        for step in range(3):
+            for i in range(len(mp)):
+                oracle.adamw_scale_step(mp[i], grads[step][i].clone(), m[i], v[i], kc[i], step + 1, 0.01, 0.9, 0.999, wd, 1e-6, True)
+        for i in range(len(mp)):
+            st = opt.state[rp[i]]
+            assert torch.equal(mp[i], rp[i].detach()), (name, i, "p")
+            assert torch.equal(m[i], st["exp_avg"]) and torch.equal(v[i], st["exp_avg_sq"]), (name, i, "state")
+            if use_k:
+                assert torch.equal(kc[i], st["kahan_comp"]), (name, i, "kahan")
+            out[f"{name}__p0_{i}"] = npy(p0[i])
+            out[f"{name}__p_{i}"] = npy(mp[i])
+            out[f"{name}__m_{i}"] = npy(m[i])
+            out[f"{name}__v_{i}"] = npy(v[i])
+            if use_k:
+                out[f"{name}__k_{i}"] = npy(kc[i])
+            for step in range(3):
+                out[f"{name}__g{step}_{i}"] = npy(grads[step][i])
+        out[f"{name}__cfg"] = np.array([{torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype], int(kahan), wd, 0.01, 0.9, 0.999, 1e-6])
+    save("adamw_scale", **out)
+
+
 def main():
     torch.set_num_threads(8)
     gen_rpe()
@@ -368,6 +415,7 @@ def main():
     gen_triton_case("triton_t100_nc_1h_fp16", 23, 1, 2, 96, 100, 64, "1h", False, 0.5)
     gen_rmsnorm()
     gen_ce()
+    gen_adamw()
 
 
 if __name__ == "__main__":
