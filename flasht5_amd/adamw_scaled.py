@@ -69,6 +69,8 @@ class AdamWScale(Optimizer):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             buckets = {}
+            steps = []
+            pre_cache = {}  # step count -> prefactor (all tensors of a group normally share one step count)
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -83,11 +85,13 @@ class AdamWScale(Optimizer):
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     kah = group["kahan_sum"] and p.dtype in (torch.float16, torch.bfloat16)
                     state["kahan_comp"] = torch.zeros_like(p, memory_format=torch.preserve_format) if kah else None
-                state["step"] += 1
+                steps.append(state["step"])
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("AdamWScale: parameters and gradients must be contiguous")
                 g = p.grad if p.grad.dtype == p.dtype else p.grad.to(p.dtype)
                 buckets.setdefault((p.device, p.dtype, state["kahan_comp"] is not None), []).append((p, g, state))
+            if steps:
+                torch._foreach_add_(steps, 1)  # reference :120
             for (device, dtype, kahan), items in buckets.items():
                 table = (_Desc * (len(items) + 1))()
                 chunk = 0
@@ -97,7 +101,10 @@ class AdamWScale(Optimizer):
                     d.p, d.g, d.m, d.v = p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr()
                     d.k = state["kahan_comp"].data_ptr() if kahan else None
                     d.numel, d.chunk_begin = p.numel(), chunk
-                    d.step_prefactor = self._prefactor(group["lr"], beta1, beta2, int(state["step"]), group["correct_bias"])
+                    st = int(state["step"])
+                    if st not in pre_cache:
+                        pre_cache[st] = self._prefactor(group["lr"], beta1, beta2, st, group["correct_bias"])
+                    d.step_prefactor = pre_cache[st]
                     chunk += (p.numel() + CHUNK - 1) // CHUNK
                     keep.append(g)
                 table[len(items)].chunk_begin = chunk
