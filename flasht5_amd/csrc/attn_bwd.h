@@ -125,6 +125,14 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   // rows without a visible key (lse = -inf) and rows whose every key is masked by a finfo.min bias (lse ~ -2e38: the
   // reference's `use_masking`; p = exp(s - L) has no digits left there, in the reference kernels neither) contribute nothing
   const float nL2 = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;
+  if (a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
+    // accumulator initial values of the 64-key dK/dV body (attn_bwd64.h): S' = Q K^T - L/scale, dP' = dO V^T - delta; rows that
+    // contribute nothing (past M, dead) start at -inf * sign(scale) -> p = 0
+    float* st = a.stat2 + (((int64_t)b * a.H + h) * ((M + 31) / 32) + (qrow >> 5)) * 64 + (qrow & 31);
+    const bool live = qrow < M && !(Lq < kDeadRowLse);
+    st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
+    st[32] = qrow < M ? -delta : 0.f;
+  }
 
   const float* sTa = sT;  // this lane's aligned copy of the table
   if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);

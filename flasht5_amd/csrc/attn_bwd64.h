@@ -1,0 +1,712 @@
+// FlashAttention-2 backward, dK / dV / bias-table-gradient body for long sequences on gfx950: 64 keys per wave,
+// software-pipelined query-step loop.
+//
+// Same contract as attn_bwd_kv_kernel (attn_bwd.h; replaces the reference Triton `_bwd_kv_kernel`,
+// src/model/ops/flash_attention_v2_bias.py:559-745) for bias = none / in-kernel T5 RPE, bf16, D = 64.  What is different, and why:
+//
+//  * LDS bandwidth.  In the 32-keys-per-wave body every wave reads the whole Q and dO tile twice (row-major for S / dP,
+//    transposed for dK / dV): 1 KiB of LDS per MFMA, exactly the CU's 128 B/clk at 100 % MFMA issue -- measured 42 % MFMA
+//    utilisation with the waves parked on LDS 44 % of the time.  Here a wave owns TWO 32-key blocks: every fragment read feeds
+//    two MFMAs (512 B per MFMA), and consecutive MFMAs always target different accumulators (see attn_fwd64.h).
+//  * Registers: dK^T / dV^T of 64 keys (128) + K / V operand fragments (64) + scores -> one wave per SIMD (512 registers),
+//    so nothing hides latency but the instruction stream itself: three-stage software pipeline over 32-row query steps i.
+//    While the VALU pipe turns S', dP' of step i into P and dS (one FMA, v_exp_f32, one multiply per element, packed to bf16),
+//    the matrix pipe runs dV^T += dO^T P, dK^T += Q^T dS of step i-1 and S' = Q K^T - L/scale, dP' = dO V^T - delta of step i+1:
+//    32 MFMAs per step, one element of VALU work, about one LDS read in every MFMA gap.
+//  * Q / dO steps and their row statistics travel global -> LDS by DMA into a 4-slot ring three steps ahead; one barrier
+//    per step.  The statistics (-L/scale and -delta, the MFMA accumulators' INITIAL values) come in exactly that form from the
+//    dQ kernel (AttnArgs::stat2).
+//  * All-visible constant-bias steps (everything outside the RPE band / the causal diagonal / a key tail) run the pipelined
+//    iteration; the others run the same pipeline stages one after the other with the general softmax (table lookups, masks,
+//    per-diagonal sums through the skew tile of attn_bwd.h).
+#pragma once
+#include "attn_common.h"
+#include "attn_fwd64.h"  // static_for, integer-address LDS reads, asm LDS-DMA, pinned VALU ops
+
+namespace fat5 {
+
+template <int D>
+struct Bwd64Cfg {
+  static constexpr int NW = 4, BNK = 64 * NW, QT = 32, NT = 64 * NW, NS = 4;
+  static constexpr int IMG = rm_bytes<D, QT>();  // one 32-row image (Q or dO)
+  static constexpr int STATB = NW * 1024;        // one private 1 KiB DMA piece of row statistics per wave (256 B used)
+  static constexpr int SLOT = 2 * IMG + STATB;
+  static constexpr int RING = NS * SLOT;
+  static constexpr int SKEW_ROW = 160, SKEW = 32 * SKEW_ROW;  // (see BwdKVCfg)
+  // rpe: four aligned table copies + one private diagonal accumulator per (wave, key block) + one skew tile per wave
+  static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * 2 * NW + 63) / 64 * 64; }
+  static size_t smem(int R, int bias_mode) { return RING + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0); }
+};
+
+FAT5_DEV float asm_mul(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// acc += w.lo * o.lo + w.hi * o.hi  (two bf16 lanes of a packed word)
+FAT5_DEV void asm_dot2c_bf16(float& acc, uint32_t w, uint32_t o) { asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o)); }
+// acc += A . B with the accumulator tuple in AGPRs.  The dK^T / dV^T accumulators (128 registers) are touched by nothing but
+// MFMAs: hipcc's VGPR-form MFMA selection would keep them in VGPRs and spill everything else through v_accvgpr moves.
+// No hazard padding is generated for asm: same-accumulator MFMAs need none, A / B come from LDS reads (waitcnt is inserted
+// for asm operands) or from VALU results that are many instructions old; the epilogue pads before it reads the tuples.
+FAT5_DEV void mfma_acc_agpr(f32x16& acc, const u32x4 A, const u32x4 B) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+FAT5_DEV f32x2 asm_pk_mul(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+FAT5_DEV f32x2 asm_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 r;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
+  typedef s16x4_t __attribute__((address_space(3))) * p_t;
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)addr));
+}
+
+#ifndef FAT5_B64_PIN
+#define FAT5_B64_PIN 1
+#endif
+#ifndef FAT5_B64_PK
+#define FAT5_B64_PK 0  // 0: one v_fma / v_mul per element; 1: v_pk_mul_f32 per element pair; 2: v_pk_fma_f32 too
+#endif
+#ifndef FAT5_B64_NLC
+#define FAT5_B64_NLC 0  // 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter as a separate C operand
+#endif
+#ifndef FAT5_B64_X
+#define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
+#endif
+
+template <int D, bool BF16, int BIAS>
+FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
+  static_assert(D == 64 && BF16 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bf16, bias none / rpe1d");
+  using Cfg = Bwd64Cfg<D>;
+  constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
+  constexpr int KK = D / 16, DB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
+  int b, h, nblk;
+  decode_unit(a, bid, a.n_nblk, b, h, nblk);
+  const int bh = b * a.H + h;
+  const int M = a.M, N = a.N;
+  const int n0 = nblk * BNK;
+  const uint16_t* qb = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
+  const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
+  const uint16_t* vb = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
+  const uint16_t* dob = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1];
+  uint16_t* dkb = a.dk + (int64_t)b * a.dks[0] + (int64_t)h * a.dks[1];
+  uint16_t* dvb = a.dv + (int64_t)b * a.dvs[0] + (int64_t)h * a.dvs[1];
+  const int P = N - M;
+  const int kw0 = n0 + 64 * w;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
+
+  // K and V fragments (B operands) of this lane's two keys
+  u32x4 kf[2][KK], vf[2][KK];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int kr = min(kw0 + 32 * kb + lq, N - 1);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      kf[kb][kk] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)kr * a.ks[2] + 16 * kk + 8 * hi);
+      vf[kb][kk] = *reinterpret_cast<const u32x4*>(vb + (int64_t)kr * a.vs[2] + 16 * kk + 8 * hi);
+    }
+  }
+
+  // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators, skew tile) ----
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RING);
+  const int n1 = 2 * a.R + 1;
+  float* sD0 = sT + 4 * rpe_n1p(a.R);
+  char* sG = smem + Cfg::RING + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
+  const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
+  int sk_r[2];
+  {
+    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g4 = l >> 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sk_r[u] = (8 * g4 + 4 * u + e) * Cfg::SKEW_ROW + 8 * c;
+  }
+  const uint32_t one2s = pack2<BF16>(1.f, 1.f);
+  const u32x4 ones = {one2s, one2s, one2s, one2s};
+  float carry[2] = {0.f, 0.f};
+  int carry_d0[2] = {0, 0};
+  bool carry_valid[2] = {false, false};
+  float far_neg = 0.f, far_pos = 0.f;
+  const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
+  auto emit_diag = [&](int kb, float v, int d) {
+    if (hi == 0) {
+      if (d <= -a.R) far_neg += v;
+      else if (d >= a.R) far_pos += v;
+      else sD0[(2 * w + kb) * n1 + d + a.R] = v;  // every near diagonal of a (wave, key block) is finished exactly once
+    }
+  };
+  auto flush_carry = [&](int kb) {
+    if (carry_valid[kb]) {
+      emit_diag(kb, carry[kb], carry_d0[kb] + lq);
+      carry_valid[kb] = false;
+      carry[kb] = 0.f;
+    }
+  };
+  auto tree16 = [](const f32x16& x) {
+    const float t0 = (x[0] + x[1]) + (x[2] + x[3]), t1 = (x[4] + x[5]) + (x[6] + x[7]);
+    const float t2 = (x[8] + x[9]) + (x[10] + x[11]), t3 = (x[12] + x[13]) + (x[14] + x[15]);
+    return (t0 + t1) + (t2 + t3);
+  };
+
+  f32x16 dk[2][DB], dv[2][DB];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[kb][i][r] = 0.f; dv[kb][i][r] = 0.f; }
+
+  // query-step range: causal => only rows with q + P >= n0 see this key block
+  int m_lo = 0;
+  if (a.causal) m_lo = max(0, n0 - P) / 32 * 32;
+  const int mt0 = m_lo / 32;
+  const int nst_all = (M + 31) / 32;
+  const int nsteps = nst_all - mt0;
+
+  // ---- ring: step j (query rows 32*(mt0+j) ..+31) lives in slot j % 4: [Q image | dO image | 4 private statistics pieces] ----
+  using Dma = DmaStage<D, Cfg::QT, NT>;
+  static_assert(Dma::PER == 1 && Dma::NV == 1, "one 16-byte piece per thread and image");
+  Dma qst, dost;
+  qst.init(a.qs[2], tid);
+  dost.init(a.dos[2], tid);
+  const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
+  const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
+  // statistics: 64 floats per step ([32] -L/scale, [32] -delta), whole steps (the dQ kernel pads the last one)
+  const __amdgpu_buffer_rsrc_t strs =
+      make_rows_rsrc(reinterpret_cast<const uint16_t*>(a.stat2 + (int64_t)bh * nst_all * 64), 128, nst_all, 128);
+  const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
+  const uint32_t svoff = (uint32_t)(l & 15) * 16u;  // (lanes 16.. re-read the same 256 bytes: no out-of-range reliance)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
+  auto dma_step = [&](int j, uint32_t slot_off) {
+    const uint32_t mt = (uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j);
+    dma16_asm(qrs, wave_lds + slot_off, qst.voff[0], mt * 32u * qstride_b);
+    dma16_asm(dors, wave_lds + slot_off + (uint32_t)IMG, dost.voff[0], mt * 32u * dostride_b);
+    dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
+  };
+  // E(j): step j+1 has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
+  auto sync_step = [&](int j, uint32_t slot3_off) {
+    if (j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else wait_dma_all();
+    __syncthreads();
+    if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
+  };
+
+  if (nsteps > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < nsteps) dma_step(i, (uint32_t)(i * SLOT));
+  }
+  // slot 3 is read (against an all-zero P / dS) before anything lands in it: finite contents
+  for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
+    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  wait_dma_all();
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+a"(kf[kb][kk]), "+a"(vf[kb][kk]));  // MFMA-only operands: AGPRs
+
+  // per-lane LDS addresses (ring base folded in; slot / image / step offsets are immediates)
+  FragAddr<D> fa;
+  fa.init(l);
+  uint32_t rmA[KK], trA[2][DB], stA;
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    rmA[kk] = lds0 + (uint32_t)fa.rm[kk];
+    asm volatile("" : "+v"(rmA[kk]));
+  }
+#pragma unroll
+  for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      trA[j2][db] = lds0 + (uint32_t)fa.tr[j2][db];
+      asm volatile("" : "+v"(trA[j2][db]));
+    }
+  stA = lds0 + (uint32_t)(2 * IMG + w * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +128+32g (-delta)
+  asm volatile("" : "+v"(stA));
+  auto rd_f4 = [&](uint32_t addr) { return __builtin_bit_cast(f32x4, lds_rd128(addr)); };
+  auto put4 = [](f32x16& x, int g, const f32x4 v) { x[4 * g] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3]; };
+  auto rd_tr = [&](uint32_t off, int t2, int db) {
+    const uint32_t o = off + (uint32_t)(16 * t2 * 2 * D);
+    return lds_rd_tr(trA[0][db] + o, trA[1][db] + o);
+  };
+
+  const float c2 = a.scale * kLog2e;
+  float cst_neg = 0.f, cst_pos = 0.f;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    cst_neg = sT[0];
+    cst_pos = sT[2 * a.R];
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // Pipeline state between two iterations (iteration i = query step i is in its softmax stage):
+  //   S, DP      S' = Q K^T - L/scale and dP' = dO V^T - delta of step i (lane = key, register r <-> row crow(r, hi))
+  //   PB, DS     P and dS of step i-1, rounded to bf16 like the reference (:702 / :720), as B operands
+  //   TRD, TRQ   first transposed fragments (t2 = 0, db = 0) of step i-1's dO and Q images
+  // ------------------------------------------------------------------------------------------------------------------
+  f32x16 S[2], DP[2];
+  u32x4 PB[2][2], DS[2][2], TRD, TRQ;
+  float facc = 0.f;  // sum of the dS of a pipelined range (one far bin)
+
+  // scores of the step in the slot at byte offset `so`
+  auto score_step = [&](const uint32_t so, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        put4(Sx[kb], g, rd_f4(stA + so + (uint32_t)(32 * g)));
+        put4(DPx[kb], g, rd_f4(stA + so + (uint32_t)(128 + 32 * g)));
+      }
+    u32x4 qa[KK], da[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      qa[kk] = lds_rd128(rmA[kk] + so);
+      da[kk] = lds_rd128(rmA[kk] + so + (uint32_t)IMG);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sx[kb]);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) DPx[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DPx[kb]);
+  };
+  // dV^T += dO^T P, dK^T += Q^T dS of the pending step, whose images are in the slot at `so`
+  auto product_step = [&](const uint32_t so) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const u32x4 dot = rd_tr(so + (uint32_t)IMG, t2, db), qt = rd_tr(so, t2, db);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr(dv[kb][db], dot, PB[kb][t2]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr(dk[kb][db], qt, DS[kb][t2]);
+      }
+  };
+
+  // general softmax stage of the step at query row mb: S, DP -> PB, DS (+ per-diagonal sums of dS)
+  auto softmax_generic = [&](const int mb) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16& s = S[kb];
+      const f32x16& dp = DP[kb];
+      const int k0 = kw0 + 32 * kb, krow = k0 + lq;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        const int R = a.R;
+        const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
+        if (dmax <= -R || dmin >= R) {
+          const float c = (dmax <= -R) ? cst_neg : cst_pos;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c);
+        } else if (dmin > -R && dmax < R) {
+          // interior of the band: four aligned 16-byte reads of this lane's table copy (see attn_bwd.h)
+          const int al = (R + krow - 3) & 3;
+          const float* tb = sT + al * rpe_n1p(R) + (R + krow - mb - 4 * hi - 3 - al);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
+            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
+            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
+            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
+            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
+          }
+        } else {
+          const int d0 = krow - mb - 4 * hi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = d0 - ((r & 3) + 8 * (r >> 2));
+            s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= c2;
+      }
+      f32x16 p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = fast_exp2(s[r]);
+        s[r] = p[r] * dp[r];
+      }
+      const bool nmask = k0 + 32 > N;
+      const bool cmask = a.causal && (k0 + 31 > mb + P);
+      if (nmask || cmask) {
+        // key visible to query m iff krow < N and (causal) krow <= m + P  <=>  crow(r, hi) >= thr
+        int thr = a.causal ? (krow - P - mb) : -(1 << 30);
+        if (krow >= N) thr = 1 << 30;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = crow(r, hi) >= thr;
+          p[r] = ok ? p[r] : 0.f;
+          s[r] = ok ? s[r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        PB[kb][t2] = pack8<BF16>(p, t2);
+        DS[kb][t2] = pack8<BF16>(s, t2);
+      }
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        if (want_drpe) {
+          const int R = a.R;
+          const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
+          if (dmax <= -R || dmin >= R) {
+            flush_carry(kb);
+            const float acc = tree16(s);
+            if (dmax <= -R) far_neg += acc; else far_pos += acc;
+          } else {
+            // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31), column sums on the matrix pipe
+            char* gw = sG + sk_w;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+              for (int wd = 0; wd < 4; ++wd) {
+                const int r = 8 * t2 + 2 * wd;
+                const uint32_t word = DS[kb][t2][wd];
+                *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
+                *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
+              }
+            typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+            const f32x4 zf4 = {0.f, 0.f, 0.f, 0.f};
+            float cs[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+              const char* p0 = sG + sk_r[0] + 32 * cb;
+              const char* p1 = sG + sk_r[1] + 32 * cb;
+              const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
+              const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
+              const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
+              cs[cb] = mfma16<BF16>(ones, fr, zf4)[0];
+            }
+            const bool up = (lq & 16) != 0;
+            const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
+            const int d_hi0 = k0 - mb + 1;  // diagonal of column 32
+            if (carry_valid[kb] && carry_d0[kb] != d_hi0) flush_carry(kb);
+            emit_diag(kb, c_hi + (carry_valid[kb] ? carry[kb] : 0.f), d_hi0 + lq);
+            carry[kb] = c_lo;
+            carry_d0[kb] = k0 - mb - 31;
+            carry_valid[kb] = true;
+          }
+        }
+      }
+    }
+  };
+
+  // the stages of one iteration one after the other (band / masked steps)
+  auto generic_iter = [&](const int j) {
+    const uint32_t o_prev = (uint32_t)(((j + 3) & 3) * SLOT), o_cur = (uint32_t)((j & 3) * SLOT), o_next = (uint32_t)(((j + 1) & 3) * SLOT);
+    product_step(o_prev);
+    sync_step(j, o_prev);
+    f32x16 Sn[2], DPn[2];
+    score_step(o_next, Sn, DPn);
+    softmax_generic((mt0 + j) * 32);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      S[kb] = Sn[kb];
+      DP[kb] = DPn[kb];
+    }
+    TRD = rd_tr(o_cur + (uint32_t)IMG, 0, 0);
+    TRQ = rd_tr(o_cur, 0, 0);
+  };
+
+  // One pipelined iteration = 32 MFMA gaps.  Gap g holds, all mutually independent:
+  //   MFMA   g < 16: products of step i-1 -- per (t2, db): dV^T[kb0], dV^T[kb1] (fragment dO^T), dK^T[kb0], dK^T[kb1] (Q^T);
+  //          16..23: S'[kb] of step i+1 (k-steps outer, C = -L/scale on the first); 24..31: dP'[kb] (C = -delta)
+  //   VALU   element g of step i (key block g >> 4, register g & 15): x = s*c2 + cst | element g-1: p = exp2(x) |
+  //          element g-2: ds = p*dp' | even g: elements g-4, g-3 packed to bf16 (P and dS words), dS summed into `facc`
+  //   LDS    gaps 0..11 the transposed fragments of the remaining three (t2, db) pairs of step i-1; gap 12 the barrier
+  //          E(i) + the DMA of step i+3; gaps 12..22 statistics (straight into the accumulators of S', dP': the MFMA C operand)
+  //          and row-major fragments of step i+1; gaps 28..31 the first
+  //          transposed fragments of step i (consumed by the next iteration's gaps 0..3)
+  // The VALU ops are volatile asm (see attn_fwd64.h); the youngest MFMA results they read are dP'[0] (finished by MFMA 30 of
+  // the previous iteration, first read in gap 2) and dP'[1] (MFMA 31, first read in gap 18).
+  auto fast_iter = [&]<int SL>(const int j, const float cst) {
+    constexpr uint32_t o_prev = ((SL + 3) & 3) * SLOT, o_cur = SL * SLOT, o_next = ((SL + 1) & 3) * SLOT;
+    f32x16 Sn[2], DPn[2];
+    [[maybe_unused]] f32x16 NL, DL;
+    u32x4 PBn[2][2], DSn[2][2], qa[KK], da[KK];
+    u32x2 trh[4][2][2], tnd[2], tnq[2];
+    float X[32], Pv[32], Dv[32];
+    auto pack_pair = [&]<int E0>() {
+      constexpr int kb = E0 >> 4, r0 = E0 & 15, t2 = r0 >> 3, wd = (r0 & 7) >> 1;
+      PBn[kb][t2][wd] = asm_cvt_pk<BF16>(Pv[E0], Pv[E0 + 1]);
+      const uint32_t dsw = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
+      DSn[kb][t2][wd] = dsw;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) asm_dot2c_bf16(facc, dsw, one2s);
+    };
+    static_for<32>([&](auto gi) {
+      constexpr int g = decltype(gi)::value;
+      // ---- MFMA ----
+      if constexpr (g < 16) {
+        constexpr int p = g >> 2, t2 = p >> 1, db = p & 1, jj = g & 3, kb = jj & 1, wh = jj >> 1;
+        u32x4 fr;
+        if constexpr (p == 0) fr = wh == 0 ? TRD : TRQ;
+        else fr = u32x4{trh[p][wh][0][0], trh[p][wh][0][1], trh[p][wh][1][0], trh[p][wh][1][1]};
+        if constexpr (wh == 0) mfma_acc_agpr(dv[kb][db], fr, PB[kb][t2]);
+        else mfma_acc_agpr(dk[kb][db], fr, DS[kb][t2]);
+      } else if constexpr (g < 24) {
+        constexpr int kk = (g - 16) >> 1, kb = g & 1;
+        if constexpr (FAT5_B64_NLC && kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], NL);
+        else Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sn[kb]);  // (accumulator preloaded with -L/scale)
+      } else {
+        constexpr int kk = (g - 24) >> 1, kb = g & 1;
+        if constexpr (FAT5_B64_NLC && kk == 0) DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DL);
+        else DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DPn[kb]);  // (preloaded with -delta)
+      }
+      // ---- barrier + DMA ----
+      if constexpr (g == 12 && !(FAT5_B64_X & 4)) sync_step(j, o_prev);
+      // ---- LDS ----
+      if constexpr ((FAT5_B64_X & 2) != 0) {
+        if constexpr (g == 0) {
+#pragma unroll
+          for (int pp = 1; pp < 4; ++pp)
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) { trh[pp][wh][0] = u32x2{TRD[0], TRD[1]}; trh[pp][wh][1] = u32x2{TRQ[2], TRQ[3]}; }
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) { qa[kk] = TRD; da[kk] = TRQ; }
+          Sn[0] = S[0]; Sn[1] = S[1]; DPn[0] = DP[0]; DPn[1] = DP[1];
+          tnd[0] = u32x2{TRD[0], TRD[1]}; tnd[1] = u32x2{TRD[2], TRD[3]}; tnq[0] = u32x2{TRQ[0], TRQ[1]}; tnq[1] = u32x2{TRQ[2], TRQ[3]};
+        }
+      } else if constexpr (g < 12) {
+        constexpr int pp = (g >> 2) + 1, t2 = pp >> 1, db = pp & 1, wh = (g >> 1) & 1, half = g & 1;
+        trh[pp][wh][half] = lds_rd_tr_half(trA[half][db] + o_prev + (uint32_t)((wh == 0 ? IMG : 0) + 16 * t2 * 2 * D));
+#if FAT5_B64_NLC
+      } else if constexpr (g == 12) {
+        put4(NL, 0, rd_f4(stA + o_next));
+        put4(NL, 1, rd_f4(stA + o_next + 32u));
+        put4(NL, 2, rd_f4(stA + o_next + 64u));
+        put4(NL, 3, rd_f4(stA + o_next + 96u));
+      } else if constexpr (g >= 13 && g <= 16) {
+        qa[g - 13] = lds_rd128(rmA[g - 13] + o_next);
+      } else if constexpr (g == 17) {
+        put4(DL, 0, rd_f4(stA + o_next + 128u));
+        put4(DL, 1, rd_f4(stA + o_next + 160u));
+        put4(DL, 2, rd_f4(stA + o_next + 192u));
+        put4(DL, 3, rd_f4(stA + o_next + 224u));
+#else
+      } else if constexpr (g == 12) {
+        put4(Sn[0], 0, rd_f4(stA + o_next));
+        put4(Sn[0], 1, rd_f4(stA + o_next + 32u));
+        put4(Sn[0], 2, rd_f4(stA + o_next + 64u));
+        put4(Sn[0], 3, rd_f4(stA + o_next + 96u));
+      } else if constexpr (g == 13) {
+        put4(Sn[1], 0, rd_f4(stA + o_next));
+        put4(Sn[1], 1, rd_f4(stA + o_next + 32u));
+        qa[0] = lds_rd128(rmA[0] + o_next);
+      } else if constexpr (g == 14) {
+        put4(Sn[1], 2, rd_f4(stA + o_next + 64u));
+        put4(Sn[1], 3, rd_f4(stA + o_next + 96u));
+        qa[1] = lds_rd128(rmA[1] + o_next);
+      } else if constexpr (g == 15 || g == 16) {
+        qa[g - 13] = lds_rd128(rmA[g - 13] + o_next);
+      } else if constexpr (g == 17 || g == 18) {
+        constexpr int kb = g - 17;
+        put4(DPn[kb], 0, rd_f4(stA + o_next + 128u));
+        put4(DPn[kb], 1, rd_f4(stA + o_next + 160u));
+        put4(DPn[kb], 2, rd_f4(stA + o_next + 192u));
+        put4(DPn[kb], 3, rd_f4(stA + o_next + 224u));
+#endif
+      } else if constexpr (g >= 19 && g <= 22) {
+        da[g - 19] = lds_rd128(rmA[g - 19] + o_next + (uint32_t)IMG);
+      } else if constexpr (g >= 28) {
+        constexpr int half = g & 1;
+        if constexpr (g < 30) tnd[half] = lds_rd_tr_half(trA[half][0] + o_cur + (uint32_t)IMG);
+        else tnq[half] = lds_rd_tr_half(trA[half][0] + o_cur);
+      }
+      // ---- VALU ----
+      if constexpr ((FAT5_B64_X & 1) != 0) {
+        if constexpr (g == 0) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) { PBn[kb][t2] = PB[kb][t2]; DSn[kb][t2] = DS[kb][t2]; }
+        }
+      } else {
+#if FAT5_B64_PK == 0
+      if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
+      if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
+      if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
+      X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
+      if constexpr (g == 31 && !(FAT5_B64_X & 8)) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
+        Pv[31] = asm_exp2(X[31]);
+        Dv[30] = asm_mul(Pv[30], DP[1][14]);
+        pack_pair.template operator()<28>();
+        Dv[31] = asm_mul(Pv[31], DP[1][15]);
+        pack_pair.template operator()<30>();
+      }
+#else
+      // pair form: odd gaps pack the pair multiplied in the gap before; even gaps multiply pair (g-4, g-3) and (PK 2) form the
+      // exponent arguments of pair (g, g+1) with one packed op each
+      if constexpr (g >= 5 && (g & 1) == 1) pack_pair.template operator()<g - 5>();
+      if constexpr (g >= 4 && (g & 1) == 0) {
+        constexpr int e0 = g - 4, kb = e0 >> 4, r = e0 & 15;
+        const f32x2 d2 = asm_pk_mul(f32x2{Pv[e0], Pv[e0 + 1]}, f32x2{DP[kb][r], DP[kb][r + 1]});
+        Dv[e0] = d2[0];
+        Dv[e0 + 1] = d2[1];
+      }
+      if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
+#if FAT5_B64_PK == 2
+      if constexpr ((g & 1) == 0) {
+        const f32x2 x2 = asm_pk_fma(f32x2{S[g >> 4][g & 15], S[g >> 4][(g & 15) + 1]}, f32x2{c2, c2}, f32x2{cst, cst});
+        X[g] = x2[0];
+        X[g + 1] = x2[1];
+      }
+#else
+      X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
+#endif
+      if constexpr (g == 31) {
+        Pv[31] = asm_exp2(X[31]);
+        {
+          const f32x2 d2 = asm_pk_mul(f32x2{Pv[28], Pv[29]}, f32x2{DP[1][12], DP[1][13]});
+          Dv[28] = d2[0]; Dv[29] = d2[1];
+        }
+        {
+          const f32x2 d2 = asm_pk_mul(f32x2{Pv[30], Pv[31]}, f32x2{DP[1][14], DP[1][15]});
+          Dv[30] = d2[0]; Dv[31] = d2[1];
+        }
+        pack_pair.template operator()<28>();
+        pack_pair.template operator()<30>();
+      }
+#endif
+      if constexpr (g == 31 && (FAT5_B64_X & 8) != 0) { Pv[31] = Pv[30]; Dv[30] = Dv[29]; Dv[31] = Dv[29]; pack_pair.template operator()<28>(); pack_pair.template operator()<30>(); }
+      }
+#if FAT5_B64_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      S[kb] = Sn[kb];
+      DP[kb] = DPn[kb];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        PB[kb][t2] = PBn[kb][t2];
+        DS[kb][t2] = DSn[kb][t2];
+      }
+    }
+    TRD = u32x4{tnd[0][0], tnd[0][1], tnd[1][0], tnd[1][1]};
+    TRQ = u32x4{tnq[0][0], tnq[0][1], tnq[1][0], tnq[1][1]};
+  };
+
+  // pipelined range [j, je) of all-visible steps with the constant bias `cst`; j % 4 == 0 on entry
+  auto fast_range = [&](int& j, const int je, const float cst, float& farbin) {
+    if (j >= je) return;
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      flush_carry(0);
+      flush_carry(1);
+    }
+    facc = 0.f;
+    for (; j + 4 <= je; j += 4) {
+      static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
+    }
+    static_for<3>([&](auto si) {
+      if (j < je) {
+        fast_iter.template operator()<decltype(si)::value>(j, cst);
+        ++j;
+      }
+    });
+    farbin += facc;
+  };
+
+  if (nsteps > 0) {
+    // Step classes (workgroup-uniform), m ascending = k - q descending:  [0, ia) far-positive | [ia, ib0) general | [ib0, nsteps) far-negative / no bias
+    int ia = 0, ib0 = nsteps;
+    if (n0 + BNK <= N) {
+      int j_vis = 0;  // causal: first step whose every row sees every key of the workgroup
+      if (a.causal) j_vis = max(0, (max(0, n0 + BNK - 1 - P) + 31) / 32 - mt0);
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        const int lim_p = n0 - a.R - 31;  // far-positive: n0 - (mrow0 + 31) >= R
+        if (!a.causal && lim_p >= 0) ia = min(nsteps, max(0, lim_p / 32 + 1 - mt0));
+        const int mt_n = (n0 + BNK - 1 + a.R + 31) / 32;  // far-negative: n0 + BNK - 1 - mrow0 <= -R
+        ib0 = min(nsteps, max(ia, max(mt_n - mt0, j_vis)));
+      } else {
+        ib0 = min(nsteps, j_vis);
+      }
+    }
+    ib0 = min(nsteps, (ib0 + 3) & ~3);  // (pipelined ranges start in ring slot 0)
+
+    // fill: scores of the first step, nothing pending
+    score_step(0u, S, DP);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) { PB[kb][t2] = zero4; DS[kb][t2] = zero4; }
+    TRD = zero4;
+    TRQ = zero4;
+
+    int j = 0;
+    fast_range(j, ia, cst_pos, far_pos);
+    for (; j < ib0; ++j) generic_iter(j);
+    fast_range(j, nsteps, BIAS == FAT5_BIAS_RPE1D ? cst_neg : 0.f, far_neg);
+    // drain: the products of the last step
+    product_step((uint32_t)(((nsteps - 1) & 3) * SLOT));
+  }
+
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
+  // ---- partial per-diagonal sums of this key block (before the dK / dV stores: see attn_bwd.h) ----
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    if (want_drpe) {
+      flush_carry(0);
+      flush_carry(1);
+      far_neg = wave_sum(far_neg);
+      far_pos = wave_sum(far_pos);
+      if (l == 0) {
+        sD0[(2 * w) * n1] += far_neg;
+        sD0[(2 * w) * n1 + 2 * a.R] += far_pos;
+      }
+      __syncthreads();
+      float* out = a.drpe_part + ((int64_t)bh * a.n_nblk + nblk) * n1;
+      for (int i2 = tid; i2 < n1; i2 += NT) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 2 * Cfg::NW; ++ww) acc += sD0[ww * n1 + i2];
+        out[i2] = acc;
+      }
+    }
+  }
+
+  const float scale = a.scale;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int krow = kw0 + 32 * kb + lq;
+    if (krow < N) {
+      uint16_t* dkrow = dkb + (int64_t)krow * a.dks[2];
+      uint16_t* dvrow = dvb + (int64_t)krow * a.dvs[2];
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 wk, wv;
+          wk[0] = pack2<BF16>(dk[kb][db][4 * g + 0] * scale, dk[kb][db][4 * g + 1] * scale);
+          wk[1] = pack2<BF16>(dk[kb][db][4 * g + 2] * scale, dk[kb][db][4 * g + 3] * scale);
+          wv[0] = pack2<BF16>(dv[kb][db][4 * g + 0], dv[kb][db][4 * g + 1]);
+          wv[1] = pack2<BF16>(dv[kb][db][4 * g + 2], dv[kb][db][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * hi) = wk;
+          *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
+        }
+    }
+  }
+}
+
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_kv64_kernel(const AttnArgs a) {
+  attn_bwd_kv64_body<D, BF16, BIAS>(a, blockIdx.x);
+}
+
+}  // namespace fat5

@@ -1,0 +1,31 @@
+// Instantiations of the 64-keys-per-wave pipelined dK/dV body (attn_bwd64.h) for one head_dim (-DFAT5_INST_D=64).
+#include "attn_bwd64.h"
+#include "attn_launch.h"
+
+#ifndef FAT5_INST_D
+#error "FAT5_INST_D must be defined"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+namespace fat5 {
+
+template <int D, int BIAS>
+static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = Bwd64Cfg<D>::smem(a.R, BIAS);
+  auto kern = attn_bwd_kv64_kernel<D, true, BIAS>;
+  if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+  if (!bf16) return hipErrorInvalidValue;
+  return bias == FAT5_BIAS_RPE1D ? launch_kv64<FAT5_INST_D, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64<FAT5_INST_D, FAT5_BIAS_NONE>(a, grid, s);
+}
+size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }
+
+}  // namespace fat5

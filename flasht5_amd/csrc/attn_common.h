@@ -241,6 +241,7 @@ struct AttnArgs {
   uint16_t *o, *dq, *dk, *dv;
   float* lse;
   float* delta;             // (B,H,M) fp32 scratch (bwd)
+  float* stat2;             // (B*H, ceil(M/32), 2, 32) fp32 scratch: -L/scale and -delta per 32-row step, the form the 64-key dK/dV body DMAs (or nullptr)
   const uint16_t* bias;     // dense
   uint16_t* ds_out;         // dense dS output (B', H', M, N) or nullptr
   const float* rpe1d;       // (H, 2R+1)

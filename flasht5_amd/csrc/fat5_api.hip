@@ -39,7 +39,8 @@ int env_int(const char* name, int dflt) {
 }
 
 struct BwdLayout {
-  size_t delta_off, ds_off, drpe_off, scratch_off, total;
+  size_t delta_off, stat2_off, ds_off, drpe_off, scratch_off, total;
+  bool kv64;        // dK/dV by the 64-keys-per-wave pipelined body (attn_bwd64.h); the dQ kernel then also writes its statistics
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
   int n_nblk;
@@ -183,10 +184,22 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   L.nw_q = pick_nw(bh * ((p->M + 127) / 128), "FAT5_BWDQ_NW");
   L.nw_kv = pick_nw(bh * ((p->N + 127) / 128), "FAT5_BWDKV_NW");
   L.n_nblk = (p->N + 32 * L.nw_kv - 1) / (32 * L.nw_kv);
+  // long sequences: 64 keys per wave, software-pipelined (attn_bwd64.h) once its 256-key workgroups (one per CU) cover the
+  // chip twice (FAT5_BWD64=0 disables, =1 forces wherever the body applies)
+  const int b64_env = env_int("FAT5_BWD64", -1);
+  L.kv64 = p->D == 64 && p->dtype == FAT5_BF16 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
+           env_int("FAT5_BWDKV_NW", 0) == 0 && (b64_env == 1 || bh * ((p->N + 255) / 256) >= 512) &&
+           smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024;
+  if (L.kv64) {
+    L.nw_kv = 4;
+    L.n_nblk = (p->N + 255) / 256;
+  }
   size_t off = 0;
   L.delta_off = off;
   // delta: (B,H,M) -- packed batches: (H, total_q), the layout of lse
   off = align_up(off + (p->cu_seqlens_q ? (size_t)p->H * p->total_q : (size_t)bh * p->M) * sizeof(float), 256);
+  L.stat2_off = off;
+  if (L.kv64) off = align_up(off + (size_t)bh * ((p->M + 31) / 32) * 64 * sizeof(float), 256);
   L.ds_staged = false;
   L.dbias_inkernel = false;
   L.ds_off = off;
@@ -226,7 +239,7 @@ static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D) {
   if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
   static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
   static const long fuse_max = [] { const char* e = getenv("FAT5_BWD_FUSE_MAX"); return e ? atol(e) : 4L * 256; }();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
-  return fuse_env && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
+  return fuse_env && !L.kv64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
 int fat5_attn_bwd_launches(const fat5_attn_params* p) {
@@ -268,7 +281,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   bwd_layout(p, L);
   if (p->bias_mode == FAT5_BIAS_RPE1D) {
     // the dK/dV body keeps the table and one private diagonal accumulator per wave in LDS
-    const size_t lds = p->D == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
+    const size_t lds = L.kv64 ? smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode)
+                     : p->D == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
                                   : (p->D == 64 ? smem_bwd_kv_d64(L.nw_kv, p->rpe_radius, p->bias_mode) : smem_bwd_kv_d128(L.nw_kv, p->rpe_radius, p->bias_mode));
     if (lds > 160 * 1024)
       return fail(FAT5_EINVAL, "bwd: rpe_radius %d needs %zu bytes of LDS (160 KiB per workgroup; radius <= 1024 fits every head_dim)", p->rpe_radius, lds);
@@ -285,6 +299,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.dos[i] = p->do_stride[i]; a.dqs[i] = p->dq_stride[i]; a.dks[i] = p->dk_stride[i]; a.dvs[i] = p->dv_stride[i];
   }
   a.delta = (float*)(ws + L.delta_off);
+  a.stat2 = L.kv64 ? (float*)(ws + L.stat2_off) : nullptr;
   // the dK/dV kernel stages -L/scale (accumulator initial value): an exact zero scale (softmax of the bias alone,
   // dq = dk = 0) runs with 1e-30 -- q.k * 1e-30 and the 1e-30-scaled dq / dk vanish in fp32 / the output dtype
   if (a.scale == 0.f) a.scale = 1e-30f;
@@ -343,6 +358,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     // 2) dK, dV, dBias
     if (stages & FAT5_BWD_DKDV) {
       launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
+      if (L.kv64) fn = launch_bwd_kv64_d64;
       hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)grid_kv, stream);
       if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
     }

@@ -148,8 +148,12 @@ def cfg3_case():
     want = want.float()
     # the two clamped end entries sum ~S^2/2 rounded dS values each: bound relative to the largest sum
     out.append(rec(name, "drpe1d(2,257) of the slice", maxdiff(d1s, want), 5e-3 * max(1.0, want.abs().max().item()) + 2e-2))
+    # the far bins sum the dS that were rounded to bf16 for the dK GEMM (the reference's bias gradient is made of the same rounded
+    # values, :720): n independent roundings, 4 sigma = 4 * 2^-9 / sqrt(3) * sqrt(sum ds^2); sum ds^2 of a head from the slice, x B;
+    # x 3 for the heads the slice does not cover
+    allow = 3 * max(4.0 * 2.0 ** -9 / 3 ** 0.5 * (q.shape[0] * (ds[0, hh].float() ** 2).sum().item()) ** 0.5 for hh in range(2))
     out.append(rec(name, "sum_k drpe1d[h,k] (softmax Jacobian rows sum to 0)", d1.sum(-1).abs().max().item(),
-                   1e-3 * d1.abs().sum(-1).max().item() + 1e-2))
+                   allow + 1e-3 * d1.abs().sum(-1).max().item() + 1e-2))
     return out
 
 

@@ -288,8 +288,13 @@ def test_cfg3_properties_s8192():
     assert maxdiff(dk[sl[0], sl[1]], rdk) <= gbound(rdk, torch.bfloat16)
     assert maxdiff(dv[sl[0], sl[1]], rdv) <= gbound(rdv, torch.bfloat16)
     # (2) softmax Jacobian: every row of dS sums to zero => the diagonal sums of each head sum to ~0
-    tot = d1.sum(-1).abs().max().item()
-    assert tot <= 1e-3 * d1.abs().sum(-1).max().item() + 1e-2, tot
+    # (the far bins sum the dS that were rounded to bf16 for the dK GEMM -- the reference's bias gradient is made of the same
+    #  rounded values, :720 -- so the total carries n independent roundings: 4 sigma = 4 * 2^-9 / sqrt(3) * sqrt(sum ds^2), with
+    #  sum ds^2 of a head estimated from the oracle's dS of the two checked heads of batch 0, times B)
+    allow = max(4.0 * 2.0 ** -9 / 3 ** 0.5 * (B * (rds[0, hh].float() ** 2).sum().item()) ** 0.5 for hh in range(2))
+    tot = d1.sum(-1).abs()
+    assert tot[:2].max().item() <= allow + 1e-3 * d1.abs().sum(-1).max().item() + 1e-2, (tot, allow)
+    assert tot.max().item() <= 3 * allow + 1e-3 * d1.abs().sum(-1).max().item() + 1e-2, (tot, allow)
     # (3) linearity in V and dO: o(2v) = 2 o(v) exactly in bf16 (power of two); dq(2 do) = 2 dq
     plan2 = AttentionPlan(q, k, (v * 2).contiguous(), (do * 2).contiguous(), rpe1d=rpe1d, radius=128, sm_scale=0.125)
     o2 = plan2.forward()

@@ -1,0 +1,126 @@
+"""GPU parity tests of the long-sequence dK/dV body (csrc/attn_bwd64.h: 64 keys per wave, software-pipelined query-step loop,
+4-slot LDS ring, AGPR accumulators) -- forced with FAT5_BWD64=1 at sizes the oracle finishes in seconds; at (4,12,8192,64)
+the default dispatch picks it by itself (test_attention_gpu.py::test_cfg3_properties_s8192)."""
+import pytest
+import torch
+
+import oracle
+from attn_helpers import make_inputs, oracle_all, maxdiff
+from test_attention_gpu import bound, gbound, _rpe_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_bwd64(monkeypatch):
+    monkeypatch.setenv("FAT5_BWD64", "1")
+
+
+def _grads(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
+    from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe
+    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+    if table is None:
+        o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], None, causal, scale)
+        dq, dk, dv = torch.autograd.grad(o, leaves, do)
+        return {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv}
+    tb = table.cuda().requires_grad_()
+    o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, scale)
+    dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
+    return {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv, "dtable": dt}
+
+
+def _table_truth(q, k, v, bias, o, L, do, scale, causal, table, M, N, bidir, md):
+    """(truth, rounding allowance) per bucket.  delta from the STORED o (see test_attention_gpu.py::
+    test_rpe_mode_matches_dense_oracle).  The pipelined steps sum the dS they rounded to bf16 for the dK GEMM -- what the
+    reference's bias gradient is made of, too (`ds.to(dtype)`, flash_attention_v2_bias.py:720) -- so a bucket of n terms carries
+    n independent roundings of relative size <= 2^-9: allowance = 4 sigma = 4 * 2^-9 / sqrt(3) * sqrt(sum ds^2)."""
+    _, _, _, _, db = oracle.attn_bwd_oracle(q, k, v, bias, o, L, do, scale, causal)
+    db = db.cpu()
+    tl = table.clone().requires_grad_()
+    oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db)
+    t2 = table.clone().requires_grad_()
+    oracle.compute_bias(t2, M, N, bidir, 32, md).backward(db * db)
+    return tl.grad, 4.0 * 2.0 ** -9 / 3 ** 0.5 * t2.grad.sqrt()
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,mode,md", [
+    (1, 2, 256, 256, False, "none", 128),     # one workgroup: 8 pipelined steps (two trips of the 4-step loop)
+    (2, 3, 1024, 1024, False, "none", 128),   # four key blocks per (b, h)
+    (2, 3, 1024, 1024, False, "rpe", 128),    # far-positive range, band (general steps), far-negative range
+    (1, 2, 1024, 1024, False, "rpe", 32),     # narrow band: pipelined ranges on both sides of every workgroup
+    (1, 2, 2048, 2048, True, "rpe", 128),     # causal: diagonal steps general, steps above the diagonal skipped
+    (1, 2, 2048, 2048, True, "none", 128),
+    (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: last step padded (rows past M), key tail workgroup (all general)
+    (1, 2, 300, 2500, True, "rpe", 128),      # M << N, bottom-right causal
+    (1, 2, 2500, 300, True, "none", 128),     # M >> N: dead rows (lse = -inf) in the pipelined range
+    (1, 1, 3000, 520, False, "rpe", 64),      # remainder iterations after the 4-step loop, 1-row-short last step
+    (1, 2, 90, 70, False, "rpe", 128),        # fewer steps than ring slots
+])
+def test_bwd64_matches_oracle(B, H, M, N, causal, mode, md):
+    dtype, scale = torch.bfloat16, 0.125
+    if mode == "rpe":
+        q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, True, md, seed=M + 5 * N)
+    else:
+        q, k, v, _, do = make_inputs(B, H, M, N, 64, dtype, None, seed=M + 5 * N, strided=True)
+        table, bias = None, None
+    ref = oracle_all(q, k, v, bias, do, scale, causal)
+    got = _grads(q, k, v, do, causal, scale, table, True, md)
+    for key in ("dq", "dk", "dv"):
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= gbound(ref[key], dtype), key
+    if table is not None:
+        want, allow = _table_truth(q, k, v, bias, got["o"], ref["L"], do, scale, causal, table, M, N, True, md)
+        err = (got["dtable"].cpu() - want).abs()
+        assert bool((err <= allow + 2e-3 * max(1.0, want.abs().max().item()) + 1e-2).all()), (err.max().item(), allow.max().item())
+
+
+def test_bwd64_agrees_with_32key_body(monkeypatch):
+    """Both dK/dV bodies on the same inputs: dk / dv equal to output rounding, the diagonal sums to fp32 summation order."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    q, k, v, _, do = make_inputs(2, 4, 2048, 2048, 64, torch.bfloat16, None, seed=3, strided=True)
+    table = (torch.randn(32, 4, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    outs = []
+    for f in ("0", "1"):
+        monkeypatch.setenv("FAT5_BWD64", f)
+        plan = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=pe.rpe1d_from_table(table, True, 32, 128), radius=128)
+        plan.forward()
+        plan.backward()
+        torch.cuda.synchronize()
+        outs.append((plan.dk.float().clone(), plan.dv.float().clone(), plan.dbias.clone()))
+    for i in (0, 1):
+        assert (outs[0][i] - outs[1][i]).abs().max().item() <= 2.0 ** -6 * max(1.0, outs[0][i].abs().max().item()), i
+    # (far bins: this body sums the bf16-rounded dS, the 32-key body the unrounded ones; ~1e6 terms each)
+    assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-2 * max(1.0, outs[0][2].abs().max().item())
+
+
+def test_bwd64_unit_range_shards_are_bit_identical(monkeypatch):
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    from flasht5_amd.sharding import unit_range
+    B, H = 2, 3
+    q, k, v, _, do = make_inputs(B, H, 1024, 1024, 64, torch.bfloat16, None, seed=5)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(2)) * 0.5).cuda()
+    rpe1d = pe.rpe1d_from_table(table, True, 32, 128)
+    full = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=rpe1d, radius=128)
+    full.forward(); full.backward()
+    torch.cuda.synchronize()
+    dk = torch.zeros_like(full.dk)
+    acc = torch.zeros_like(full.dbias)
+    for r in range(2):
+        part = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=rpe1d, radius=128, units=unit_range(B, H, 2, r))
+        part.dk.zero_()
+        part.forward(); part.backward()
+        torch.cuda.synchronize()
+        dk += part.dk
+        acc += part.dbias
+    assert torch.equal(dk, full.dk)
+    assert (acc - full.dbias).abs().max().item() <= 1e-4 * max(1.0, full.dbias.abs().max().item())
+
+
+def test_bwd64_deterministic():
+    q, k, v, do, table, _ = _rpe_case(1, 4, 2048, 2048, torch.bfloat16, False, True, 128, seed=9)
+    a = _grads(q, k, v, do, False, 0.125, table)
+    b = _grads(q, k, v, do, False, 0.125, table)
+    for key in ("dk", "dv", "dtable"):
+        assert torch.equal(a[key], b[key]), key
