@@ -75,7 +75,7 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 #define FAT5_B64_PK 0  // 0: one v_fma / v_mul per element; 1: v_pk_mul_f32 per element pair; 2: v_pk_fma_f32 too
 #endif
 #ifndef FAT5_B64_NLC
-#define FAT5_B64_NLC 0  // 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter as a separate C operand
+#define FAT5_B64_NLC 1  // 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter as a separate C operand
 #endif
 #ifndef FAT5_B64_X
 #define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
@@ -89,7 +89,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
   int b, h, nblk;
   decode_unit(a, bid, a.n_nblk, b, h, nblk);
   const int bh = b * a.H + h;
@@ -468,6 +468,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         if constexpr (FAT5_B64_NLC && kk == 0) DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DL);
         else DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DPn[kb]);  // (preloaded with -delta)
       }
+#if FAT5_B64_PIN
+      __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap)
+#endif
       // ---- barrier + DMA ----
       if constexpr (g == 12 && !(FAT5_B64_X & 4)) sync_step(j, o_prev);
       // ---- LDS ----
@@ -603,43 +606,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
     TRQ = u32x4{tnq[0][0], tnq[0][1], tnq[1][0], tnq[1][1]};
   };
 
-  // pipelined range [j, je) of all-visible steps with the constant bias `cst`; j % 4 == 0 on entry
-  auto fast_range = [&](int& j, const int je, const float cst, float& farbin) {
-    if (j >= je) return;
-    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-      flush_carry(0);
-      flush_carry(1);
-    }
-    facc = 0.f;
-    for (; j + 4 <= je; j += 4) {
-      static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
-    }
-    static_for<3>([&](auto si) {
-      if (j < je) {
-        fast_iter.template operator()<decltype(si)::value>(j, cst);
-        ++j;
-      }
-    });
-    farbin += facc;
-  };
-
   if (nsteps > 0) {
-    // Step classes (workgroup-uniform), m ascending = k - q descending:  [0, ia) far-positive | [ia, ib0) general | [ib0, nsteps) far-negative / no bias
-    int ia = 0, ib0 = nsteps;
-    if (n0 + BNK <= N) {
-      int j_vis = 0;  // causal: first step whose every row sees every key of the workgroup
-      if (a.causal) j_vis = max(0, (max(0, n0 + BNK - 1 - P) + 31) / 32 - mt0);
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        const int lim_p = n0 - a.R - 31;  // far-positive: n0 - (mrow0 + 31) >= R
-        if (!a.causal && lim_p >= 0) ia = min(nsteps, max(0, lim_p / 32 + 1 - mt0));
-        const int mt_n = (n0 + BNK - 1 + a.R + 31) / 32;  // far-negative: n0 + BNK - 1 - mrow0 <= -R
-        ib0 = min(nsteps, max(ia, max(mt_n - mt0, j_vis)));
-      } else {
-        ib0 = min(nsteps, j_vis);
-      }
-    }
-    ib0 = min(nsteps, (ib0 + 3) & ~3);  // (pipelined ranges start in ring slot 0)
-
     // fill: scores of the first step, nothing pending
     score_step(0u, S, DP);
 #pragma unroll
@@ -649,10 +616,42 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
     TRD = zero4;
     TRQ = zero4;
 
+    // this wave's 64 keys x the step's 32 rows: all visible and one constant bias?  (wave-uniform; rows past M contribute
+    // nothing by their statistics).  side: +1 far-positive (k - q >= R), -1 far-negative / no bias
+    auto classify = [&](const int j, int& side) {
+      const int mb = (mt0 + j) * 32;
+      bool fast = kw0 + 64 <= N && (!a.causal || kw0 + 63 <= mb + P);
+      side = -1;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        const bool fpos = kw0 - (mb + 31) >= a.R, fneg = kw0 + 63 - mb <= -a.R;
+        fast = fast && (fpos || fneg);
+        side = fpos ? 1 : -1;
+      }
+      return fast;
+    };
     int j = 0;
-    fast_range(j, ia, cst_pos, far_pos);
-    for (; j < ib0; ++j) generic_iter(j);
-    fast_range(j, nsteps, BIAS == FAT5_BIAS_RPE1D ? cst_neg : 0.f, far_neg);
+    while (j < nsteps) {
+      int side, side3;
+      // steady state: four steps (ring slots 0..3) per trip, straight-line; the fast steps of one side are contiguous, so the
+      // first and the last step of a trip decide for all four.  Fast steps that do not fill an aligned trip run the general iteration.
+      while (j + 4 <= nsteps && (j & 3) == 0 && classify(j, side) && classify(j + 3, side3) && side3 == side) {
+        const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
+        if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          flush_carry(0);
+          flush_carry(1);
+        }
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
+        j += 4;
+        if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          if (side > 0) far_pos += facc; else far_neg += facc;
+          facc = 0.f;
+        }
+      }
+      if (j < nsteps) {
+        generic_iter(j);
+        ++j;
+      }
+    }
     // drain: the products of the last step
     product_step((uint32_t)(((nsteps - 1) & 3) * SLOT));
   }
@@ -701,6 +700,433 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         }
     }
   }
+}
+
+// =============================================================================================
+// dQ (+ delta, + the row statistics of the dK/dV body): 64 query rows per wave, software-pipelined key-step loop
+// =============================================================================================
+// Same contract as attn_bwd_q_kernel (attn_bwd.h; replaces the reference `_bwd_preprocess` + `_bwd_q_kernel`,
+// flash_attention_v2_bias.py:516-556, :748-905).  A wave owns two 32-row query blocks (Q / dO fragments and the dQ^T
+// accumulators in AGPRs), one wave per SIMD; per 32-key step i the matrix pipe runs dQ^T += K^T dS^T of step i-1 and
+// S^T = K Q^T, dP'^T = V dO^T - delta of step i+1 (24 MFMAs, every K / V fragment read from LDS feeds two of them) while the
+// VALU pipe turns step i's scores into dS (FMA, v_exp_f32, multiply per element; bf16 pack per pair).  K / V steps come
+// global -> LDS by DMA three steps ahead into a 4-slot ring, one barrier per step.  Every wave picks the pipelined or the
+// general iteration by ITS 64 rows (wave-uniform): only the steps that cross the wave's own RPE band / causal diagonal / the key
+// tail run the general softmax.
+template <int D>
+struct BwdQ64Cfg {
+  static constexpr int NW = 4, BM = 64 * NW, KT = 32, NT = 64 * NW, NS = 4;
+  static constexpr int IMG = rm_bytes<D, KT>();  // one 32-key image (K or V)
+  static constexpr int SLOT = 2 * IMG;
+  static constexpr int RING = NS * SLOT;
+  static size_t smem(int R, int bias_mode) { return RING + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0); }
+};
+
+template <int D, bool BF16, int BIAS>
+FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
+  static_assert(D == 64 && BF16 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bf16, bias none / rpe1d");
+  using Cfg = BwdQ64Cfg<D>;
+  constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
+  constexpr int KK = D / 16, DB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RING);
+
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
+  int b, h, mblk;
+  decode_unit(a, bid, a.n_mblk, b, h, mblk);
+  const int M = a.M, N = a.N;
+  const int m0 = mblk * BM;
+  if (m0 >= M) return;
+  const uint16_t* qb_ = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
+  const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
+  const uint16_t* vb_ = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
+  const uint16_t* ob_ = a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1];
+  const uint16_t* dob_ = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1];
+  uint16_t* dqb_ = a.dq + (int64_t)b * a.dqs[0] + (int64_t)h * a.dqs[1];
+  const int64_t stat_off = ((int64_t)b * a.H + h) * a.M;
+  const int P = N - M;
+  int n_end = N;
+  if (a.causal) n_end = min(N, m0 + BM + P);
+  const int nt = n_end > 0 ? (n_end + 31) / 32 : 0;
+  const int qw0 = m0 + 64 * w;  // first query row of this wave; block qb covers qw0 + 32*qb .. +31
+
+  // Q and dO fragments (B operands), delta = rowsum(o * do) (reference _bwd_preprocess, :516-556), row statistics
+  u32x4 qf[2][KK], dof[2][KK];
+  float nL2[2];
+  // dP'^T = V dO^T - delta: the accumulator's initial value comes from one extra MFMA per query block, ones(32 x 16) x D3 with
+  // D3[j][q] = the j-th bf16 piece of -delta_q (hi + mid + lo: 24 bits, exact to fp32) -- a 16-register broadcast of -delta per
+  // block as the C operand would hold 32 VGPRs for the whole loop (C and D of an MFMA share one register file)
+  u32x4 d3[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = qw0 + 32 * qb + lq, qrow_c = min(qrow, M - 1);
+    float dsum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
+      dof[qb][kk] = *reinterpret_cast<const u32x4*>(dob_ + (int64_t)qrow_c * a.dos[2] + 16 * kk + 8 * hi);
+      const u32x4 of = *reinterpret_cast<const u32x4*>(ob_ + (int64_t)qrow_c * a.os[2] + 16 * kk + 8 * hi);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dsum = fmaf(cvt_lo<BF16>(of[j]), cvt_lo<BF16>(dof[qb][kk][j]), dsum);
+        dsum = fmaf(cvt_hi<BF16>(of[j]), cvt_hi<BF16>(dof[qb][kk][j]), dsum);
+      }
+    }
+    const float delta = pair_sum(dsum);
+    if (a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
+    const float Lq = a.lse[stat_off + qrow_c];
+    nL2[qb] = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;  // (dead rows: see attn_bwd.h)
+    if (a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
+      float* st = a.stat2 + (((int64_t)b * a.H + h) * ((M + 31) / 32) + (qrow >> 5)) * 64 + (qrow & 31);
+      const bool live = qrow < M && !(Lq < kDeadRowLse);
+      st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
+      st[32] = qrow < M ? -delta : 0.f;
+    }
+    {
+      const float nd = -delta;
+      const uint32_t p0 = pack2<BF16>(nd, 0.f) & 0xffffu;
+      const float r1 = nd - __uint_as_float(p0 << 16);
+      const uint32_t p1 = pack2<BF16>(r1, 0.f) & 0xffffu;
+      const float r2 = r1 - __uint_as_float(p1 << 16);
+      const uint32_t p2 = pack2<BF16>(r2, 0.f) & 0xffffu;
+      d3[qb] = hi == 0 ? u32x4{p0 | (p1 << 16), p2, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};  // (k-index 8*hi + j of the B operand)
+    }
+  }
+  const uint32_t one2 = pack2<BF16>(1.f, 1.f);
+  u32x4 ones4 = {one2, one2, one2, one2};
+  const float* sTa[2] = {sT, sT};
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) sTa[qb] = sT + ((a.R - (qw0 + 32 * qb + lq)) & 3) * rpe_n1p(a.R);
+  }
+
+  f32x16 dq[2][DB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[qb][i][r] = 0.f;
+
+  // ---- ring: key step t (keys 32t ..+31) lives in slot t % 4: [K image | V image] ----
+  using Dma = DmaStage<D, Cfg::KT, NT>;
+  static_assert(Dma::PER == 1 && Dma::NV == 1, "one 16-byte piece per thread and image");
+  Dma kst, vst;
+  kst.init(a.ks[2], tid);
+  vst.init(a.vs[2], tid);
+  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
+  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb_, a.vs[2], N, D);
+  const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
+  auto dma_step = [&](int t, uint32_t slot_off) {
+    const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane(t);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + slot_off));
+    dma16_asm(krs, dst, kst.voff[0], tt * 32u * kstride_b);
+    dma16_asm(vrs, dst + (uint32_t)IMG, vst.voff[0], tt * 32u * vstride_b);
+  };
+  // E(t): step t+1 has landed and is visible to every wave; every wave is done with step t-1, whose slot takes step t+3
+  auto sync_step = [&](int t, uint32_t slot3_off) {
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else wait_dma_all();
+    __syncthreads();
+    if (t + 3 < nt) dma_step(t + 3, slot3_off);
+  };
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
+  for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  wait_dma_all();
+  __syncthreads();
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+a"(qf[qb][kk]), "+a"(dof[qb][kk]));  // MFMA-only operands: AGPRs
+  asm volatile("" : "+a"(d3[0]), "+a"(d3[1]), "+a"(ones4));
+
+  FragAddr<D> fa;
+  fa.init(l);
+  uint32_t rmA[KK], trA[2][DB];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) rmA[kk] = lds0 + (uint32_t)fa.rm[kk];
+#pragma unroll
+  for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) trA[j2][db] = lds0 + (uint32_t)fa.tr[j2][db];
+
+  const float c2 = a.scale * kLog2e;
+  float cst_neg = 0.f, cst_pos = 0.f;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    cst_neg = sT[0];
+    cst_pos = sT[2 * a.R];
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // Pipeline state between two iterations (iteration i = key step i is in its softmax stage):
+  //   S, DP     S^T = K Q^T and dP'^T = V dO^T - delta of step i (lane = query row, register r <-> key crow(r, hi))
+  //   DSB       dS^T of step i-1 rounded to bf16 (:720), as B operands;  TRK  the K^T fragments (t2 = 0; db = 0, 1) of step i-1
+  f32x16 S[2], DP[2];
+  u32x4 DSB[2][2], TRK[2];
+
+  auto rd_tr = [&](uint32_t off, int t2, int db) {
+    const uint32_t o = off + (uint32_t)(16 * t2 * 2 * D);
+    return lds_rd_tr(trA[0][db] + o, trA[1][db] + o);
+  };
+  auto score_step = [&](const uint32_t so, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
+    u32x4 kf[KK], vf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      kf[kk] = lds_rd128(rmA[kk] + so);
+      vf[kk] = lds_rd128(rmA[kk] + so + (uint32_t)IMG);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) Sx[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], kk == 0 ? zero16 : Sx[qb]);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) DPx[qb] = mfma32<BF16>(ones4, d3[qb], zero16);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) DPx[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPx[qb]);
+  };
+  // dQ^T[d][q] += K^T[d][key] dS^T[key][q] of the pending step, whose K image is in the slot at `so`
+  auto product_step = [&](const uint32_t so) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const u32x4 kt = rd_tr(so, t2, db);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) mfma_acc_agpr(dq[qb][db], kt, DSB[qb][t2]);
+      }
+  };
+  // general softmax stage of the key step at nb: S, DP -> DSB
+  auto softmax_generic = [&](const int nb) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16& s = S[qb];
+      const f32x16& dp = DP[qb];
+      const int qr0 = qw0 + 32 * qb, qrow = qr0 + lq;
+      const float nl = nL2[qb];
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        const int R = a.R;
+        const int dmin = nb - (qr0 + 31), dmax = nb + 31 - qr0;
+        if (dmax <= -R || dmin >= R) {
+          const float ad = ((dmax <= -R) ? cst_neg : cst_pos) + nl;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, ad);
+        } else if (dmin > -R && dmax < R) {
+          const float4* tp4 = reinterpret_cast<const float4*>(sTa[qb] + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 bq = tp4[2 * g];
+            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nl);
+            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nl);
+            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nl);
+            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nl);
+          }
+        } else {
+          const int dl = nb + 4 * hi - qrow;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = dl + (r & 3) + 8 * (r >> 2);
+            s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nl);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nl);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];  // dS = P (dP - delta)   (:713)
+      const bool nmask = nb + 32 > N;
+      const bool cmask = a.causal && (nb + 31 > qr0 + P);
+      if (nmask || cmask) {
+        const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (nb + crow(r, hi) > lim) s[r] = 0.f;
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = pack8<BF16>(s, t2);
+    }
+  };
+  auto generic_iter = [&](const int t) {
+    const uint32_t o_prev = (uint32_t)(((t + 3) & 3) * SLOT), o_cur = (uint32_t)((t & 3) * SLOT), o_next = (uint32_t)(((t + 1) & 3) * SLOT);
+    product_step(o_prev);
+    sync_step(t, o_prev);
+    f32x16 Sn[2], DPn[2];
+    score_step(o_next, Sn, DPn);
+    softmax_generic(t * 32);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      S[qb] = Sn[qb];
+      DP[qb] = DPn[qb];
+    }
+    TRK[0] = rd_tr(o_cur, 0, 0);
+    TRK[1] = rd_tr(o_cur, 0, 1);
+  };
+
+  // One pipelined iteration = 26 MFMA gaps.  Gap g holds, all mutually independent:
+  //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1 (fragment pairs (t2, db) outer, query blocks inner);
+  //          8..15: S^T[qb] of step i+1 (k-steps outer); 16, 17: dP'^T[qb] = -delta; 18..25: dP'^T[qb] += V dO^T
+  //   VALU   elements [32g/26, 32(g+1)/26) of step i (32 per lane, query block e >> 4): x = s*c2 + (cst - L2) | one gap later
+  //          p = exp2(x) | one more: ds = p*dp' | pairs packed to bf16 once both halves exist
+  //   LDS    gaps 0..3 the K^T fragments (t2 = 1) of step i-1; gap 4 the barrier E(i) + the DMA of step i+3; gaps 4..7 the K,
+  //          gaps 12..15 the V row-major fragments of step i+1; gaps 22..25 the K^T fragments (t2 = 0) of step i
+  // SL = the step's ring slot, a compile-time constant: the steady state runs four steps (slots 0..3) per trip, straight-line --
+  // slot offsets are instruction immediates and S / Sn (...) trade registers from one step to the next instead of being copied.
+  constexpr int NG = 26;
+  auto fast_iter = [&]<int SL>(const int t, const float ad0, const float ad1) {
+    constexpr uint32_t o_prev = (uint32_t)(((SL + 3) & 3) * SLOT), o_cur = (uint32_t)(SL * SLOT), o_next = (uint32_t)(((SL + 1) & 3) * SLOT);
+    f32x16 Sn[2], DPn[2];
+    u32x4 DSn[2][2], kf[KK], vf[KK];
+    u32x2 th[2][2], tn[2][2];  // [db][half]: K^T fragments t2 = 1 of step i-1 / t2 = 0 of step i
+    float X[32], Pv[32], Dv[32];
+    auto stA_ = [&]<int E>() { X[E] = asm_fma(S[E >> 4][E & 15], c2, (E >> 4) == 0 ? ad0 : ad1); };
+    auto stB_ = [&]<int E>() { Pv[E] = asm_exp2(X[E]); };
+    auto stC_ = [&]<int E>() { Dv[E] = asm_mul(Pv[E], DP[E >> 4][E & 15]); };
+    auto stD_ = [&]<int E0>() {
+      constexpr int qb = E0 >> 4, r0 = E0 & 15;
+      DSn[qb][r0 >> 3][(r0 & 7) >> 1] = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
+    };
+    static_for<NG>([&](auto gi) {
+      constexpr int g = decltype(gi)::value;
+      // ---- MFMA ----
+      if constexpr (g < 8) {
+        constexpr int p = g >> 1, t2 = p >> 1, db = p & 1, qb = g & 1;
+        u32x4 fr;
+        if constexpr (t2 == 0) fr = TRK[db];
+        else fr = u32x4{th[db][0][0], th[db][0][1], th[db][1][0], th[db][1][1]};
+        mfma_acc_agpr(dq[qb][db], fr, DSB[qb][t2]);
+      } else if constexpr (g < 16) {
+        constexpr int kk = (g - 8) >> 1, qb = g & 1;
+        if constexpr (kk == 0) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
+        else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);
+      } else if constexpr (g < 18) {
+        DPn[g - 16] = mfma32<BF16>(ones4, d3[g - 16], zero16);
+      } else {
+        constexpr int kk = (g - 18) >> 1, qb = g & 1;
+        DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPn[qb]);
+      }
+#if FAT5_B64_PIN
+      __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap: without this it may sink below the gap's VALU work and pair up with the next one)
+#endif
+      // ---- barrier + DMA ----
+      if constexpr (g == 4) sync_step(t, o_prev);
+      // ---- LDS ----
+      if constexpr (g < 4) {
+        constexpr int db = g >> 1, half = g & 1;
+        th[db][half] = lds_rd_tr_half(trA[half][db] + o_prev + (uint32_t)(16 * 2 * D));
+      } else if constexpr (g < 8) {
+        kf[g - 4] = lds_rd128(rmA[g - 4] + o_next);
+      } else if constexpr (g >= 12 && g < 16) {
+        vf[g - 12] = lds_rd128(rmA[g - 12] + o_next + (uint32_t)IMG);
+      } else if constexpr (g >= NG - 4) {
+        constexpr int db = (g - (NG - 4)) >> 1, half = g & 1;
+        tn[db][half] = lds_rd_tr_half(trA[half][db] + o_cur);
+      }
+      // ---- VALU ----
+      {
+        constexpr auto lo = [](int gg) { return gg <= 0 ? 0 : (32 * gg) / NG; };  // first element whose stage A sits in gap gg
+        static_for<lo(g - 2) - lo(g - 3)>([&](auto ei) {  // stage D: pairs whose odd half was multiplied one gap ago
+          constexpr int e = lo(g - 3) + decltype(ei)::value;
+          if constexpr ((e & 1) == 1) stD_.template operator()<e - 1>();
+        });
+        static_for<lo(g - 1) - lo(g - 2)>([&](auto ei) { stC_.template operator()<lo(g - 2) + decltype(ei)::value>(); });
+        static_for<lo(g) - lo(g - 1)>([&](auto ei) { stB_.template operator()<lo(g - 1) + decltype(ei)::value>(); });
+        static_for<lo(g + 1) - lo(g)>([&](auto ei) { stA_.template operator()<lo(g) + decltype(ei)::value>(); });
+        if constexpr (g == NG - 1) {  // the tail of the step (dependent ops back to back)
+          static_for<32 - lo(NG - 1)>([&](auto ei) { stB_.template operator()<lo(NG - 1) + decltype(ei)::value>(); });
+          static_for<32 - lo(NG - 2)>([&](auto ei) { stC_.template operator()<lo(NG - 2) + decltype(ei)::value>(); });
+          static_for<32 - lo(NG - 3)>([&](auto ei) {
+            constexpr int e = lo(NG - 3) + decltype(ei)::value;
+            if constexpr ((e & 1) == 1) stD_.template operator()<e - 1>();
+          });
+        }
+      }
+#if FAT5_B64_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      S[qb] = Sn[qb];
+      DP[qb] = DPn[qb];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = DSn[qb][t2];
+    }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) TRK[db] = u32x4{tn[db][0][0], tn[db][0][1], tn[db][1][0], tn[db][1][1]};
+  };
+
+  if (nt > 0) {
+    score_step(0u, S, DP);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = zero4;
+    TRK[0] = zero4;
+    TRK[1] = zero4;
+    // this wave's 64 rows x the step's 32 keys: all visible and one constant bias?  (wave-uniform)
+    auto classify = [&](const int t, float& cst) {
+      const int nb = t * 32;
+      bool fast = nb + 32 <= N && (!a.causal || nb + 31 <= qw0 + P);
+      cst = 0.f;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        const bool fneg = nb + 31 - qw0 <= -a.R, fpos = nb - (qw0 + 63) >= a.R;
+        fast = fast && (fneg || fpos);
+        cst = fneg ? cst_neg : cst_pos;
+      }
+      return fast;
+    };
+    // (two single-body inner loops, not one loop over `fast ? A : B`: the register allocator keeps one assignment per loop and
+    //  pays its copies only at the few transitions)
+    int t = 0;
+    while (t < nt) {
+      float cst, cst3;
+      // steady state: four steps (ring slots 0..3) per trip; the fast steps of one side are contiguous, so the first and the last
+      // step of a trip decide for all four.  Fast steps that do not fill an aligned trip run the general iteration.
+      while (t + 4 <= nt && (t & 3) == 0 && classify(t, cst) && classify(t + 3, cst3) && cst3 == cst) {
+        const float ad0 = cst + nL2[0], ad1 = cst + nL2[1];
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(t + decltype(si)::value, ad0, ad1); });
+        t += 4;
+      }
+      if (t < nt) {
+        generic_iter(t);
+        ++t;
+      }
+    }
+    product_step((uint32_t)(((nt - 1) & 3) * SLOT));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
+
+  const float scale = a.scale;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = qw0 + 32 * qb + lq;
+    if (qrow < M) {
+      uint16_t* drow = dqb_ + (int64_t)qrow * a.dqs[2];
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 wv;
+          wv[0] = pack2<BF16>(dq[qb][db][4 * g + 0] * scale, dq[qb][db][4 * g + 1] * scale);
+          wv[1] = pack2<BF16>(dq[qb][db][4 * g + 2] * scale, dq[qb][db][4 * g + 3] * scale);
+          *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
+        }
+    }
+  }
+}
+
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_q64_kernel(const AttnArgs a) {
+  attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x);
 }
 
 template <int D, bool BF16, int BIAS>

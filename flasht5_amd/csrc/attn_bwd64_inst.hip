@@ -22,6 +22,22 @@ static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int D, int BIAS>
+static hipError_t launch_q64(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = BwdQ64Cfg<D>::smem(a.R, BIAS);
+  auto kern = attn_bwd_q64_kernel<D, true, BIAS>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+  if (!bf16) return hipErrorInvalidValue;
+  return bias == FAT5_BIAS_RPE1D ? launch_q64<FAT5_INST_D, FAT5_BIAS_RPE1D>(a, grid, s) : launch_q64<FAT5_INST_D, FAT5_BIAS_NONE>(a, grid, s);
+}
+
 hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
   if (!bf16) return hipErrorInvalidValue;
   return bias == FAT5_BIAS_RPE1D ? launch_kv64<FAT5_INST_D, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64<FAT5_INST_D, FAT5_BIAS_NONE>(a, grid, s);

@@ -23,4 +23,6 @@ hipError_t launch_fwd64_d64(const AttnArgs& a, int bf16, int bias, int nw, int g
 // 64 keys per wave, software-pipelined dK/dV body (attn_bwd64.h): bf16, bias none / rpe1d, no packed batches
 hipError_t launch_bwd_kv64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 size_t smem_bwd_kv64_d64(int R, int bias);
+// 64 query rows per wave, software-pipelined dQ body (attn_bwd64.h): same conditions
+hipError_t launch_bwd_q64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 }  // namespace fat5

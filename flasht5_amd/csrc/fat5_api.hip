@@ -41,6 +41,7 @@ int env_int(const char* name, int dflt) {
 struct BwdLayout {
   size_t delta_off, stat2_off, ds_off, drpe_off, scratch_off, total;
   bool kv64;        // dK/dV by the 64-keys-per-wave pipelined body (attn_bwd64.h); the dQ kernel then also writes its statistics
+  bool q64;         // dQ by the 64-rows-per-wave pipelined body (attn_bwd64.h)
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
   int n_nblk;
@@ -194,6 +195,10 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     L.nw_kv = 4;
     L.n_nblk = (p->N + 255) / 256;
   }
+  const int q64_env = env_int("FAT5_BWDQ64", -1);
+  L.q64 = p->D == 64 && p->dtype == FAT5_BF16 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
+          env_int("FAT5_BWDQ_NW", 0) == 0 && (q64_env == 1 || bh * ((p->M + 255) / 256) >= 512);
+  if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;
   // delta: (B,H,M) -- packed batches: (H, total_q), the layout of lse
@@ -239,7 +244,7 @@ static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D) {
   if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
   static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
   static const long fuse_max = [] { const char* e = getenv("FAT5_BWD_FUSE_MAX"); return e ? atol(e) : 4L * 256; }();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
-  return fuse_env && !L.kv64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
+  return fuse_env && !L.kv64 && !L.q64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
 int fat5_attn_bwd_launches(const fat5_attn_params* p) {
@@ -352,6 +357,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     // 1) dQ (+ delta)
     if (stages & FAT5_BWD_DQ) {
       launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
+      if (L.q64) fn = launch_bwd_q64_d64;
       hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)grid_q, stream);
       if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
     }

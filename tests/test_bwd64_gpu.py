@@ -1,6 +1,7 @@
-"""GPU parity tests of the long-sequence dK/dV body (csrc/attn_bwd64.h: 64 keys per wave, software-pipelined query-step loop,
-4-slot LDS ring, AGPR accumulators) -- forced with FAT5_BWD64=1 at sizes the oracle finishes in seconds; at (4,12,8192,64)
-the default dispatch picks it by itself (test_attention_gpu.py::test_cfg3_properties_s8192)."""
+"""GPU parity tests of the long-sequence backward bodies (csrc/attn_bwd64.h: dK/dV with 64 keys per wave, dQ with 64 query rows
+per wave; software-pipelined step loops, 4-slot LDS rings, AGPR accumulators) -- forced with FAT5_BWD64=1 / FAT5_BWDQ64=1 at sizes
+the oracle finishes in seconds; at (4,12,8192,64) the default dispatch picks them by itself
+(test_attention_gpu.py::test_cfg3_properties_s8192)."""
 import pytest
 import torch
 
@@ -14,6 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def force_bwd64(monkeypatch):
     monkeypatch.setenv("FAT5_BWD64", "1")
+    monkeypatch.setenv("FAT5_BWDQ64", "1")
 
 
 def _grads(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
@@ -83,12 +85,13 @@ def test_bwd64_agrees_with_32key_body(monkeypatch):
     outs = []
     for f in ("0", "1"):
         monkeypatch.setenv("FAT5_BWD64", f)
+        monkeypatch.setenv("FAT5_BWDQ64", f)
         plan = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=pe.rpe1d_from_table(table, True, 32, 128), radius=128)
         plan.forward()
         plan.backward()
         torch.cuda.synchronize()
-        outs.append((plan.dk.float().clone(), plan.dv.float().clone(), plan.dbias.clone()))
-    for i in (0, 1):
+        outs.append((plan.dk.float().clone(), plan.dv.float().clone(), plan.dbias.clone(), plan.dq.float().clone()))
+    for i in (0, 1, 3):
         assert (outs[0][i] - outs[1][i]).abs().max().item() <= 2.0 ** -6 * max(1.0, outs[0][i].abs().max().item()), i
     # (far bins: this body sums the bf16-rounded dS, the 32-key body the unrounded ones; ~1e6 terms each)
     assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-2 * max(1.0, outs[0][2].abs().max().item())
@@ -106,15 +109,19 @@ def test_bwd64_unit_range_shards_are_bit_identical(monkeypatch):
     full.forward(); full.backward()
     torch.cuda.synchronize()
     dk = torch.zeros_like(full.dk)
+    dq = torch.zeros_like(full.dq)
     acc = torch.zeros_like(full.dbias)
     for r in range(2):
         part = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=rpe1d, radius=128, units=unit_range(B, H, 2, r))
         part.dk.zero_()
+        part.dq.zero_()
         part.forward(); part.backward()
         torch.cuda.synchronize()
         dk += part.dk
+        dq += part.dq
         acc += part.dbias
     assert torch.equal(dk, full.dk)
+    assert torch.equal(dq, full.dq)
     assert (acc - full.dbias).abs().max().item() <= 1e-4 * max(1.0, full.dbias.abs().max().item())
 
 
@@ -122,5 +129,5 @@ def test_bwd64_deterministic():
     q, k, v, do, table, _ = _rpe_case(1, 4, 2048, 2048, torch.bfloat16, False, True, 128, seed=9)
     a = _grads(q, k, v, do, False, 0.125, table)
     b = _grads(q, k, v, do, False, 0.125, table)
-    for key in ("dk", "dv", "dtable"):
+    for key in ("dq", "dk", "dv", "dtable"):
         assert torch.equal(a[key], b[key]), key
