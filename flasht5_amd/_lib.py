@@ -99,6 +99,30 @@ def load():
     return lib
 
 
+_native = False  # (False: not looked up yet; None: unavailable / disabled)
+
+
+def native():
+    """The C++ host path (csrc/torch_binding.cpp -> lib/_fat5_torch.so: at::Tensor in / out, C++ autograd functions on the C ABI),
+    or None when it is not built or FAT5_TORCH_BINDING=0 -- the ctypes path below is then used for eager calls as well (same
+    kernels, ~10x the host time per call)."""
+    global _native
+    if _native is False:
+        _native = None
+        if os.environ.get("FAT5_TORCH_BINDING", "1") != "0" and not _VAR:
+            path = os.path.join(_HERE, "lib", "_fat5_torch.so")
+            if os.path.exists(path):
+                import importlib.util
+                load()  # (libfat5.so first: same image for both paths)
+                spec = importlib.util.spec_from_file_location("_fat5_torch", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.sizeof_attn_params() != ctypes.sizeof(AttnParams):
+                    raise ImportError("lib/_fat5_torch.so was built against another include/fat5.h: rebuild (python flasht5_amd/build.py)")
+                _native = mod
+    return _native
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().fat5_last_error().decode("utf-8", "replace")

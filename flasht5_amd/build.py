@@ -76,5 +76,38 @@ def build_lib(force=False, verbose=True):
     return LIB
 
 
+TORCH_EXT = os.path.join(HERE, "lib", "_fat5_torch.so")
+
+
+def build_torch_binding(force=False, verbose=True):
+    """The native host path (csrc/torch_binding.cpp: at::Tensor -> C ABI, C++ autograd functions) as a Python extension module,
+    compiled with g++ against the installed torch headers (host code only; it links libfat5.so through $ORIGIN)."""
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(INCLUDE, "fat5.h")))
+    if not force and os.path.exists(TORCH_EXT) and os.path.getmtime(TORCH_EXT) >= newest:
+        return TORCH_EXT
+    import sysconfig
+    import torch
+    import pybind11
+    tdir = os.path.dirname(torch.__file__)
+    if verbose:
+        print("[fat5 build] compiling the torch binding (g++, ~1-2 min) ...", flush=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_fat5_torch",
+           "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include(), "-I", INCLUDE,
+           src, "-o", TORCH_EXT, "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-ltorch_python", "-L", os.path.dirname(LIB), "-l:" + os.path.basename(LIB),
+           "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"torch binding failed to build:\n{' '.join(cmd)}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
+    if verbose:
+        print(f"[fat5 build] linked {TORCH_EXT}", flush=True)
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     build_lib(force="--force" in sys.argv)
+    if "--no-torch" not in sys.argv and not VARIANT:
+        build_torch_binding(force="--force" in sys.argv)

@@ -1,0 +1,230 @@
+// Native host path of the attention operators: at::Tensor in / out, C++ autograd functions, straight onto the C ABI of
+// libfat5.so (include/fat5.h).  Same behaviour as the ctypes path in flasht5_amd/flash_attention_v2_bias.py (which stays the
+// reference implementation of the host logic and the path torch.compile traces); this one exists because an eager call through
+// Python + ctypes costs ~100 us of host time per direction -- several times the S = 512 kernels -- most of it interpreter work
+// and, in the backward, the hand-over between the autograd engine's device thread and the GIL.
+//
+// Mirrors reference src/model/ops/flash_attention_v2_bias.py:27-80 (fwd op), :91-217 (bwd op), :228-271 (autograd function).
+// Built by flasht5_amd/build.py into flasht5_amd/lib/_fat5_torch.so (g++, links libfat5.so; no device code here).
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "fat5.h"
+
+namespace {
+
+using at::Tensor;
+using OptT = c10::optional<Tensor>;
+
+bool kernel_ready(const Tensor& t) {  // last-dim stride 1, 16-byte aligned base, other strides multiples of 8 elements
+  if (t.stride(-1) != 1 || (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) != 0) return false;
+  for (int64_t i = 0; i + 1 < t.dim(); ++i)
+    if (t.stride(i) % 8 != 0) return false;
+  return true;
+}
+Tensor prep(const Tensor& t) { return kernel_ready(t) ? t : t.contiguous(); }
+Tensor empty_like_ready(const Tensor& t) {
+  Tensor e = at::empty_like(t);
+  return kernel_ready(e) ? e : at::empty(t.sizes(), t.options());
+}
+void set3(int64_t (&d)[3], const Tensor& t) {
+  d[0] = t.stride(0);
+  d[1] = t.stride(1);
+  d[2] = t.stride(2);
+}
+int dtype_code(const Tensor& t) {
+  if (t.scalar_type() == at::kHalf) return FAT5_F16;
+  if (t.scalar_type() == at::kBFloat16) return FAT5_BF16;
+  TORCH_CHECK(false, "q, k, v must share dtype float16 or bfloat16");
+}
+void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (fat5 status ", rc, "): ", fat5_last_error()); }
+
+void base_params(fat5_attn_params& p, const Tensor& q, const Tensor& k, const Tensor& v, bool causal, double scale) {
+  memset(&p, 0, sizeof(p));
+  p.B = (int)q.size(0); p.H = (int)q.size(1); p.M = (int)q.size(2); p.N = (int)k.size(2); p.D = (int)q.size(3);
+  p.dtype = dtype_code(q);
+  p.causal = causal ? 1 : 0;
+  p.sm_scale = (float)scale;
+  p.q = q.data_ptr(); p.k = k.data_ptr(); p.v = v.data_ptr();
+  set3(p.q_stride, q); set3(p.k_stride, k); set3(p.v_stride, v);
+}
+void set_bias(fat5_attn_params& p, const Tensor& bias) {  // broadcast (1|B, 1|H, M, N) via zero strides (reference :45-52)
+  p.bias_mode = FAT5_BIAS_DENSE;
+  p.bias = bias.data_ptr();
+  p.bias_stride[0] = bias.size(0) == 1 ? 0 : bias.stride(0);
+  p.bias_stride[1] = bias.size(1) == 1 ? 0 : bias.stride(1);
+  p.bias_stride[2] = bias.stride(2);
+}
+
+// backward scratch: one growing buffer per (device, stream) -- launches on one stream are ordered
+Tensor workspace(size_t nbytes, const Tensor& like, hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, Tensor> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto key = std::make_pair((int)like.get_device(), (void*)stream);
+  auto it = cache.find(key);
+  if (it == cache.end() || (size_t)it->second.numel() < nbytes) {
+    Tensor ws = at::empty({(int64_t)std::max<size_t>(nbytes, 256)}, like.options().dtype(at::kByte));
+    cache[key] = ws;
+    return ws;
+  }
+  return it->second;
+}
+
+std::tuple<Tensor, Tensor> attn_fwd(const Tensor& q_, const Tensor& k_, const Tensor& v_, const OptT& bias_, const OptT& rpe1d,
+                                    int64_t radius, bool causal, double scale) {
+  Tensor q = prep(q_), k = prep(k_), v = prep(v_);
+  Tensor o = empty_like_ready(q);  // reference :58
+  Tensor L = at::empty({q.size(0), q.size(1), q.size(2)}, q.options().dtype(at::kFloat));  // reference :59
+  fat5_attn_params p;
+  base_params(p, q, k, v, causal, scale);
+  p.o = o.data_ptr(); p.lse = (float*)L.data_ptr(); set3(p.o_stride, o);
+  Tensor bias;
+  if (bias_.has_value() && bias_->defined()) {
+    bias = bias_->stride(-1) == 1 ? *bias_ : bias_->contiguous();
+    set_bias(p, bias);
+  } else if (rpe1d.has_value() && rpe1d->defined()) {
+    p.bias_mode = FAT5_BIAS_RPE1D; p.rpe1d = (const float*)rpe1d->data_ptr(); p.rpe_radius = (int)radius;
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());  // (ROCm builds of torch call the device type "cuda")
+  check_rc(fat5_attn_fwd(&p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.get_device()).stream()), "fat5_attn_fwd");
+  return {o, L};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> attn_bwd(const Tensor& o_, const Tensor& do_, const Tensor& q_, const Tensor& k_,
+                                                    const Tensor& v_, const OptT& bias_, const OptT& rpe1d, int64_t radius,
+                                                    const Tensor& L, bool causal, double scale, bool need_dbias,
+                                                    const OptT& bucket, int64_t num_buckets) {
+  Tensor q = prep(q_), k = prep(k_), v = prep(v_), o = prep(o_), dout = prep(do_);
+  Tensor dq = empty_like_ready(q), dk = empty_like_ready(k), dv = empty_like_ready(v);  // reference :140-141,:191
+  fat5_attn_params p;
+  base_params(p, q, k, v, causal, scale);
+  p.o = o.data_ptr(); p.lse = (float*)L.data_ptr(); set3(p.o_stride, o);
+  p.dout = dout.data_ptr(); p.dq = dq.data_ptr(); p.dk = dk.data_ptr(); p.dv = dv.data_ptr();
+  set3(p.do_stride, dout); set3(p.dq_stride, dq); set3(p.dk_stride, dk); set3(p.dv_stride, dv);
+  Tensor bias, dbias;
+  if (bias_.has_value() && bias_->defined()) {
+    bias = bias_->stride(-1) == 1 ? *bias_ : bias_->contiguous();
+    set_bias(p, bias);
+    if (need_dbias) {
+      dbias = at::empty(bias.sizes(), bias.options());  // shape / dtype of bias (:149,:224)
+      p.dbias = dbias.data_ptr(); p.dbias_batch = (int)bias.size(0); p.dbias_heads = (int)bias.size(1);
+    }
+  } else if (rpe1d.has_value() && rpe1d->defined()) {
+    p.bias_mode = FAT5_BIAS_RPE1D; p.rpe1d = (const float*)rpe1d->data_ptr(); p.rpe_radius = (int)radius;
+    if (need_dbias) {
+      if (bucket.has_value() && bucket->defined()) {  // table gradient straight from the reduction launch
+        dbias = at::empty({num_buckets, q.size(1)}, q.options().dtype(at::kFloat));
+        p.rpe_bucket = (const int32_t*)bucket->data_ptr(); p.drpe_table = (float*)dbias.data_ptr(); p.rpe_num_buckets = (int)num_buckets;
+      } else {
+        dbias = at::empty_like(*rpe1d);
+        p.drpe1d = (float*)dbias.data_ptr();
+      }
+    }
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());  // (ROCm builds of torch call the device type "cuda")
+  hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(q.get_device()).stream();
+  Tensor ws = workspace(fat5_attn_bwd_workspace_bytes(&p), q, stream);
+  p.workspace = ws.data_ptr(); p.workspace_bytes = (size_t)ws.numel();
+  check_rc(fat5_attn_bwd(&p, stream), "fat5_attn_bwd");
+  return {dq, dk, dv, dbias};
+}
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+// FlashAttentionAdditiveBias (reference :228-271): o = attention(q, k, v, bias); gradients for q, k, v, bias
+struct BiasFn : public torch::autograd::Function<BiasFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const OptT& bias, bool causal, double scale) {
+    auto [o, L] = attn_fwd(q, k, v, bias, c10::nullopt, 0, causal, scale);
+    const bool has_bias = bias.has_value() && bias->defined();
+    ctx->save_for_backward({q, k, v, has_bias ? *bias : Tensor(), o, L});
+    ctx->saved_data["causal"] = causal;
+    ctx->saved_data["scale"] = scale;
+    return o;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool has_bias = s[3].defined();
+    auto [dq, dk, dv, ds] = attn_bwd(s[4], grads[0], s[0], s[1], s[2], has_bias ? OptT(s[3]) : OptT(), c10::nullopt, 0, s[5],
+                                     ctx->saved_data["causal"].toBool(), ctx->saved_data["scale"].toDouble(), has_bias,
+                                     c10::nullopt, 0);
+    return {dq, dk, dv, has_bias ? ds : Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// RPE mode on the (num_buckets, H) table: the kernels read the (H, 2R+1) generator `rpe1d` built (and cached) by the caller;
+// the table gradient comes scattered into buckets from the reduction launch (`bucket`: (2R+1,) int32)
+struct RpeTableFn : public torch::autograd::Function<RpeTableFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& table,
+                        const Tensor& rpe1d, const Tensor& bucket, int64_t radius, int64_t num_buckets, bool causal, double scale) {
+    auto [o, L] = attn_fwd(q, k, v, c10::nullopt, rpe1d, radius, causal, scale);
+    ctx->save_for_backward({q, k, v, o, L, rpe1d, bucket});
+    ctx->saved_data["causal"] = causal;
+    ctx->saved_data["scale"] = scale;
+    ctx->saved_data["radius"] = radius;
+    ctx->saved_data["num_buckets"] = num_buckets;
+    ctx->saved_data["tdtype"] = (int64_t)table.scalar_type();
+    return o;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool need = ctx->needs_input_grad(3);
+    auto [dq, dk, dv, dt] = attn_bwd(s[3], grads[0], s[0], s[1], s[2], c10::nullopt, s[5], ctx->saved_data["radius"].toInt(), s[4],
+                                     ctx->saved_data["causal"].toBool(), ctx->saved_data["scale"].toDouble(), need, s[6],
+                                     ctx->saved_data["num_buckets"].toInt());
+    if (need) dt = dt.to((at::ScalarType)ctx->saved_data["tdtype"].toInt());
+    return {dq, dk, dv, need ? dt : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// RPE mode on the 1-D generator itself (differentiable in rpe1d; `r1` = its detached fp32 contiguous form)
+struct Rpe1dFn : public torch::autograd::Function<Rpe1dFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& rpe1d, const Tensor& r1,
+                        int64_t radius, bool causal, double scale) {
+    auto [o, L] = attn_fwd(q, k, v, c10::nullopt, r1, radius, causal, scale);
+    ctx->save_for_backward({q, k, v, o, L, r1});
+    ctx->saved_data["causal"] = causal;
+    ctx->saved_data["scale"] = scale;
+    ctx->saved_data["radius"] = radius;
+    ctx->saved_data["rdtype"] = (int64_t)rpe1d.scalar_type();
+    return o;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const bool need = ctx->needs_input_grad(3);
+    auto [dq, dk, dv, d1] = attn_bwd(s[3], grads[0], s[0], s[1], s[2], c10::nullopt, s[5], ctx->saved_data["radius"].toInt(), s[4],
+                                     ctx->saved_data["causal"].toBool(), ctx->saved_data["scale"].toDouble(), need, c10::nullopt, 0);
+    if (need) d1 = d1.to((at::ScalarType)ctx->saved_data["rdtype"].toInt());
+    return {dq, dk, dv, need ? d1 : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor bias_apply(const Tensor& q, const Tensor& k, const Tensor& v, const OptT& bias, bool causal, double scale) {
+  return BiasFn::apply(q, k, v, bias, causal, scale);
+}
+Tensor rpe_table_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& table, const Tensor& rpe1d, const Tensor& bucket,
+                       int64_t radius, int64_t num_buckets, bool causal, double scale) {
+  return RpeTableFn::apply(q, k, v, table, rpe1d, bucket, radius, num_buckets, causal, scale);
+}
+Tensor rpe1d_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& rpe1d, const Tensor& r1, int64_t radius, bool causal,
+                   double scale) {
+  return Rpe1dFn::apply(q, k, v, rpe1d, r1, radius, causal, scale);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_fat5_torch, m) {
+  m.doc() = "native host path of the flasht5_amd attention operators (at::Tensor -> libfat5.so C ABI)";
+  m.def("attn_fwd", &attn_fwd);
+  m.def("attn_bwd", &attn_bwd);
+  m.def("bias_apply", &bias_apply);
+  m.def("rpe_table_apply", &rpe_table_apply);
+  m.def("rpe1d_apply", &rpe1d_apply);
+  m.def("sizeof_attn_params", []() { return (int64_t)sizeof(fat5_attn_params); });
+}

@@ -248,7 +248,22 @@ def flash_attention_v2_bias(q, k, v, bias, causal=False, sm_scale=None):
 
     q: (B, H, M, D); k, v: (B, H, N, D) (strided views are fine); bias: (B|1, H|1, M, N) or None.
     Differentiable in q, k, v and bias.  Returns o: (B, H, M, D)."""
-    return FlashAttentionAdditiveBias.apply(q, k, v, bias, causal, sm_scale)
+    nat = None if _tracing() else _lib.native()
+    if nat is None:
+        return FlashAttentionAdditiveBias.apply(q, k, v, bias, causal, sm_scale)
+    # eager: the same checks, then the C++ autograd function (csrc/torch_binding.cpp) straight onto the C ABI
+    D = q.shape[-1]
+    assert D == k.shape[-1] == v.shape[-1]
+    assert D in {16, 32, 64, 128}
+    _check_inputs(q, k, v)
+    if bias is not None:
+        _check_bias(bias, q, k)
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    if D == 16:
+        q, k, v = _pad16((q, k, v))
+    o = nat.bias_apply(q, k, v, bias, bool(causal), float(sm_scale))
+    return o[..., :16] if D == 16 else o
 
 
 # ------------------------------------------------------------------------------------------------
@@ -366,7 +381,26 @@ def flash_attention_v2_rpe(q, k, v, rpe_table, bidirectional=True, num_buckets=3
     (`RelativePositionalEncoding.relative_attention_bias.weight` of the reference).  Equivalent to
     `flash_attention_v2_bias(q, k, v, compute_bias(table, M, N), ...)` with O(S) memory; differentiable in
     q, k, v and the table."""
-    return FlashAttentionRPE.apply(q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale)
+    nat = None if _tracing() else _lib.native()
+    if nat is None:
+        return FlashAttentionRPE.apply(q, k, v, rpe_table, bidirectional, num_buckets, max_distance, causal, sm_scale)
+    D = q.shape[-1]
+    assert D in {16, 32, 64, 128}
+    _check_inputs(q, k, v)
+    R = _pe.rpe_radius(max_distance)
+    if R > _lib.MAX_RPE_RADIUS:
+        raise ValueError(f"max_distance {max_distance} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
+    if rpe_table.shape != (num_buckets, q.shape[1]):
+        raise ValueError("rpe_table must be (num_buckets, n_heads)")
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    if D == 16:
+        q, k, v = _pad16((q, k, v))
+    rpe1d = _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance)
+    _check_rpe1d(rpe1d, q.shape[1], R, q.device)
+    idx = _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device)
+    o = nat.rpe_table_apply(q, k, v, rpe_table, rpe1d, idx, R, int(num_buckets), bool(causal), float(sm_scale))
+    return o[..., :16] if D == 16 else o
 
 
 class FlashAttentionRPE1D(torch.autograd.Function):
@@ -408,7 +442,25 @@ class FlashAttentionRPE1D(torch.autograd.Function):
 
 def flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, causal=False, sm_scale=None):
     """Attention with the Toeplitz bias generated in-kernel from `rpe1d (H, 2*radius+1)` (see FlashAttentionRPE1D)."""
-    return FlashAttentionRPE1D.apply(q, k, v, rpe1d, int(radius), causal, sm_scale)
+    nat = None if _tracing() else _lib.native()
+    if nat is None:
+        return FlashAttentionRPE1D.apply(q, k, v, rpe1d, int(radius), causal, sm_scale)
+    D = q.shape[-1]
+    radius = int(radius)
+    assert D in {16, 32, 64, 128}
+    _check_inputs(q, k, v)
+    if radius > _lib.MAX_RPE_RADIUS:
+        raise ValueError(f"radius {radius} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
+    if rpe1d.shape != (q.shape[1], 2 * radius + 1):
+        raise ValueError("rpe1d must be (n_heads, 2 * radius + 1)")
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    if D == 16:
+        q, k, v = _pad16((q, k, v))
+    r1 = rpe1d.detach().float().contiguous()
+    _check_rpe1d(r1, q.shape[1], radius, q.device)
+    o = nat.rpe1d_apply(q, k, v, rpe1d, r1, radius, bool(causal), float(sm_scale))
+    return o[..., :16] if D == 16 else o
 
 
 # ------------------------------------------------------------------------------------------------

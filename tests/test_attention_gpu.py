@@ -842,3 +842,40 @@ def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatc
     # same terms, same rounding, same order as the staged path: equal up to one rounding of the sum
     assert maxdiff(db, res["0"][3]) <= 2.0 ** -7 * max(1.0, ref["db"].abs().max().item())
     assert torch.equal(dq, res["0"][0]) and torch.equal(dk, res["0"][1]) and torch.equal(dv, res["0"][2])
+
+
+def test_native_host_path_equals_ctypes_path():
+    """the C++ host path (csrc/torch_binding.cpp: C++ autograd functions on the C ABI) and the Python / ctypes path run the same
+    launches: outputs and gradients are bit-identical, for the dense-bias, table and 1-D generator entry points"""
+    from flasht5_amd import _lib, flash_attention_v2_bias, flash_attention_v2_rpe, flash_attention_v2_rpe1d
+    from flasht5_amd.flash_attention_v2_bias import FlashAttentionAdditiveBias, FlashAttentionRPE, FlashAttentionRPE1D
+    from flasht5_amd import positional_encoding as pe
+    assert _lib.native() is not None, "lib/_fat5_torch.so missing: python flasht5_amd/build.py"
+    q, k, v, b, do = make_inputs(2, 3, 200, 264, 64, torch.bfloat16, "1h", seed=21, strided=True)
+    table = (torch.randn(32, 3, generator=torch.Generator().manual_seed(3)) * 0.5).cuda()
+
+    def grads(fn, extra):
+        leaves = [t.detach().clone().requires_grad_() for t in (q, k, v, extra)]
+        o = fn(*leaves)
+        return [o.detach()] + list(torch.autograd.grad(o, leaves, do))
+
+    pairs = [
+        (lambda q_, k_, v_, b_: flash_attention_v2_bias(q_, k_, v_, b_, True, 0.125),
+         lambda q_, k_, v_, b_: FlashAttentionAdditiveBias.apply(q_, k_, v_, b_, True, 0.125), b),
+        (lambda q_, k_, v_, t_: flash_attention_v2_rpe(q_, k_, v_, t_, True, 32, 128, False, 0.125),
+         lambda q_, k_, v_, t_: FlashAttentionRPE.apply(q_, k_, v_, t_, True, 32, 128, False, 0.125), table),
+        (lambda q_, k_, v_, r_: flash_attention_v2_rpe1d(q_, k_, v_, r_, 128, False, 0.125),
+         lambda q_, k_, v_, r_: FlashAttentionRPE1D.apply(q_, k_, v_, r_, 128, False, 0.125), pe.rpe1d_from_table(table)),
+    ]
+    for native_fn, ctypes_fn, extra in pairs:
+        for x, y in zip(grads(native_fn, extra), grads(ctypes_fn, extra)):
+            assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+    # no-bias call, D = 16 (zero-padded on the way in, sliced on the way out), grads flow through the pad
+    q16, k16, v16, _, do16 = make_inputs(1, 2, 96, 96, 16, torch.bfloat16, None, seed=4)
+    ln = [t.detach().clone().requires_grad_() for t in (q16, k16, v16)]
+    lc = [t.detach().clone().requires_grad_() for t in (q16, k16, v16)]
+    on = flash_attention_v2_bias(*ln, None, False, None)
+    oc = FlashAttentionAdditiveBias.apply(*lc, None, False, None)
+    assert on.shape == (1, 2, 96, 16) and torch.equal(on, oc)
+    for x, y in zip(torch.autograd.grad(on, ln, do16), torch.autograd.grad(oc, lc, do16)):
+        assert torch.equal(x, y)

@@ -197,3 +197,14 @@ def test_fake_impls_trace_without_a_gpu():
         assert losses.shape == (16,) and losses.dtype == torch.float32 and z.shape == (16,) and lse.shape == (16,)
         dl = torch.ops.fat5.cross_entropy_bwd(losses, logits, lse, labels, False, 0.0, 1.0, 1e-4, -100)
         assert dl.shape == logits.shape and dl.dtype == logits.dtype
+
+
+def test_native_torch_binding_loads_and_exports():
+    """lib/_fat5_torch.so (the C++ host path) loads next to libfat5.so and exports its entry points (no GPU: nothing is launched)"""
+    from flasht5_amd import _lib
+    nat = _lib.native()
+    assert nat is not None, "lib/_fat5_torch.so missing: python flasht5_amd/build.py"
+    for name in ("attn_fwd", "attn_bwd", "bias_apply", "rpe_table_apply", "rpe1d_apply"):
+        assert callable(getattr(nat, name))
+    import ctypes
+    assert nat.sizeof_attn_params() == ctypes.sizeof(_lib.AttnParams)
