@@ -452,8 +452,13 @@ int fat5_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t
 }
 
 static int rms_bwd_blocks(int64_t rows) {
-  int64_t b = (rows + 7) / 8;
-  return (int)(b < 256 ? b : 256);
+  // persistent 8-wave workgroups, one row per wave and trip: two (FAT5_RMS_BWD_BLOCKS per chip) per CU keep enough 16-byte
+  // loads in flight to cover the HBM latency (one per CU: 4.5 TB/s at (65536, 1024))
+  // (measured: 256 / 384 / 512 / 768 workgroups -> 4.48 / 4.98 / 5.08 / 4.78 TB/s; small inputs keep >= 2 rows per wave so that
+  //  the dw reduction over the workgroups' partial sums stays short)
+  static const int cap = env_int("FAT5_RMS_BWD_BLOCKS", 512);
+  int64_t b = (rows + 15) / 16;
+  return (int)(b < cap ? b : cap);
 }
 size_t fat5_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t n) {
   return (size_t)rms_bwd_blocks(rows) * (size_t)n * sizeof(float);
