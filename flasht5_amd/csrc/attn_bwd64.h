@@ -43,14 +43,20 @@ FAT5_DEV float asm_mul(float a, float b) {
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// acc += w.lo * o.lo + w.hi * o.hi  (two bf16 lanes of a packed word)
-FAT5_DEV void asm_dot2c_bf16(float& acc, uint32_t w, uint32_t o) { asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o)); }
+// acc += w.lo * o.lo + w.hi * o.hi  (the two 16-bit lanes of a packed word)
+template <bool BF16>
+FAT5_DEV void asm_dot2c(float& acc, uint32_t w, uint32_t o) {
+  if constexpr (BF16) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o));
+  else asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o));
+}
 // acc += A . B with the accumulator tuple in AGPRs.  The dK^T / dV^T accumulators (128 registers) are touched by nothing but
 // MFMAs: hipcc's VGPR-form MFMA selection would keep them in VGPRs and spill everything else through v_accvgpr moves.
 // No hazard padding is generated for asm: same-accumulator MFMAs need none, A / B come from LDS reads (waitcnt is inserted
 // for asm operands) or from VALU results that are many instructions old; the epilogue pads before it reads the tuples.
+template <bool BF16>
 FAT5_DEV void mfma_acc_agpr(f32x16& acc, const u32x4 A, const u32x4 B) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+  if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 FAT5_DEV f32x2 asm_pk_mul(f32x2 a, f32x2 b) {
@@ -83,7 +89,7 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 
 template <int D, bool BF16, int BIAS>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
-  static_assert(D == 64 && BF16 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bf16, bias none / rpe1d");
+  static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
   using Cfg = Bwd64Cfg<D>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -293,9 +299,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       for (int db = 0; db < DB; ++db) {
         const u32x4 dot = rd_tr(so + (uint32_t)IMG, t2, db), qt = rd_tr(so, t2, db);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr(dv[kb][db], dot, PB[kb][t2]);
+        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr<BF16>(dv[kb][db], dot, PB[kb][t2]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr(dk[kb][db], qt, DS[kb][t2]);
+        for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr<BF16>(dk[kb][db], qt, DS[kb][t2]);
       }
   };
 
@@ -447,7 +453,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       PBn[kb][t2][wd] = asm_cvt_pk<BF16>(Pv[E0], Pv[E0 + 1]);
       const uint32_t dsw = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
       DSn[kb][t2][wd] = dsw;
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) asm_dot2c_bf16(facc, dsw, one2s);
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) asm_dot2c<BF16>(facc, dsw, one2s);
     };
     static_for<32>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
@@ -457,8 +463,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         u32x4 fr;
         if constexpr (p == 0) fr = wh == 0 ? TRD : TRQ;
         else fr = u32x4{trh[p][wh][0][0], trh[p][wh][0][1], trh[p][wh][1][0], trh[p][wh][1][1]};
-        if constexpr (wh == 0) mfma_acc_agpr(dv[kb][db], fr, PB[kb][t2]);
-        else mfma_acc_agpr(dk[kb][db], fr, DS[kb][t2]);
+        if constexpr (wh == 0) mfma_acc_agpr<BF16>(dv[kb][db], fr, PB[kb][t2]);
+        else mfma_acc_agpr<BF16>(dk[kb][db], fr, DS[kb][t2]);
       } else if constexpr (g < 24) {
         constexpr int kk = (g - 16) >> 1, kb = g & 1;
         if constexpr (FAT5_B64_NLC && kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], NL);
@@ -724,7 +730,7 @@ struct BwdQ64Cfg {
 
 template <int D, bool BF16, int BIAS>
 FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
-  static_assert(D == 64 && BF16 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bf16, bias none / rpe1d");
+  static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
   using Cfg = BwdQ64Cfg<D>;
   constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -754,7 +760,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   u32x4 qf[2][KK], dof[2][KK];
   float nL2[2];
   // dP'^T = V dO^T - delta: the accumulator's initial value comes from one extra MFMA per query block, ones(32 x 16) x D3 with
-  // D3[j][q] = the j-th bf16 piece of -delta_q (hi + mid + lo: 24 bits, exact to fp32) -- a 16-register broadcast of -delta per
+  // D3[j][q] = the j-th 16-bit piece of -delta_q (hi + mid + lo: 24+ bits, exact to fp32) -- a 16-register broadcast of -delta per
   // block as the C operand would hold 32 VGPRs for the whole loop (C and D of an MFMA share one register file)
   u32x4 d3[2];
 #pragma unroll
@@ -784,11 +790,11 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     }
     {
       const float nd = -delta;
-      const uint32_t p0 = pack2<BF16>(nd, 0.f) & 0xffffu;
-      const float r1 = nd - __uint_as_float(p0 << 16);
-      const uint32_t p1 = pack2<BF16>(r1, 0.f) & 0xffffu;
-      const float r2 = r1 - __uint_as_float(p1 << 16);
-      const uint32_t p2 = pack2<BF16>(r2, 0.f) & 0xffffu;
+      const uint32_t p0 = to16<BF16>(nd);
+      const float r1 = nd - cvt16<BF16>((uint16_t)p0);
+      const uint32_t p1 = to16<BF16>(r1);
+      const float r2 = r1 - cvt16<BF16>((uint16_t)p1);
+      const uint32_t p2 = to16<BF16>(r2);
       d3[qb] = hi == 0 ? u32x4{p0 | (p1 << 16), p2, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};  // (k-index 8*hi + j of the B operand)
     }
   }
@@ -900,7 +906,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       for (int db = 0; db < DB; ++db) {
         const u32x4 kt = rd_tr(so, t2, db);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) mfma_acc_agpr(dq[qb][db], kt, DSB[qb][t2]);
+        for (int qb = 0; qb < 2; ++qb) mfma_acc_agpr<BF16>(dq[qb][db], kt, DSB[qb][t2]);
       }
   };
   // general softmax stage of the key step at nb: S, DP -> DSB
@@ -1001,7 +1007,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         u32x4 fr;
         if constexpr (t2 == 0) fr = TRK[db];
         else fr = u32x4{th[db][0][0], th[db][0][1], th[db][1][0], th[db][1][1]};
-        mfma_acc_agpr(dq[qb][db], fr, DSB[qb][t2]);
+        mfma_acc_agpr<BF16>(dq[qb][db], fr, DSB[qb][t2]);
       } else if constexpr (g < 16) {
         constexpr int kk = (g - 8) >> 1, qb = g & 1;
         if constexpr (kk == 0) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);

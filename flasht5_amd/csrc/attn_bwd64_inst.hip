@@ -10,10 +10,10 @@
 
 namespace fat5 {
 
-template <int D, int BIAS>
+template <int D, bool BF16, int BIAS>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = Bwd64Cfg<D>::smem(a.R, BIAS);
-  auto kern = attn_bwd_kv64_kernel<D, true, BIAS>;
+  auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -22,10 +22,10 @@ static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int D, int BIAS>
+template <int D, bool BF16, int BIAS>
 static hipError_t launch_q64(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = BwdQ64Cfg<D>::smem(a.R, BIAS);
-  auto kern = attn_bwd_q64_kernel<D, true, BIAS>;
+  auto kern = attn_bwd_q64_kernel<D, BF16, BIAS>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -34,13 +34,15 @@ static hipError_t launch_q64(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
-  if (!bf16) return hipErrorInvalidValue;
-  return bias == FAT5_BIAS_RPE1D ? launch_q64<FAT5_INST_D, FAT5_BIAS_RPE1D>(a, grid, s) : launch_q64<FAT5_INST_D, FAT5_BIAS_NONE>(a, grid, s);
+  if (bias == FAT5_BIAS_RPE1D)
+    return bf16 ? launch_q64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_q64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
+  return bf16 ? launch_q64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_q64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
 }
 
 hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
-  if (!bf16) return hipErrorInvalidValue;
-  return bias == FAT5_BIAS_RPE1D ? launch_kv64<FAT5_INST_D, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64<FAT5_INST_D, FAT5_BIAS_NONE>(a, grid, s);
+  if (bias == FAT5_BIAS_RPE1D)
+    return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
+  return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
 }
 size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }
 

@@ -188,7 +188,7 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   // long sequences: 64 keys per wave, software-pipelined (attn_bwd64.h) once its 256-key workgroups (one per CU) cover the
   // chip twice (FAT5_BWD64=0 disables, =1 forces wherever the body applies)
   const int b64_env = env_int("FAT5_BWD64", -1);
-  L.kv64 = p->D == 64 && p->dtype == FAT5_BF16 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
+  L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
            env_int("FAT5_BWDKV_NW", 0) == 0 && (b64_env == 1 || bh * ((p->N + 255) / 256) >= 512) &&
            smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024;
   if (L.kv64) {
@@ -196,7 +196,7 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     L.n_nblk = (p->N + 255) / 256;
   }
   const int q64_env = env_int("FAT5_BWDQ64", -1);
-  L.q64 = p->D == 64 && p->dtype == FAT5_BF16 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
+  L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
           env_int("FAT5_BWDQ_NW", 0) == 0 && (q64_env == 1 || bh * ((p->M + 255) / 256) >= 512);
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
