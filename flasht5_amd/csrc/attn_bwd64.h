@@ -81,7 +81,11 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 #define FAT5_B64_PK 0  // 0: one v_fma / v_mul per element; 1: v_pk_mul_f32 per element pair; 2: v_pk_fma_f32 too
 #endif
 #ifndef FAT5_B64_NLC
-#define FAT5_B64_NLC 1  // 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter as a separate C operand
+// 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter the first k-step as a separate C operand
+// (measured -2 %).  Off: a C operand that is not also the destination is read by the MFMA for ~19 cycles after issue, and the
+// volatile-asm VALU ops that follow in the same gap get no hazard padding from hipcc -- correct only as long as the register
+// allocator happens to turn the dead C registers into the next accumulator (it did) and not into a VALU temporary.
+#define FAT5_B64_NLC 0
 #endif
 #ifndef FAT5_B64_X
 #define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
