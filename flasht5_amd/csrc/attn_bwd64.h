@@ -87,6 +87,9 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 // allocator happens to turn the dead C registers into the next accumulator (it did) and not into a VALU temporary.
 #define FAT5_B64_NLC 0
 #endif
+#ifndef FAT5_Q64_CREG
+#define FAT5_Q64_CREG 1  // dQ body: 1 = -delta as a 16-register broadcast per query block (C operand of the first dP k-step; 24 gaps per step:
+#endif                   //          1077 vs 1108 us at cfg3), 0 = through one extra MFMA per query block (26 gaps, 32 VGPRs fewer)
 #ifndef FAT5_B64_X
 #define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
 #endif
@@ -763,10 +766,12 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   // Q and dO fragments (B operands), delta = rowsum(o * do) (reference _bwd_preprocess, :516-556), row statistics
   u32x4 qf[2][KK], dof[2][KK];
   float nL2[2];
-  // dP'^T = V dO^T - delta: the accumulator's initial value comes from one extra MFMA per query block, ones(32 x 16) x D3 with
+  // dP'^T = V dO^T - delta.  The pipelined loop takes -delta as a C operand (nd16: 16 registers per query block, live for the whole
+  // loop); the general iteration (and FAT5_Q64_CREG = 0) forms it with one extra MFMA per query block, ones(32 x 16) x D3 with
   // D3[j][q] = the j-th 16-bit piece of -delta_q (hi + mid + lo: 24+ bits, exact to fp32) -- a 16-register broadcast of -delta per
   // block as the C operand would hold 32 VGPRs for the whole loop (C and D of an MFMA share one register file)
   u32x4 d3[2];
+  [[maybe_unused]] f32x16 nd16[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = qw0 + 32 * qb + lq, qrow_c = min(qrow, M - 1);
@@ -800,6 +805,8 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       const float r2 = r1 - cvt16<BF16>((uint16_t)p1);
       const uint32_t p2 = to16<BF16>(r2);
       d3[qb] = hi == 0 ? u32x4{p0 | (p1 << 16), p2, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};  // (k-index 8*hi + j of the B operand)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nd16[qb][r] = nd;
     }
   }
   const uint32_t one2 = pack2<BF16>(1.f, 1.f);
@@ -989,7 +996,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   //          gaps 12..15 the V row-major fragments of step i+1; gaps 22..25 the K^T fragments (t2 = 0) of step i
   // SL = the step's ring slot, a compile-time constant: the steady state runs four steps (slots 0..3) per trip, straight-line --
   // slot offsets are instruction immediates and S / Sn (...) trade registers from one step to the next instead of being copied.
-  constexpr int NG = 26;
+  constexpr int NG = FAT5_Q64_CREG ? 24 : 26, G_DP = FAT5_Q64_CREG ? 16 : 18;  // (G_DP: first gap of the dP k-steps)
   auto fast_iter = [&]<int SL>(const int t, const float ad0, const float ad1) {
     constexpr uint32_t o_prev = (uint32_t)(((SL + 3) & 3) * SLOT), o_cur = (uint32_t)(SL * SLOT), o_next = (uint32_t)(((SL + 1) & 3) * SLOT);
     f32x16 Sn[2], DPn[2];
@@ -1016,11 +1023,12 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         constexpr int kk = (g - 8) >> 1, qb = g & 1;
         if constexpr (kk == 0) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
         else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);
-      } else if constexpr (g < 18) {
+      } else if constexpr (g < G_DP) {
         DPn[g - 16] = mfma32<BF16>(ones4, d3[g - 16], zero16);
       } else {
-        constexpr int kk = (g - 18) >> 1, qb = g & 1;
-        DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPn[qb]);
+        constexpr int kk = (g - G_DP) >> 1, qb = g & 1;
+        if constexpr (FAT5_Q64_CREG && kk == 0) DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], nd16[qb]);  // (nd16 lives for the whole loop: no WAR window)
+        else DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPn[qb]);
       }
 #if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap: without this it may sink below the gap's VALU work and pair up with the next one)
