@@ -82,7 +82,7 @@ template <bool BF16>
 FAT5_DEV uint32_t asm_cvt_pk(float a, float b) {
   uint32_t r;
   if constexpr (BF16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  else r = pack2<false>(a, b);
+  else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (gfx950: one instruction, round-to-nearest-even like the cast)
   return r;
 }
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
