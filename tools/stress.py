@@ -31,4 +31,28 @@ for S, D, H in ((512, 64, 12), (2048, 64, 12), (777, 128, 3), (1024, 32, 6)):
                     n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, cur))
             print(f"S={S} D={D} {mode:5s} causal={int(causal)}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
             bad += n_bad
+# the 64-wide pipelined bodies (attn_fwd64.h, attn_bwd64.h): forced at a mid size (many workgroups per CU in flight, ragged
+# ends), then at the size where the dispatch picks them by itself
+for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (8192, 8192, max(3, reps // 30), "-1")):
+    for mode in ("none", "rpe"):
+        for causal in (False, True):
+            for name in ("FAT5_FWD64", "FAT5_BWD64", "FAT5_BWDQ64"):
+                os.environ[name] = force
+            q, k, v, _, do = make_inputs(4, 12, M, S, 64, torch.bfloat16, None, seed=S + 7, strided=True)
+            kw = {}
+            table = (torch.randn(32, 12, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+            if mode == "rpe":
+                kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+            plan = AttentionPlan(q, k, v, do, sm_scale=0.125, causal=causal, **kw)
+            plan.forward(); plan.backward(); torch.cuda.synchronize()
+            ref = [t.clone() for t in (plan.o, plan.lse, plan.dq, plan.dk, plan.dv)] + ([plan.dbias.clone()] if plan.dbias is not None else [])
+            n_bad = 0
+            for i in range(reps2):
+                plan.forward(); plan.backward()
+                if i % 25 == 24 or i == reps2 - 1:
+                    torch.cuda.synchronize()
+                    cur = [plan.o, plan.lse, plan.dq, plan.dk, plan.dv] + ([plan.dbias] if plan.dbias is not None else [])
+                    n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, cur))
+            print(f"64-wide M={M} N={S} {mode:5s} causal={int(causal)} x{reps2}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
+            bad += n_bad
 print("TOTAL MISMATCHES", bad)
