@@ -134,3 +134,19 @@ def test_bwd64_deterministic():
     b = _grads(q, k, v, do, False, 0.125, table)
     for key in ("dq", "dk", "dv", "dtable"):
         assert torch.equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("kv64,q64", [("1", "0"), ("0", "1")])
+def test_bwd64_mixed_with_32wide_bodies(monkeypatch, kv64, q64):
+    """one 64-wide body next to the other 32-wide one (what the dispatch picks when only M or only N is long): the row statistics
+    cross between them in both directions (delta for the 32-key dK/dV body, the pre-scaled pair for the 64-key one)"""
+    monkeypatch.setenv("FAT5_BWD64", kv64)
+    monkeypatch.setenv("FAT5_BWDQ64", q64)
+    q, k, v, do, table, bias = _rpe_case(2, 2, 600, 456, torch.bfloat16, True, True, 128, seed=77)
+    ref = oracle_all(q, k, v, bias, do, 0.125, True)
+    got = _grads(q, k, v, do, True, 0.125, table)
+    for key in ("dq", "dk", "dv"):
+        assert maxdiff(got[key], ref[key]) <= gbound(ref[key], torch.bfloat16), key
+    want, allow = _table_truth(q, k, v, bias, got["o"], ref["L"], do, 0.125, True, table, 600, 456, True, 128)
+    err = (got["dtable"].cpu() - want).abs()
+    assert bool((err <= allow + 2e-3 * max(1.0, want.abs().max().item()) + 1e-2).all())
