@@ -199,9 +199,16 @@ def test_fake_impls_trace_without_a_gpu():
         assert dl.shape == logits.shape and dl.dtype == logits.dtype
 
 
-def test_native_torch_binding_loads_and_exports():
+def test_native_torch_binding_loads_and_exports(lib):
     """lib/_fat5_torch.so (the C++ host path) loads next to libfat5.so and exports its entry points (no GPU: nothing is launched)"""
     from flasht5_amd import _lib
+    if not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), "_fat5_torch.so")):  # (fresh checkout: g++ build, 1-2 min)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("fat5_build", os.path.join(ROOT, "flasht5_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_torch_binding()
+        _lib._native = False
     nat = _lib.native()
     assert nat is not None, "lib/_fat5_torch.so missing: python flasht5_amd/build.py"
     for name in ("attn_fwd", "attn_bwd", "bias_apply", "rpe_table_apply", "rpe1d_apply"):
