@@ -15,7 +15,7 @@ from .flash_attention_v2_bias import (flash_attention_v2_bias, FlashAttentionAdd
                                       flash_attention_v2_rpe, FlashAttentionRPE, flash_attention_v2_rpe1d, FlashAttentionRPE1D,
                                       flash_attn_varlen_fwd, flash_attn_varlen_bwd,
                                       flash_attn_varlen_func, FlashAttentionVarlen)
-from .rms_norm import fast_rms_layernorm, Fast_RMS_Layernorm  # noqa: E402
+from .rms_norm import fast_rms_layernorm, Fast_RMS_Layernorm, fused_add_rms_layernorm, FusedAddRMSLayernorm  # noqa: E402
 from .cross_entropy_loss import cross_entropy_loss, CrossEntropyLoss  # noqa: E402
 from .lm_head_cross_entropy import lm_head_cross_entropy, LMHeadCrossEntropy  # noqa: E402
 from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_from_table,  # noqa: E402

@@ -47,7 +47,8 @@ class AttnParams(ctypes.Structure):
 EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages",
-    "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_ce_fwd", "fat5_ce_bwd",
+    "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
+    "fat5_ce_fwd", "fat5_ce_bwd",
     "fat5_adamw_scale_step", "fat5_sizeof_adamw_tensor",
 )
 
@@ -83,6 +84,10 @@ def load():
     lib.fat5_rmsnorm_bwd_workspace_bytes.argtypes = [i64, i64]
     lib.fat5_rmsnorm_bwd.restype = ctypes.c_int
     lib.fat5_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
+    lib.fat5_add_rmsnorm_fwd.restype = ctypes.c_int
+    lib.fat5_add_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, i32, i32, vp]
+    lib.fat5_add_rmsnorm_bwd.restype = ctypes.c_int
+    lib.fat5_add_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.fat5_ce_fwd.restype = ctypes.c_int
     lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
     lib.fat5_ce_bwd.restype = ctypes.c_int

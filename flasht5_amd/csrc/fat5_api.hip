@@ -451,6 +451,27 @@ int fat5_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t
   return FAT5_OK;
 }
 
+int fat5_add_rmsnorm_fwd(const void* x, const void* r, const void* w, void* h, void* y, float* rstd, int64_t rows, int64_t n,
+                         int64_t xs, int64_t rs, int64_t hs, int64_t ys, float eps, int x_dtype, int w_dtype, void* stream_) {
+  if (!x || !r || !w || !h || !y || !rstd) return fail(FAT5_EINVAL, "add_rmsnorm_fwd: null pointer");
+  if (!dtype_ok(x_dtype) || !dtype_ok(w_dtype)) return fail(FAT5_EINVAL, "add_rmsnorm_fwd: bad dtype");
+  if (rows <= 0 || n <= 0 || n > (1 << 24)) return fail(FAT5_EINVAL, "add_rmsnorm_fwd: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int vx = vec_of(x_dtype);
+  const bool vecok = (n % vx == 0) && (xs % vx == 0) && (rs % vx == 0) && (hs % vx == 0) && (ys % vx == 0) && aligned16(x) &&
+                     aligned16(r) && aligned16(h) && aligned16(y) && aligned16(w) && (n % 8 == 0);
+  const int grid = (int)((rows + 3) / 4);
+  RMS_DISPATCH({
+    if (vecok)
+      hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<XDT, WDT, true>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);
+    else
+      hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<XDT, WDT, false>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "add_rmsnorm_fwd launch");
+  return FAT5_OK;
+}
+
 static int rms_bwd_blocks(int64_t rows) {
   // persistent 8-wave workgroups, one row per wave and trip: two (FAT5_RMS_BWD_BLOCKS per chip) per CU keep enough 16-byte
   // loads in flight to cover the HBM latency (one per CU: 4.5 TB/s at (65536, 1024))
@@ -464,15 +485,28 @@ size_t fat5_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t n) {
   return (size_t)rms_bwd_blocks(rows) * (size_t)n * sizeof(float);
 }
 
+static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, int64_t drs, void* dx,
+                            void* dw, int64_t rows, int64_t n, int64_t dys, int64_t xs, int64_t dxs, int x_dtype, int w_dtype,
+                            void* workspace, size_t workspace_bytes, void* stream_);
 int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw, int64_t rows,
                      int64_t n, int64_t dys, int64_t xs, int64_t dxs, int x_dtype, int w_dtype, void* workspace,
                      size_t workspace_bytes, void* stream_) {
+  return rmsnorm_bwd_impl(dy, x, w, rstd, nullptr, 0, dx, dw, rows, n, dys, xs, dxs, x_dtype, w_dtype, workspace, workspace_bytes, stream_);
+}
+int fat5_add_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dx, void* dw,
+                         int64_t rows, int64_t n, int64_t dys, int64_t hs, int64_t drs, int64_t dxs, int x_dtype, int w_dtype,
+                         void* workspace, size_t workspace_bytes, void* stream_) {
+  return rmsnorm_bwd_impl(dy, h, w, rstd, dres, drs, dx, dw, rows, n, dys, hs, dxs, x_dtype, w_dtype, workspace, workspace_bytes, stream_);
+}
+static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, int64_t drs, void* dx,
+                            void* dw, int64_t rows, int64_t n, int64_t dys, int64_t xs, int64_t dxs, int x_dtype, int w_dtype,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
   if (!dy || !x || !w || !rstd || !dx || !dw) return fail(FAT5_EINVAL, "rmsnorm_bwd: null pointer");
   if (!dtype_ok(x_dtype) || !dtype_ok(w_dtype)) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad dtype");
   if (rows <= 0 || n <= 0) return fail(FAT5_EINVAL, "rmsnorm_bwd: bad shape");
   const int vx = vec_of(x_dtype);
   const bool vecok = !((n % 8) || (xs % vx) || (dys % vx) || (dxs % vx) || !aligned16(x) || !aligned16(dy) || !aligned16(dx) ||
-                       !aligned16(w)) && (n <= 16 * 64 * vx);
+                       !aligned16(w) || (dres && ((drs % vx) || !aligned16(dres)))) && (n <= 16 * 64 * vx);
   if (n > 16384) return fail(FAT5_EINVAL, "rmsnorm_bwd: n = %lld exceeds 16384", (long long)n);
   const size_t need = fat5_rmsnorm_bwd_workspace_bytes(rows, n);
   if (!workspace || workspace_bytes < need) return fail(FAT5_EWORKSPACE, "rmsnorm_bwd: workspace of %zu bytes required", need);
@@ -482,12 +516,12 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
   const size_t smem = (size_t)n * sizeof(float);
   float* part = (float*)workspace;
 #define RMS_BWD_LAUNCH(NCH) \
-  hipLaunchKernelGGL((rmsnorm_bwd_kernel<XDT, WDT, NCH>), dim3(blocks), dim3(512), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs)
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<XDT, WDT, NCH>), dim3(blocks), dim3(512), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs, dres, drs)
   RMS_DISPATCH({
     if (!vecok) {
       auto kern = rmsnorm_bwd_scalar_kernel<XDT, WDT>;
       if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, dy, x, w, rstd, dx, part, rows, (int)n, dys, xs, dxs, dres, drs);
     } else if (nch <= 2) RMS_BWD_LAUNCH(2);
     else if (nch <= 4) RMS_BWD_LAUNCH(4);
     else if (nch <= 8) RMS_BWD_LAUNCH(8);

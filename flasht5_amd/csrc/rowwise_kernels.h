@@ -129,6 +129,65 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Residual add + RMSNorm forward (the residual epilogue of a T5 sub-layer fused into the next pre-norm,
+// reference modeling_flash_t5.py:159-164 / :304-318): h = x + r rounded to the activation dtype (exactly what the separate add
+// writes), y = rmsnorm(h) from the rounded sum -- bit-identical to `h = x + r; y = fast_rms_layernorm(h)`, one pass over x and r
+// instead of two kernels and five tensor passes.  One wave per row; h is re-read from cache in the second pass.
+// ---------------------------------------------------------------------------------------------
+template <int XDT, int WDT, bool VECOK>
+__global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ r_,
+                                                              const void* __restrict__ w_, void* __restrict__ h_,
+                                                              void* __restrict__ y_, float* __restrict__ rstd, int64_t rows, int n,
+                                                              int64_t xs, int64_t rs, int64_t hs, int64_t ys, float eps) {
+  typedef Elem<XDT> X;
+  constexpr int VEC = X::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+  const typename X::T* r = reinterpret_cast<const typename X::T*>(r_) + row * rs;
+  typename X::T* h = reinterpret_cast<typename X::T*>(h_) + row * hs;
+  typename X::T* y = reinterpret_cast<typename X::T*>(y_) + row * ys;
+  float ss = 0.f;
+  if constexpr (VECOK) {
+    for (int c = lane * VEC; c < n; c += 64 * VEC) {
+      float f[VEC], g[VEC];
+      X::load(x + c, f);
+      X::load(r + c, g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] += g[j];
+      X::store(h + c, f);
+      X::load(h + c, f);  // (the rounded sum: same thread, same address)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      X::st1(h + c, X::ld1(x + c) + X::ld1(r + c));
+      const float f = X::ld1(h + c);
+      ss = fmaf(f, f, ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float rr = 1.0f / sqrtf(ss / (float)n + eps);
+  if (lane == 0) rstd[row] = rr;
+  if constexpr (VECOK) {
+    for (int c = lane * VEC; c < n; c += 64 * VEC) {
+      float f[VEC], wv[VEC];
+      X::load(h + c, f);
+      load_w<WDT, VEC>(w_, c, wv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = f[j] * rr * wv[j];
+      X::store(y + c, f);
+    }
+  } else {
+    typedef Elem<WDT> W;
+    const typename W::T* w = reinterpret_cast<const typename W::T*>(w_);
+    for (int c = lane; c < n; c += 64) X::st1(y + c, X::ld1(h + c) * rr * W::ld1(w + c));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RMSNorm backward: persistent waves over strided rows; dw accumulated per lane in registers,
 // reduced across the workgroup's waves through LDS, one fp32 partial row per workgroup.
 //   NCH = max 16-byte chunks per lane (n <= NCH * 64 * VEC)
@@ -137,7 +196,10 @@ template <int XDT, int WDT, int NCH>
 __global__ __launch_bounds__(512) void rmsnorm_bwd_kernel(const void* __restrict__ dy_, const void* __restrict__ x_,
                                                           const void* __restrict__ w_, const float* __restrict__ rstd,
                                                           void* __restrict__ dx_, float* __restrict__ dw_part,
-                                                          int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs) {
+                                                          int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs,
+                                                          const void* __restrict__ dres_ = nullptr, int64_t drs = 0) {
+  // dres_ (optional): the gradient that reaches the normalised tensor through its OTHER consumer (the residual stream of the fused
+  // add + norm): dx = round(dx_norm) + dres, rounded again -- what autograd's accumulation of the two branch gradients computes
   typedef Elem<XDT> X;
   constexpr int VEC = X::VEC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,6 +247,14 @@ __global__ __launch_bounds__(512) void rmsnorm_bwd_kernel(const void* __restrict
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = (wdy[i][j] - xh[i][j] * c1) * r;  // :122
+        if (dres_) {  // (workgroup-uniform)
+          float g[VEC];
+          X::store(dx + c, o);
+          X::load(dx + c, o);  // rounded like the separate kernel's output
+          X::load(reinterpret_cast<const typename X::T*>(dres_) + row * drs + c, g);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) o[j] += g[j];
+        }
         X::store(dx + c, o);
       }
     }
@@ -212,7 +282,8 @@ template <int XDT, int WDT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_scalar_kernel(const void* __restrict__ dy_, const void* __restrict__ x_,
                                                                  const void* __restrict__ w_, const float* __restrict__ rstd,
                                                                  void* __restrict__ dx_, float* __restrict__ dw_part,
-                                                                 int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs) {
+                                                                 int64_t rows, int n, int64_t dys, int64_t xs, int64_t dxs,
+                                                                 const void* __restrict__ dres_ = nullptr, int64_t drs = 0) {
   typedef Elem<XDT> X;
   typedef Elem<WDT> W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -235,6 +306,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_scalar_kernel(const void* __r
     for (int c = lane; c < n; c += 64) {
       const float xh = X::ld1(x + c) * r, dyf = X::ld1(dy + c);
       X::st1(dx + c, (W::ld1(w + c) * dyf - xh * c1) * r);
+      if (dres_) X::st1(dx + c, X::ld1(dx + c) + X::ld1(reinterpret_cast<const typename X::T*>(dres_) + row * drs + c));
       atomicAdd(&sdw[c], dyf * xh);
     }
   }

@@ -51,6 +51,7 @@ class FAT5Config:
     pad_token_id: int = 0
     crossentropy_inplace_backward: bool = True
     fuse_lm_head_ce: bool = False          # lm_head + loss in row chunks: the (B*T, vocab) logits are never materialised
+    fuse_add_norm: bool = False            # every residual add runs inside the next pre-norm (fused_add_rms_layernorm): same bits, fewer passes
     is_decoder: bool = False
 
 
@@ -71,6 +72,14 @@ class FAT5GatedAct(nn.Module):  # reference FlashT5DenseGatedAct / FlashT5DenseA
         return self.act(self.wi(x))
 
 
+def _pre_norm(ln, h, pending):
+    """pre-norm of a sub-layer with the previous sub-layer's residual add folded in: (h + pending, layer_norm(h + pending))"""
+    if pending is None:
+        return h, ln(h)
+    from .rms_norm import fused_add_rms_layernorm
+    return fused_add_rms_layernorm(h, pending, ln.weight, ln.variance_epsilon)
+
+
 class FAT5LayerFF(nn.Module):  # :148-164
     def __init__(self, c):
         super().__init__()
@@ -80,6 +89,11 @@ class FAT5LayerFF(nn.Module):  # :148-164
 
     def forward(self, h):
         return h + self.wo(self.act(self.layer_norm(h)))
+
+    def forward_deferred(self, h, pending):
+        """(h, delta): the residual stream after the pending add, and this sub-layer's output whose add is left to the next pre-norm"""
+        h, n = _pre_norm(self.layer_norm, h, pending)
+        return h, self.wo(self.act(n))
 
 
 class FAT5LayerSelfAttention(nn.Module):  # :297-318
@@ -92,6 +106,11 @@ class FAT5LayerSelfAttention(nn.Module):  # :297-318
         a, position_bias = self.self_attention(self.layer_norm(h), position_bias=position_bias)
         return h + a, position_bias
 
+    def forward_deferred(self, h, pending, position_bias=None):
+        h, n = _pre_norm(self.layer_norm, h, pending)
+        a, position_bias = self.self_attention(n, position_bias=position_bias)
+        return h, a, position_bias
+
 
 class FAT5LayerCrossAttention(nn.Module):  # :321-349
     def __init__(self, c):
@@ -102,6 +121,11 @@ class FAT5LayerCrossAttention(nn.Module):  # :321-349
     def forward(self, h, key_value_states):
         a, _ = self.cross_attention(self.layer_norm(h), key_value_states=key_value_states)
         return h + a
+
+    def forward_deferred(self, h, pending, key_value_states):
+        h, n = _pre_norm(self.layer_norm, h, pending)
+        a, _ = self.cross_attention(n, key_value_states=key_value_states)
+        return h, a
 
 
 class FAT5Block(nn.Module):  # :352-392
@@ -119,6 +143,13 @@ class FAT5Block(nn.Module):  # :352-392
             h = self.cross_attention_layer(h, encoder_hidden_states)
         return self.ff_layer(h), position_bias
 
+    def forward_deferred(self, h, pending, position_bias=None, encoder_hidden_states=None):
+        h, pending, position_bias = self.self_attention_layer.forward_deferred(h, pending, position_bias)
+        if self.is_decoder and encoder_hidden_states is not None:
+            h, pending = self.cross_attention_layer.forward_deferred(h, pending, encoder_hidden_states)
+        h, pending = self.ff_layer.forward_deferred(h, pending)
+        return h, pending, position_bias
+
 
 class FAT5Stack(nn.Module):  # :394-464
     def __init__(self, c, embed_tokens, n_layers):
@@ -126,12 +157,18 @@ class FAT5Stack(nn.Module):  # :394-464
         self.embed_tokens = embed_tokens
         self.block = nn.ModuleList([FAT5Block(c, has_positional_encoding=(i == 0)) for i in range(n_layers)])
         self.final_layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
+        self.fuse_add_norm = c.fuse_add_norm
 
     def forward(self, input_ids, encoder_hidden_states=None):
         h = self.embed_tokens(input_ids)
         if torch.is_autocast_enabled() and h.is_cuda:  # :424-425
             h = h.to(torch.get_autocast_gpu_dtype())
         position_bias = None  # produced by block 0, shared by the others (:452-455)
+        if self.fuse_add_norm:
+            pending = None  # the last sub-layer's output: its residual add happens inside the next pre-norm
+            for blk in self.block:
+                h, pending, position_bias = blk.forward_deferred(h, pending, position_bias, encoder_hidden_states)
+            return _pre_norm(self.final_layer_norm, h, pending)[1]
         for blk in self.block:
             h, position_bias = blk(h, position_bias, encoder_hidden_states)
         return self.final_layer_norm(h)

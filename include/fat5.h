@@ -147,6 +147,18 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* hip_stream
 int fat5_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int64_t n,
                      int64_t x_row_stride, int64_t y_row_stride, float eps, int x_dtype, int w_dtype,
                      void* hip_stream);
+/* Residual add + RMSNorm (the residual epilogue of a T5 sub-layer fused into the next pre-norm, reference
+ * src/model/modeling_flash_t5.py:159-164 + :304-318 / :95-98): h = x + r rounded to x_dtype, y = rmsnorm(h) * w, rstd saved --
+ * bit-identical to the separate add followed by fat5_rmsnorm_fwd.  x, r, h, y: (rows, n) with row strides in elements. */
+int fat5_add_rmsnorm_fwd(const void* x, const void* r, const void* w, void* h, void* y, float* rstd, int64_t rows, int64_t n,
+                         int64_t x_row_stride, int64_t r_row_stride, int64_t h_row_stride, int64_t y_row_stride, float eps,
+                         int x_dtype, int w_dtype, void* hip_stream);
+/* its backward: dx = round(rmsnorm_bwd_dx(dy, h, w, rstd)) + dres (dres = gradient reaching h through the residual stream, may be
+ * NULL), dw as fat5_rmsnorm_bwd; dx is the gradient of BOTH x and r.  Workspace: fat5_rmsnorm_bwd_workspace_bytes(rows, n). */
+int fat5_add_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dx, void* dw,
+                         int64_t rows, int64_t n, int64_t dy_row_stride, int64_t h_row_stride, int64_t dres_row_stride,
+                         int64_t dx_row_stride, int x_dtype, int w_dtype, void* workspace, size_t workspace_bytes,
+                         void* hip_stream);
 size_t fat5_rmsnorm_bwd_workspace_bytes(int64_t rows, int64_t n);
 int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, void* dw,
                      int64_t rows, int64_t n, int64_t dy_row_stride, int64_t x_row_stride,

@@ -218,3 +218,40 @@ def test_lm_head_cross_entropy_chunked(rows, d, V, dtype, chunk):
     assert not z1.requires_grad
     if chunk is None:  # FAT5-base head, 8 x 1024 target tokens: 537 MB of logits never exist; what remains is weight-sized
         assert peak <= peak0 - 0.5 * rows * V * h.element_size(), (peak, peak0)  # (the fp32 dW accumulator + one 64 MB chunk)
+
+
+@pytest.mark.parametrize("rows,n,dtype,wdtype", [(4096, 768, torch.bfloat16, torch.bfloat16), (37, 1024, torch.float16, torch.float32),
+                                                 (5, 100, torch.bfloat16, torch.bfloat16), (64, 768, torch.float32, torch.float32)])
+def test_fused_add_rmsnorm_equals_add_then_norm(rows, n, dtype, wdtype):
+    """residual add + RMSNorm in one pass (SURVEY 8(f) n3): h, y and every gradient bit-identical to `h = x + r;
+    y = fast_rms_layernorm(h)` (the residual stream and the normalised tensor both feed later work), and within the
+    RMSNorm tolerance of the fp32 oracle composition"""
+    from flasht5_amd import fast_rms_layernorm, fused_add_rms_layernorm
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, n, generator=g).to(dtype).cuda()
+    r = (torch.randn(rows, n, generator=g) * 0.5).to(dtype).cuda()
+    w = (1 + 0.1 * torch.randn(n, generator=g)).to(wdtype).cuda()
+    gh = torch.randn(rows, n, generator=g).to(dtype).cuda()
+    gy = torch.randn(rows, n, generator=g).to(dtype).cuda()
+
+    def run(fused):
+        xs, rs, ws = (t.detach().clone().requires_grad_() for t in (x, r, w))
+        if fused:
+            h, y = fused_add_rms_layernorm(xs, rs, ws, 1e-6)
+        else:
+            h = xs + rs
+            y = fast_rms_layernorm(h, ws, 1e-6)
+        return [h.detach(), y.detach()] + list(torch.autograd.grad([h, y], [xs, rs, ws], [gh, gy]))
+
+    for a, b in zip(run(True), run(False)):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    # y alone (the final norm of a stack: nothing flows back through the residual stream)
+    xs, rs = x.clone().requires_grad_(), r.clone().requires_grad_()
+    _, y1 = fused_add_rms_layernorm(xs, rs, w, 1e-6)
+    x2 = x.clone().requires_grad_()
+    y2 = fast_rms_layernorm(x2 + r, w, 1e-6)
+    assert torch.equal(y1, y2)
+    assert torch.equal(torch.autograd.grad(y1, xs, gy)[0], torch.autograd.grad(y2, x2, gy)[0])
+    # against the oracle composition in fp32
+    want, _ = oracle.rmsnorm_fwd_oracle((x.float() + r.float()).to(dtype).cpu(), w.cpu(), 1e-6)
+    assert md(y1, want) <= 1e-2 * max(1.0, want.float().abs().max().item())
