@@ -122,7 +122,16 @@ def rowwise_bench(device):
         bf, bb = 2 * rows * n * 2, 3 * rows * n * 2
         out[f"rmsnorm_{rows}x{n}"] = {"fwd_us": round(tf * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "fwd_frac": round(bf / tf / 1e9 / PEAK_HBM_GBS, 3),
                                       "bwd_us": round(tb * 1e6, 2), "bwd_GBs": round(bb / tb / 1e9, 1), "bwd_frac": round(bb / tb / 1e9 / PEAK_HBM_GBS, 3)}
-        del x, dy
+        # residual add fused into the pre-norm: x, r read; h, y written / dy, h, dres read; dx written
+        from flasht5_amd.rms_norm import add_rmsnorm_fwd, add_rmsnorm_bwd
+        r_ = torch.randn_like(x)
+        h_, _, rstd2 = add_rmsnorm_fwd(x, r_, w, 1e-6)
+        tf2 = graph_time(lambda: add_rmsnorm_fwd(x, r_, w, 1e-6))
+        tb2 = graph_time(lambda: add_rmsnorm_bwd(dy, h_, w, rstd2, r_, True))
+        b4 = 4 * rows * n * 2
+        out[f"add_rmsnorm_{rows}x{n}"] = {"fwd_us": round(tf2 * 1e6, 2), "fwd_GBs": round(b4 / tf2 / 1e9, 1), "fwd_frac": round(b4 / tf2 / 1e9 / PEAK_HBM_GBS, 3),
+                                          "bwd_us": round(tb2 * 1e6, 2), "bwd_GBs": round(b4 / tb2 / 1e9, 1), "bwd_frac": round(b4 / tb2 / 1e9 / PEAK_HBM_GBS, 3)}
+        del x, dy, r_, h_
     for rows, V in ((4096, 32768), (16384, 32768)):
         lg = torch.randn(rows, V, device=device).bfloat16()
         lab = torch.randint(0, V, (rows,), device=device)
@@ -135,7 +144,7 @@ def rowwise_bench(device):
         out[f"ce_{rows}x{V}"] = {"fwd_us": round(tf * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "fwd_frac": round(bf / tf / 1e9 / PEAK_HBM_GBS, 3),
                                  "bwd_us": round(tb * 1e6, 2), "bwd_GBs": round(bb / tb / 1e9, 1), "bwd_frac": round(bb / tb / 1e9 / PEAK_HBM_GBS, 3)}
         del lg, dst
-    out["bytes_model"] = "rmsnorm fwd 2RNe, bwd 3RNe; ce fwd RVe, bwd 2RVe (e = 2); label smoothing 0.1, z-loss 1e-4"
+    out["bytes_model"] = "rmsnorm fwd 2RNe, bwd 3RNe; add_rmsnorm fwd 4RNe, bwd 4RNe; ce fwd RVe, bwd 2RVe (e = 2); label smoothing 0.1, z-loss 1e-4"
     # fused AdamWScale step over a FAT5-base sized parameter set (bf16 parameters + Kahan compensation): two launches
     from flasht5_amd import AdamWScale
     shapes = [(32768, 768)] * 2 + [(768, 768)] * (4 * 36) + [(2048, 768)] * (3 * 24) + [(768,)] * 62 + [(32, 12)] * 2
