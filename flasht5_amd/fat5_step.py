@@ -271,3 +271,4 @@ def train_step(model, input_ids, labels, optimizer=None, group=None, max_grad_no
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return loss.detach()
+

@@ -164,3 +164,4 @@ def test_cfg5_fused_add_norm_is_bit_identical():
     for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
         rel = 2.0 ** -4 if "relative_attention_bias" in n else 2.0 ** -7
         assert maxdiff(p1.grad, p0.grad) <= rel * max(p0.grad.float().abs().max().item(), 1e-6), n
+
