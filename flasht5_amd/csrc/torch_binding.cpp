@@ -205,6 +205,108 @@ struct Rpe1dFn : public torch::autograd::Function<Rpe1dFn> {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (reference src/model/ops/rms_norm.py:250-287) and the residual add fused into it: same host logic as
+// flasht5_amd/rms_norm.py.  124 norm launches per FAT5-base step: their Python + dispatcher time is what this saves.
+// ------------------------------------------------------------------------------------------------
+int any_dtype_code(const Tensor& t) {
+  if (t.scalar_type() == at::kFloat) return FAT5_F32;
+  if (t.scalar_type() == at::kHalf) return FAT5_F16;
+  if (t.scalar_type() == at::kBFloat16) return FAT5_BF16;
+  TORCH_CHECK(false, "unsupported dtype (float32, float16, bfloat16)");
+}
+bool rows_ok(const Tensor& t) { return t.stride(-1) == 1 && (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0; }
+Tensor rows2d(const Tensor& t) {
+  Tensor r = t.reshape({-1, t.size(-1)});
+  return rows_ok(r) ? r : r.contiguous();
+}
+
+std::tuple<Tensor, Tensor> rms_fwd(const Tensor& X, const Tensor& W_, double eps) {
+  const int64_t M = X.size(0), N = X.size(1);
+  Tensor W = W_.contiguous();
+  Tensor Y = at::empty({M, N}, X.options()), rstd = at::empty({M}, X.options().dtype(at::kFloat));
+  if (M == 0) return {Y, rstd};
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
+  check_rc(fat5_rmsnorm_fwd(X.data_ptr(), W.data_ptr(), Y.data_ptr(), (float*)rstd.data_ptr(), M, N, X.stride(0), Y.stride(0), (float)eps,
+                            any_dtype_code(X), any_dtype_code(W), c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(X.get_device()).stream()),
+           "fat5_rmsnorm_fwd");
+  return {Y, rstd};
+}
+std::tuple<Tensor, Tensor, Tensor> add_rms_fwd(const Tensor& X, const Tensor& R, const Tensor& W_, double eps) {
+  const int64_t M = X.size(0), N = X.size(1);
+  Tensor W = W_.contiguous();
+  Tensor H = at::empty({M, N}, X.options()), Y = at::empty({M, N}, X.options()), rstd = at::empty({M}, X.options().dtype(at::kFloat));
+  if (M == 0) return {H, Y, rstd};
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
+  check_rc(fat5_add_rmsnorm_fwd(X.data_ptr(), R.data_ptr(), W.data_ptr(), H.data_ptr(), Y.data_ptr(), (float*)rstd.data_ptr(), M, N, X.stride(0),
+                                R.stride(0), H.stride(0), Y.stride(0), (float)eps, any_dtype_code(X), any_dtype_code(W),
+                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(X.get_device()).stream()),
+           "fat5_add_rmsnorm_fwd");
+  return {H, Y, rstd};
+}
+// dres: undefined -> plain RMSNorm backward
+std::tuple<Tensor, Tensor> rms_bwd(const Tensor& dy_, const Tensor& x, const Tensor& W_, const Tensor& rstd, const Tensor& dres_) {
+  const int64_t M = x.size(0), N = x.size(1);
+  Tensor dy = dy_.scalar_type() == x.scalar_type() ? dy_ : dy_.to(x.scalar_type());
+  if (!rows_ok(dy)) dy = dy.contiguous();
+  Tensor dres = dres_;
+  if (dres.defined()) {
+    if (dres.scalar_type() != x.scalar_type()) dres = dres.to(x.scalar_type());
+    if (!rows_ok(dres)) dres = dres.contiguous();
+  }
+  Tensor W = W_.contiguous();
+  Tensor dx = at::empty({M, N}, x.options()), dw = at::empty({N}, W.options());
+  if (M == 0) return {dx, dw.zero_()};
+  const size_t nbytes = fat5_rmsnorm_bwd_workspace_bytes(M, N);
+  Tensor ws = at::empty({(int64_t)std::max<size_t>(nbytes, 16)}, x.options().dtype(at::kByte));
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+  check_rc(fat5_add_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), (const float*)rstd.data_ptr(), dres.defined() ? dres.data_ptr() : nullptr,
+                                dx.data_ptr(), dw.data_ptr(), M, N, dy.stride(0), x.stride(0), dres.defined() ? dres.stride(0) : 0, dx.stride(0),
+                                any_dtype_code(x), any_dtype_code(W), ws.data_ptr(), (size_t)ws.numel(),
+                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.get_device()).stream()),
+           "fat5_rmsnorm_bwd");
+  return {dx, dw};
+}
+
+struct RmsNormFn : public torch::autograd::Function<RmsNormFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& W, double eps) {
+    Tensor x2 = rows2d(X);
+    auto [y, rstd] = rms_fwd(x2, W, eps);
+    ctx->save_for_backward({x2, W, rstd});  // y is recomputed in backward, like the reference (:261-262)
+    ctx->saved_data["shape"] = X.sizes().vec();
+    return y.reshape(X.sizes());
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    auto [dx, dw] = rms_bwd(grads[0].reshape({-1, s[0].size(1)}), s[0], s[1], s[2], Tensor());
+    return {dx.reshape(ctx->saved_data["shape"].toIntVector()), dw, Tensor()};
+  }
+};
+struct AddRmsNormFn : public torch::autograd::Function<AddRmsNormFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& X, const Tensor& R, const Tensor& W, double eps) {
+    auto [h, y, rstd] = add_rms_fwd(rows2d(X), rows2d(R), W, eps);
+    ctx->save_for_backward({h, W, rstd});
+    ctx->saved_data["shape"] = X.sizes().vec();
+    return {h.reshape(X.sizes()), y.reshape(X.sizes())};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const auto shape = ctx->saved_data["shape"].toIntVector();
+    const Tensor& dH = grads[0];
+    const Tensor& dY = grads[1];
+    if (!dY.defined()) return {dH, dH, Tensor(), Tensor()};  // only the residual stream is used downstream
+    const int64_t n = s[0].size(1);
+    auto [dx, dw] = rms_bwd(dY.reshape({-1, n}), s[0], s[1], s[2], dH.defined() ? dH.reshape({-1, n}) : Tensor());
+    Tensor d = dx.reshape(shape);
+    return {d, d, dw, Tensor()};
+  }
+};
+Tensor rmsnorm_apply(const Tensor& X, const Tensor& W, double eps) { return RmsNormFn::apply(X, W, eps); }
+std::tuple<Tensor, Tensor> add_rmsnorm_apply(const Tensor& X, const Tensor& R, const Tensor& W, double eps) {
+  auto r = AddRmsNormFn::apply(X, R, W, eps);
+  return {r[0], r[1]};
+}
+
 Tensor bias_apply(const Tensor& q, const Tensor& k, const Tensor& v, const OptT& bias, bool causal, double scale) {
   return BiasFn::apply(q, k, v, bias, causal, scale);
 }
@@ -226,5 +328,7 @@ PYBIND11_MODULE(_fat5_torch, m) {
   m.def("bias_apply", &bias_apply);
   m.def("rpe_table_apply", &rpe_table_apply);
   m.def("rpe1d_apply", &rpe1d_apply);
+  m.def("rmsnorm_apply", &rmsnorm_apply);
+  m.def("add_rmsnorm_apply", &add_rmsnorm_apply);
   m.def("sizeof_attn_params", []() { return (int64_t)sizeof(fat5_attn_params); });
 }

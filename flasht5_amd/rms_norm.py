@@ -99,6 +99,9 @@ class Fast_RMS_Layernorm(torch.autograd.Function):
 def fast_rms_layernorm(X, W, eps):
     """y = x * rsqrt(mean(x^2, -1) + eps) * W over the last dim; differentiable in X and W
     (reference rms_norm.py:285-287)."""
+    nat = None if torch.compiler.is_compiling() else _lib.native()
+    if nat is not None and X.is_cuda and X.dim() >= 1 and W.dim() == 1 and W.shape[0] == X.shape[-1]:
+        return nat.rmsnorm_apply(X, W, float(eps))  # the same launches from C++ autograd functions (csrc/torch_binding.cpp)
     return Fast_RMS_Layernorm.apply(X, W, eps)
 
 
@@ -199,4 +202,7 @@ class FusedAddRMSLayernorm(torch.autograd.Function):
 def fused_add_rms_layernorm(X, residual, W, eps):
     """(h, y) with h = X + residual (rounded to X's dtype) and y = fast_rms_layernorm(h, W, eps), in one pass; differentiable in
     X, residual and W.  Bit-identical to the two separate operations."""
+    nat = None if torch.compiler.is_compiling() else _lib.native()
+    if nat is not None and X.is_cuda and residual.shape == X.shape and residual.dtype == X.dtype and W.dim() == 1 and W.shape[0] == X.shape[-1]:
+        return nat.add_rmsnorm_apply(X, residual, W, float(eps))
     return FusedAddRMSLayernorm.apply(X, residual, W, eps)

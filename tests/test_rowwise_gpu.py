@@ -243,8 +243,12 @@ def test_fused_add_rmsnorm_equals_add_then_norm(rows, n, dtype, wdtype):
             y = fast_rms_layernorm(h, ws, 1e-6)
         return [h.detach(), y.detach()] + list(torch.autograd.grad([h, y], [xs, rs, ws], [gh, gy]))
 
-    for a, b in zip(run(True), run(False)):
-        assert a.dtype == b.dtype and torch.equal(a, b)
+    for i, (a, b) in enumerate(zip(run(True), run(False))):
+        assert a.dtype == b.dtype
+        if i == 4 and n % 8:  # dw of the scalar fallback kernel (n not a multiple of 8): LDS float atomics, order not fixed
+            assert md(a, b) <= 1e-2 * max(1.0, b.float().abs().max().item())
+        else:
+            assert torch.equal(a, b), i
     # y alone (the final norm of a stack: nothing flows back through the residual stream)
     xs, rs = x.clone().requires_grad_(), r.clone().requires_grad_()
     _, y1 = fused_add_rms_layernorm(xs, rs, w, 1e-6)
@@ -255,3 +259,28 @@ def test_fused_add_rmsnorm_equals_add_then_norm(rows, n, dtype, wdtype):
     # against the oracle composition in fp32
     want, _ = oracle.rmsnorm_fwd_oracle((x.float() + r.float()).to(dtype).cpu(), w.cpu(), 1e-6)
     assert md(y1, want) <= 1e-2 * max(1.0, want.float().abs().max().item())
+
+
+def test_native_rmsnorm_path_equals_custom_op_path():
+    """the C++ autograd functions (csrc/torch_binding.cpp) and the Python custom-op path launch the same kernels: y, h and the
+    gradients are bit-identical (N-d input, vector path)"""
+    from flasht5_amd import _lib, fast_rms_layernorm, fused_add_rms_layernorm, Fast_RMS_Layernorm, FusedAddRMSLayernorm
+    assert _lib.native() is not None
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 50, 768, generator=g).bfloat16().cuda()
+    r = torch.randn(3, 50, 768, generator=g).bfloat16().cuda()
+    w = (1 + 0.1 * torch.randn(768, generator=g)).bfloat16().cuda()
+    gy, gh = torch.randn_like(x), torch.randn_like(x)
+
+    def run(fn, fused):
+        xs, rs, ws = (t.clone().requires_grad_() for t in (x, r, w))
+        if fused:
+            h, y = fn(xs, rs, ws, 1e-6)
+            return [h.detach(), y.detach()] + list(torch.autograd.grad([h, y], [xs, rs, ws], [gh, gy]))
+        y = fn(xs, ws, 1e-6)
+        return [y.detach()] + list(torch.autograd.grad(y, [xs, ws], gy))
+
+    for a, b in zip(run(fast_rms_layernorm, False), run(Fast_RMS_Layernorm.apply, False)):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(run(fused_add_rms_layernorm, True), run(FusedAddRMSLayernorm.apply, True)):
+        assert a.shape == b.shape and torch.equal(a, b)
