@@ -449,7 +449,10 @@ def main():
                 by_seq[str(s2)] = {"fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "fwd_tflops": round(f / tf / 1e9, 1),
                                    "bwd_tflops": round(2.5 * f / tb / 1e9, 1),
                                    "fwd_bwd_tflops": round(3.5 * f / (tf + tb) / 1e9, 1),
-                                   "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4)}
+                                   "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                   # backward: counted flops (5 GEMMs) and executed MFMA flops (the two-kernel design runs 7)
+                                   "bwd_frac_of_peak": round(2.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                   "bwd_mfma_frac_of_peak": round(3.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4)}
                 del p2
             out["by_seq"] = by_seq
             if world == 1:
