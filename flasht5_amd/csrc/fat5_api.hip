@@ -461,8 +461,13 @@ int fat5_add_rmsnorm_fwd(const void* x, const void* r, const void* w, void* h, v
   const bool vecok = (n % vx == 0) && (xs % vx == 0) && (rs % vx == 0) && (hs % vx == 0) && (ys % vx == 0) && aligned16(x) &&
                      aligned16(r) && aligned16(h) && aligned16(y) && aligned16(w) && (n % 8 == 0);
   const int grid = (int)((rows + 3) / 4);
+  const int nch = (int)((n + 64 * vx - 1) / (64 * vx));
   RMS_DISPATCH({
-    if (vecok)
+    if (vecok && nch <= 2)
+      hipLaunchKernelGGL((add_rmsnorm_fwd_reg_kernel<XDT, WDT, 2>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);
+    else if (vecok && nch <= 4)
+      hipLaunchKernelGGL((add_rmsnorm_fwd_reg_kernel<XDT, WDT, 4>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);
+    else if (vecok)
       hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<XDT, WDT, true>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);
     else
       hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<XDT, WDT, false>), dim3(grid), dim3(256), 0, stream, x, r, w, h, y, rstd, rows, (int)n, xs, rs, hs, ys, eps);

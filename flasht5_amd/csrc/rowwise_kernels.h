@@ -187,6 +187,75 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_kernel(const void* __rest
   }
 }
 
+// Register-resident variant (n <= NCH * 64 * VEC, 16-byte friendly rows): the rounded sum stays in registers between the two
+// passes -- x and r are read once, h and y written once, nothing is re-read (108 -> 97 us at (65536, 1024) bf16, 5.6 TB/s of its four tensor passes).
+template <int DT>
+FAT5_DEV void round_to_dtype(float (&f)[Elem<DT>::VEC], u32x4& packed) {
+  if constexpr (DT == FAT5_F32) {
+    packed = u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+  } else {
+    constexpr bool BF = (DT == FAT5_BF16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      packed[j] = pack2<BF>(f[2 * j], f[2 * j + 1]);
+      f[2 * j] = cvt_lo<BF>(packed[j]);
+      f[2 * j + 1] = cvt_hi<BF>(packed[j]);
+    }
+  }
+}
+template <int XDT, int WDT, int NCH>
+__global__ __launch_bounds__(256) void add_rmsnorm_fwd_reg_kernel(const void* __restrict__ x_, const void* __restrict__ r_,
+                                                                  const void* __restrict__ w_, void* __restrict__ h_,
+                                                                  void* __restrict__ y_, float* __restrict__ rstd, int64_t rows, int n,
+                                                                  int64_t xs, int64_t rs, int64_t hs, int64_t ys, float eps) {
+  typedef Elem<XDT> X;
+  constexpr int VEC = X::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+  const typename X::T* r = reinterpret_cast<const typename X::T*>(r_) + row * rs;
+  typename X::T* h = reinterpret_cast<typename X::T*>(h_) + row * hs;
+  typename X::T* y = reinterpret_cast<typename X::T*>(y_) + row * ys;
+  float f[NCH][VEC], g[NCH][VEC];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+    if (c < n) {
+      X::load(x + c, f[i]);
+      X::load(r + c, g[i]);
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+    if (c < n) {
+      u32x4 packed;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[i][j] += g[i][j];
+      round_to_dtype<XDT>(f[i], packed);
+      *reinterpret_cast<u32x4*>(h + c) = packed;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ss = fmaf(f[i][j], f[i][j], ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float rr = 1.0f / sqrtf(ss / (float)n + eps);
+  if (lane == 0) rstd[row] = rr;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+    if (c < n) {
+      float wv[VEC];
+      load_w<WDT, VEC>(w_, c, wv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[i][j] = f[i][j] * rr * wv[j];
+      X::store(y + c, f[i]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // RMSNorm backward: persistent waves over strided rows; dw accumulated per lane in registers,
 // reduced across the workgroup's waves through LDS, one fp32 partial row per workgroup.
