@@ -151,3 +151,30 @@ def test_bwd64_mixed_with_32wide_bodies(monkeypatch, kv64, q64):
     want, allow = _table_truth(q, k, v, bias, got["o"], ref["L"], do, 0.125, True, table, 600, 456, True, 128)
     err = (got["dtable"].cpu() - want).abs()
     assert bool((err <= allow + 2e-3 * max(1.0, want.abs().max().item()) + 1e-2).all())
+
+
+@pytest.mark.parametrize("dtype,causal", [(torch.float16, False), (torch.bfloat16, True)])
+def test_default_dispatch_long_sequence_slice_vs_oracle(monkeypatch, dtype, causal):
+    """(4, 12, 4096, 64): the dispatch picks the 64-wide bodies by itself (fp16 too; causal too).  Two heads of batch 0 against the
+    fp32 oracle run on the device, table gradient of the whole batch through the zero-sum property of the softmax Jacobian."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    for name in ("FAT5_BWD64", "FAT5_BWDQ64", "FAT5_FWD64"):
+        monkeypatch.delenv(name, raising=False)
+    B, H, S = 4, 12, 4096
+    q, k, v, _, do = make_inputs(B, H, S, S, 64, dtype, None, seed=12, strided=True)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(4)) * 0.5).cuda()
+    plan = AttentionPlan(q, k, v, do, rpe1d=pe.rpe1d_from_table(table), radius=128, sm_scale=0.125, causal=causal)
+    o = plan.forward().clone()
+    dq, dk, dv, d1 = (t.clone() for t in plan.backward())
+    torch.cuda.synchronize()
+    bias = pe.compute_bias(table[:, :2], S, S).contiguous()
+    sl = (slice(0, 1), slice(0, 2))
+    qs, ks, vs, dos = (t[sl] for t in (q, k, v, do))
+    ref_o, ref_L = oracle.attn_fwd_oracle(qs, ks, vs, bias, 0.125, causal)
+    rdq, rdk, rdv, _, _ = oracle.attn_bwd_oracle(qs, ks, vs, bias, ref_o, ref_L, dos, 0.125, causal)
+    assert maxdiff(o[sl], ref_o) <= bound(ref_o, dtype)
+    for got, ref, name in ((dq[sl], rdq, "dq"), (dk[sl], rdk, "dk"), (dv[sl], rdv, "dv")):
+        assert torch.isfinite(got.float()).all(), name
+        assert maxdiff(got, ref) <= gbound(ref, dtype), name
+    assert torch.isfinite(d1).all()
