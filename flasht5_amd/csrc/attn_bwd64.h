@@ -2,7 +2,7 @@
 // software-pipelined query-step loop.
 //
 // Same contract as attn_bwd_kv_kernel (attn_bwd.h; replaces the reference Triton `_bwd_kv_kernel`,
-// src/model/ops/flash_attention_v2_bias.py:559-745) for bias = none / in-kernel T5 RPE, bf16, D = 64.  What is different, and why:
+// src/model/ops/flash_attention_v2_bias.py:559-745) for bias = none / in-kernel T5 RPE, bf16 / fp16, D = 64.  What is different, and why:
 //
 //  * LDS bandwidth.  In the 32-keys-per-wave body every wave reads the whole Q and dO tile twice (row-major for S / dP,
 //    transposed for dK / dV): 1 KiB of LDS per MFMA, exactly the CU's 128 B/clk at 100 % MFMA issue -- measured 42 % MFMA
