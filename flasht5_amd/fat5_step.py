@@ -247,11 +247,12 @@ def allreduce_gradients(model: nn.Module, group=None, average=True):
         params = head + [p for p in params if id(p) not in ids]
     if not params:
         return None
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None  # one rank: nothing to exchange (and no 1 GB flat copy of a FAT5-base gradient set)
     flat = torch.cat([p.grad.detach().reshape(-1).float() for p in params])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= dist.get_world_size(group)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
     off = 0
     for p in params:
         n = p.numel()
