@@ -49,7 +49,7 @@ EXPORTS = (
     "fat5_attn_bwd_stages",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
     "fat5_ce_fwd", "fat5_ce_bwd",
-    "fat5_adamw_scale_step", "fat5_sizeof_adamw_tensor",
+    "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
 )
 
 _lib = None
@@ -95,6 +95,10 @@ def load():
     lib.fat5_adamw_scale_step.restype = ctypes.c_int
     f64 = ctypes.c_double
     lib.fat5_adamw_scale_step.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, vp]
+    lib.fat5_adamw_scale_step_clipped.restype = ctypes.c_int
+    lib.fat5_adamw_scale_step_clipped.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, vp, vp]
+    lib.fat5_adamw_grad_sumsq.restype = ctypes.c_int
+    lib.fat5_adamw_grad_sumsq.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.fat5_sizeof_adamw_tensor.restype = ctypes.c_size_t
     lib.fat5_sizeof_attn_params.restype = ctypes.c_size_t
     if lib.fat5_sizeof_attn_params() != ctypes.sizeof(AttnParams):

@@ -27,11 +27,16 @@ class _Desc(ctypes.Structure):
 
 class AdamWScale(Optimizer):
     """Same arguments as the reference class (:40-66).  `foreach` is accepted and ignored (the fused step replaces both of the
-    reference's paths); `use_state_dtype` other than None is not supported by the fused kernels."""
+    reference's paths); `use_state_dtype` other than None is not supported by the fused kernels.
+
+    Extension (keyword only): `max_grad_norm` folds `torch.nn.utils.clip_grad_norm_(params, max_grad_norm)` -- what the reference's
+    trainer runs before every optimizer step (`max_grad_norm: 1.0`) -- into the step: one more pass over the gradients for the global
+    norm, the clip coefficient stays on the device and scales every gradient as it is read (rounded to the gradient dtype like the
+    in-place multiply).  The gradient tensors are left untouched; `last_grad_norm` holds the norm (device tensor) for logging."""
 
     def __init__(self, params: Iterable[nn.parameter.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-6, weight_decay: float = 0.0, kahan_sum: bool = False, foreach: bool = False,
-                 correct_bias: bool = True, use_state_dtype: torch.dtype = None):
+                 correct_bias: bool = True, use_state_dtype: torch.dtype = None, *, max_grad_norm: float = None):
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr} - should be >= 0.0")
         if not 0.0 <= betas[0] < 1.0:
@@ -45,6 +50,10 @@ class AdamWScale(Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=foreach, kahan_sum=kahan_sum,
                         correct_bias=correct_bias, use_state_dtype=use_state_dtype)
         super().__init__(params, defaults)
+        if max_grad_norm is not None and not max_grad_norm > 0.0:
+            raise ValueError(f"Invalid max_grad_norm: {max_grad_norm} - should be > 0")
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm = None
         if ctypes.sizeof(_Desc) != _lib.load().fat5_sizeof_adamw_tensor():
             raise ImportError("fat5_adamw_tensor layout mismatch between libfat5.so and its binding")
 
@@ -66,6 +75,7 @@ class AdamWScale(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        jobs = []  # one per (group, device, dtype, kahan) bucket: descriptor table on the device, launched below
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             buckets = {}
@@ -112,10 +122,30 @@ class AdamWScale(Optimizer):
                     continue
                 raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
                 partials = torch.empty(chunk, dtype=torch.float32, device=device)
+                jobs.append((device, dtype, kahan, raw, len(items), chunk, partials, group, keep))
+        if not jobs:
+            return loss
+        coef = None
+        if self.max_grad_norm is not None:
+            if len({j[0] for j in jobs}) != 1:
+                raise RuntimeError("AdamWScale(max_grad_norm=...): parameters on several devices are not supported")
+            total = None
+            for device, dtype, kahan, raw, n, chunk, partials, group, keep in jobs:
                 with _lib.on_device(device):
-                    _lib.check(lib.fat5_adamw_scale_step(raw.data_ptr(), len(items), chunk, partials.data_ptr(), float(group["lr"]),
-                                                         float(beta1), float(beta2), float(group["weight_decay"]), float(group["eps"]),
-                                                         _lib.dtype_code(dtype), int(kahan), _lib.stream_ptr(device)),
-                               "fat5_adamw_scale_step")
-                del keep
+                    _lib.check(lib.fat5_adamw_grad_sumsq(raw.data_ptr(), n, chunk, partials.data_ptr(), _lib.dtype_code(dtype),
+                                                         _lib.stream_ptr(device)), "fat5_adamw_grad_sumsq")
+                s_ = partials.sum()
+                total = s_ if total is None else total + s_
+            norm = total.sqrt()
+            self.last_grad_norm = norm
+            coef = (self.max_grad_norm / (norm + 1e-6)).clamp(max=1.0).float().contiguous()  # clip_grad_norm_'s clip_coef_clamped
+        for device, dtype, kahan, raw, n, chunk, partials, group, keep in jobs:
+            beta1, beta2 = group["betas"]
+            args = (raw.data_ptr(), n, chunk, partials.data_ptr(), float(group["lr"]), float(beta1), float(beta2),
+                    float(group["weight_decay"]), float(group["eps"]), _lib.dtype_code(dtype), int(kahan))
+            with _lib.on_device(device):
+                if coef is None:
+                    _lib.check(lib.fat5_adamw_scale_step(*args, _lib.stream_ptr(device)), "fat5_adamw_scale_step")
+                else:
+                    _lib.check(lib.fat5_adamw_scale_step_clipped(*args, coef.data_ptr(), _lib.stream_ptr(device)), "fat5_adamw_scale_step_clipped")
         return loss

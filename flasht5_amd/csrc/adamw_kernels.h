@@ -51,7 +51,8 @@ FAT5_DEV int tensor_of_chunk(const fat5_adamw_tensor* __restrict__ tab, int n, i
   return lo;
 }
 
-template <int DT>
+// GRAD: sum of squares of the gradients instead (global-norm clipping, see fat5_adamw_grad_sumsq)
+template <int DT, bool GRAD = false>
 __global__ __launch_bounds__(256) void adamw_sumsq_kernel(const fat5_adamw_tensor* __restrict__ tab, int n, float* __restrict__ partial) {
   typedef typename adt<DT>::type T;
   __shared__ float red[4];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void adamw_sumsq_kernel(const fat5_adamw_tenso
   const fat5_adamw_tensor t = tab[tensor_of_chunk(tab, n, c)];
   const int64_t e0 = (int64_t)(c - t.chunk_begin) * kAdamChunk;
   const int64_t cnt = min((int64_t)kAdamChunk, t.numel - e0);
-  const T* p = reinterpret_cast<const T*>(t.p) + e0;
+  const T* p = reinterpret_cast<const T*>(GRAD ? t.g : t.p) + e0;
   float acc = 0.f;
   constexpr int V = 16 / sizeof(T);
   if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
@@ -81,11 +82,15 @@ __global__ __launch_bounds__(256) void adamw_sumsq_kernel(const fat5_adamw_tenso
 template <int DT, bool KAHAN>
 __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tensor* __restrict__ tab, int n,
                                                            const float* __restrict__ partial, float beta1, float beta2, float a1,
-                                                           float a2, float wdf, float eps) {
+                                                           float a2, float wdf, float eps, const float* __restrict__ grad_coef = nullptr) {
   typedef typename adt<DT>::type T;
   __shared__ float red[4];
   const int c = blockIdx.x;
   const int ti = tensor_of_chunk(tab, n, c);
+  // global-norm clipping folded in: every gradient enters as rnd(g * coef), the value `clip_grad_norm_`'s in-place g.mul_(coef)
+  // leaves behind (torch.nn.utils.clip_grad_norm_, the reference's `max_grad_norm: 1.0`); the gradients themselves stay untouched
+  const bool clip = grad_coef != nullptr;
+  const float gcoef = clip ? *grad_coef : 1.f;
   const fat5_adamw_tensor t = tab[ti];
   // ---- rms(p) of the whole tensor from its chunk partials, fixed order; reference :69-70, :184 ----
   const int nc = (int)((t.numel + kAdamChunk - 1) / kAdamChunk);
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tens
   T* k = KAHAN ? reinterpret_cast<T*>(t.k) + e0 : nullptr;
 
   auto one = [&](float pf, float gf, float mf, float vf, float kf, float& po, float& mo, float& vo, float& ko) {
+    if (clip) gf = rnd<DT>(gf * gcoef);
     mf = rnd<DT>(mf * beta1);                         // exp_avg.mul_(beta1)                         :173
     mf = rnd<DT>(fmaf(a1, gf, mf));                   //        .add_(grad, alpha=1-beta1)
     vf = rnd<DT>(vf * beta2);                         // exp_avg_sq.mul_(beta2)                      :174

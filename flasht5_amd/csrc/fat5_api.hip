@@ -606,8 +606,8 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
 // ============================================================================================
 size_t fat5_sizeof_adamw_tensor(void) { return sizeof(fat5_adamw_tensor); }
 
-int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr_, double beta1_,
-                          double beta2_, double weight_decay_, double eps_, int dtype, int kahan, void* stream_) {
+static int adamw_step_impl(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr_, double beta1_,
+                           double beta2_, double weight_decay_, double eps_, int dtype, int kahan, const float* grad_coef, void* stream_) {
   // scalars reach the kernels as the fp32 "opmath" values the reference's ops see: each Python double is cast once
   const float beta1 = (float)beta1_, beta2 = (float)beta2_, eps = (float)eps_;
   const float a1 = (float)(1.0 - beta1_), a2 = (float)(1.0 - beta2_), wdf = (float)(-lr_ * weight_decay_);
@@ -618,19 +618,42 @@ int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int
   hipStream_t stream = (hipStream_t)stream_;
   dispatch_dtype(dtype, [&](auto dt_) {
     constexpr int DT = decltype(dt_)::value;
-    hipLaunchKernelGGL((adamw_sumsq_kernel<DT>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials);
+    hipLaunchKernelGGL((adamw_sumsq_kernel<DT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials);
     if constexpr (DT != FAT5_F32) {
       if (kahan) {
         hipLaunchKernelGGL((adamw_update_kernel<DT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2,
-                           a1, a2, wdf, eps);
+                           a1, a2, wdf, eps, grad_coef);
         return;
       }
     }
     hipLaunchKernelGGL((adamw_update_kernel<DT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2, a1,
-                       a2, wdf, eps);
+                       a2, wdf, eps, grad_coef);
   });
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "adamw launch");
+  return FAT5_OK;
+}
+int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr, double beta1,
+                          double beta2, double weight_decay, double eps, int dtype, int kahan, void* stream) {
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, kahan, nullptr, stream);
+}
+int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
+                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan,
+                                  const float* grad_coef, void* stream) {
+  if (!grad_coef) return fail(FAT5_EINVAL, "adamw: grad_coef is NULL");
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, kahan, grad_coef, stream);
+}
+int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, int dtype, void* stream_) {
+  if (!table || !partials) return fail(FAT5_EINVAL, "adamw: null table / partials");
+  if (n_tensors <= 0 || n_chunks <= 0) return fail(FAT5_EINVAL, "adamw: empty group");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "adamw: bad dtype");
+  hipStream_t stream = (hipStream_t)stream_;
+  dispatch_dtype(dtype, [&](auto dt_) {
+    constexpr int DT = decltype(dt_)::value;
+    hipLaunchKernelGGL((adamw_sumsq_kernel<DT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials);
+  });
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "adamw grad sumsq launch");
   return FAT5_OK;
 }
 

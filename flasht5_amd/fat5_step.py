@@ -267,7 +267,7 @@ def train_step(model, input_ids, labels, optimizer=None, group=None, max_grad_no
     loss.backward()
     allreduce_gradients(model, group)
     if optimizer is not None:
-        if max_grad_norm:
+        if max_grad_norm and getattr(optimizer, "max_grad_norm", None) is None:  # (AdamWScale(max_grad_norm=...) clips inside its step)
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)

@@ -207,6 +207,17 @@ typedef struct fat5_adamw_tensor {
 /* hyper-parameters as doubles: the reference passes Python floats, and e.g. (1 - beta2) is formed in double before the op casts it */
 int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
                           double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan, void* hip_stream);
+/* Global-norm gradient clipping folded into the step (torch.nn.utils.clip_grad_norm_ + AdamWScale.step in one pass; the
+ * reference trains with `max_grad_norm: 1.0`, configs/flan/fat5-flan-base.yaml): fat5_adamw_grad_sumsq writes one partial sum of
+ * squares of the GRADIENTS per 8192-element chunk (the caller sums them over every group, forms
+ * coef = min(1, max_norm / (sqrt(sum) + 1e-6)) on the device) and fat5_adamw_scale_step_clipped reads that fp32 scalar:
+ * every gradient enters the update as round_to_dtype(g * coef), the value clip_grad_norm_'s in-place multiply would have left.
+ * The gradient tensors themselves are not modified. */
+int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, int dtype,
+                          void* hip_stream);
+int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
+                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan,
+                                  const float* grad_coef, void* hip_stream);
 size_t fat5_sizeof_adamw_tensor(void);
 
 #ifdef __cplusplus

@@ -101,3 +101,48 @@ def test_adamw_scale_large_tensors_vs_oracle_on_device(dtype, kahan):
             moved = (ref_p[i].float() - (base[i].cuda().float() if i < len(base) else odd.cuda().float())).abs().max().item()
             tol = ULP[dtype] * (2 * moved + 4 * k[i].float().abs().max().item()) + 1e-12
             assert (got - want).abs().max().item() <= tol, (i, "p+k", (got - want).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("gscale", [30.0, 1e-3])
+def test_fused_gradient_clipping_matches_clip_then_step(gscale):
+    """AdamWScale(max_grad_norm=1.0): the global-norm clip folded into the step against torch's clip_grad_norm_ followed by the
+    plain step.  gscale 30: coef << 1 (every gradient scaled, rounded to bf16 like the in-place multiply); 1e-3: coef clamps to
+    1 and the result is bit-identical to the unclipped step."""
+    from flasht5_amd import AdamWScale
+    g = torch.Generator().manual_seed(7)
+    shapes = [(257, 129), (4096,), (32, 12), (1000, 64)]
+    base = [(torch.randn(*sh, generator=g) * 0.05).bfloat16().cuda() for sh in shapes]
+    grads = [(torch.randn(*sh, generator=g) * gscale * 0.01).bfloat16().cuda() for sh in shapes]
+
+    def run(fused):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = AdamWScale(ps, lr=1e-2, weight_decay=0.01, kahan_sum=True, **({"max_grad_norm": 1.0} if fused else {}))
+        norms = []
+        for it in range(3):
+            for p_, g_ in zip(ps, grads):
+                p_.grad = (g_ * (1.0 + 0.1 * it)).clone()
+            if not fused:
+                norms.append(torch.nn.utils.clip_grad_norm_(ps, 1.0).float())
+            opt.step()
+            if fused:
+                norms.append(opt.last_grad_norm.clone())
+        return [p_.detach().float() + opt.state[p_]["kahan_comp"].float() for p_ in ps], norms, ps
+
+    (pf, nf, psf), (pu, nu, _) = run(True), run(False)
+    for a, b in zip(nf, nu):
+        assert abs(a.item() - b.item()) <= 2.0 ** -7 * b.item() + 1e-6  # (torch forms the norms in the gradient dtype: bf16 here)
+    for a, b, b0 in zip(pf, pu, base):
+        moved = (b - b0.float()).abs().max().item()
+        # (the two clip coefficients differ by up to a bf16 ulp of the norm: a few gradients round the other way)
+        assert (a - b).abs().max().item() <= 2.0 ** -5 * moved + 1e-6, ((a - b).abs().max().item(), moved)
+    for p_, g_ in zip(psf, grads):
+        assert torch.equal(p_.grad, (g_ * 1.2).clone())  # the gradients themselves are not modified
+    if gscale < 1.0:  # coef == 1: same bits as the step without clipping
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = AdamWScale(ps, lr=1e-2, weight_decay=0.01, kahan_sum=True)
+        for it in range(3):
+            for p_, g_ in zip(ps, grads):
+                p_.grad = (g_ * (1.0 + 0.1 * it)).clone()
+            opt.step()
+        for p_, q_ in zip(ps, psf):
+            assert torch.equal(p_.detach(), q_.detach())
