@@ -82,10 +82,10 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 #endif
 #ifndef FAT5_B64_NLC
 // 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter the first k-step as a separate C operand
-// (measured -2 %).  Off: a C operand that is not also the destination is read by the MFMA for ~19 cycles after issue, and the
-// volatile-asm VALU ops that follow in the same gap get no hazard padding from hipcc -- correct only as long as the register
-// allocator happens to turn the dead C registers into the next accumulator (it did) and not into a VALU temporary.
-#define FAT5_B64_NLC 0
+// (-2 %).  A C operand that is not also the destination is read by the MFMA for ~19 cycles after issue, and the volatile-asm
+// VALU ops that follow in the same gap get no hazard padding from hipcc: the registers of NL / DL are therefore kept live (an empty
+// asm use two gaps after their last MFMA) so that nothing can be allocated into them inside that window.
+#define FAT5_B64_NLC 1
 #endif
 #ifndef FAT5_Q64_CREG
 #define FAT5_Q64_CREG 1  // dQ body: 1 = -delta as a 16-register broadcast per query block (C operand of the first dP k-step; 24 gaps per step:
@@ -483,6 +483,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       }
 #if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap)
+#endif
+#if FAT5_B64_NLC
+      if constexpr (g == 19) asm volatile("" ::"v"(NL));  // (keeps NL's registers out of reach of the VALU ops of gaps 16..18)
+      if constexpr (g == 27) asm volatile("" ::"v"(DL));
 #endif
       // ---- barrier + DMA ----
       if constexpr (g == 12 && !(FAT5_B64_X & 4)) sync_step(j, o_prev);
