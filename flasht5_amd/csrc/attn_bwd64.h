@@ -994,7 +994,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   // One pipelined iteration = 26 MFMA gaps.  Gap g holds, all mutually independent:
   //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1 (fragment pairs (t2, db) outer, query blocks inner);
   //          8..15: S^T[qb] of step i+1 (k-steps outer); 16, 17: dP'^T[qb] = -delta; 18..25: dP'^T[qb] += V dO^T
-  //   VALU   elements [32g/26, 32(g+1)/26) of step i (32 per lane, query block e >> 4): x = s*c2 + (cst - L2) | one gap later
+  //   VALU   32 elements per lane (query block e >> 4) opened evenly over gaps 0 .. NG-4: x = s*c2 + (cst - L2) | one gap later
   //          p = exp2(x) | one more: ds = p*dp' | pairs packed to bf16 once both halves exist
   //   LDS    gaps 0..3 the K^T fragments (t2 = 1) of step i-1; gap 4 the barrier E(i) + the DMA of step i+3; gaps 4..7 the K,
   //          gaps 12..15 the V row-major fragments of step i+1; gaps 22..25 the K^T fragments (t2 = 0) of step i
@@ -1053,7 +1053,9 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
       // ---- VALU ----
       {
-        constexpr auto lo = [](int gg) { return gg <= 0 ? 0 : (32 * gg) / NG; };  // first element whose stage A sits in gap gg
+        // first element whose stage A sits in gap gg: the 32 elements open in gaps 0 .. NG-4, so that the last one's multiply and pack
+        // (two and three gaps later) still fall inside this iteration -- no dependent tail behind the last MFMA
+        constexpr auto lo = [](int gg) { return gg <= 0 ? 0 : (gg >= NG - 3 ? 32 : (32 * gg) / (NG - 3)); };
         static_for<lo(g - 2) - lo(g - 3)>([&](auto ei) {  // stage D: pairs whose odd half was multiplied one gap ago
           constexpr int e = lo(g - 3) + decltype(ei)::value;
           if constexpr ((e & 1) == 1) stD_.template operator()<e - 1>();
