@@ -178,3 +178,26 @@ def test_default_dispatch_long_sequence_slice_vs_oracle(monkeypatch, dtype, caus
         assert torch.isfinite(got.float()).all(), name
         assert maxdiff(got, ref) <= gbound(ref, dtype), name
     assert torch.isfinite(d1).all()
+
+
+def test_bwd64_stage_split_equals_one_call():
+    """FAT5_BWD_DQ, FAT5_BWD_DKDV, FAT5_BWD_REDUCE as three calls (the dQ stage leaves the row statistics of the dK/dV stage in the
+    workspace) = one fat5_attn_bwd call, bit for bit; causal, unit range included"""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    q, k, v, _, do = make_inputs(2, 3, 1100, 1300, 64, torch.bfloat16, None, seed=31, strided=True)
+    table = (torch.randn(32, 3, generator=torch.Generator().manual_seed(6)) * 0.5).cuda()
+    rpe1d = pe.rpe1d_from_table(table)
+    for units in (None, (1, 4)):
+        a = AttentionPlan(q, k, v, do, sm_scale=0.125, causal=True, need_dbias=True, rpe1d=rpe1d, radius=128, units=units)
+        b = AttentionPlan(q, k, v, do, sm_scale=0.125, causal=True, need_dbias=True, rpe1d=rpe1d, radius=128, units=units)
+        for p_ in (a, b):
+            for t in (p_.dq, p_.dk, p_.dv):
+                t.zero_()
+            p_.forward()
+        a.backward()
+        for stage in (1, 2, 4):
+            b.backward(stage)
+        torch.cuda.synchronize()
+        for x, y in ((a.dq, b.dq), (a.dk, b.dk), (a.dv, b.dv), (a.dbias, b.dbias)):
+            assert torch.equal(x, y)
