@@ -74,6 +74,9 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)addr));
 }
 
+#ifndef FAT5_B64_FARMFMA
+#define FAT5_B64_FARMFMA 1  // far-bin sums of dS on the matrix pipe (0: one v_dot2c per packed word)
+#endif
 #ifndef FAT5_B64_PIN
 #define FAT5_B64_PIN 1
 #endif
@@ -142,7 +145,12 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
     for (int u = 0; u < 2; ++u) sk_r[u] = (8 * g4 + 4 * u + e) * Cfg::SKEW_ROW + 8 * c;
   }
   const uint32_t one2s = pack2<BF16>(1.f, 1.f);
-  const u32x4 ones = {one2s, one2s, one2s, one2s};
+  u32x4 ones = {one2s, one2s, one2s, one2s};
+#if FAT5_B64_FARMFMA
+  // (opaque: a constant tuple is re-materialised by v_mov right in front of the asm MFMA that reads it — and no wait states are
+  // generated between a VALU write and an asm consumer)
+  asm volatile("" : "+v"(ones));
+#endif
   float carry[2] = {0.f, 0.f};
   int carry_d0[2] = {0, 0};
   bool carry_valid[2] = {false, false};
@@ -273,6 +281,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   f32x16 S[2], DP[2];
   u32x4 PB[2][2], DS[2][2], TRD, TRQ;
   float facc = 0.f;  // sum of the dS of a pipelined range (one far bin)
+  // ... or, FAT5_B64_FARMFMA: ones(16x32) . dS words as a 32x16 B operand; every row of the 16x16 result = the column sums, so
+  // the sum over lanes and registers is 16x the sum of all the words' elements, whatever their layout
+  [[maybe_unused]] f32x4 facc4 = {0.f, 0.f, 0.f, 0.f};
 
   // scores of the step in the slot at byte offset `so`
   auto score_step = [&](const uint32_t so, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
@@ -460,7 +471,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       PBn[kb][t2][wd] = asm_cvt_pk<BF16>(Pv[E0], Pv[E0 + 1]);
       const uint32_t dsw = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
       DSn[kb][t2][wd] = dsw;
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) asm_dot2c<BF16>(facc, dsw, one2s);
+      if constexpr (BIAS == FAT5_BIAS_RPE1D && !FAT5_B64_FARMFMA) asm_dot2c<BF16>(facc, dsw, one2s);
     };
     static_for<32>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
@@ -605,6 +616,19 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
 #endif
       if constexpr (g == 31 && (FAT5_B64_X & 8) != 0) { Pv[31] = Pv[30]; Dv[30] = Dv[29]; Dv[31] = Dv[29]; pack_pair.template operator()<28>(); pack_pair.template operator()<30>(); }
       }
+#if FAT5_B64_FARMFMA
+      // far-bin sum of the step's dS: one 16x16x32 MFMA (16 cycles of the pipe, inside the gap's slack) per four packed words once they
+      // are complete — 16 v_dot2c_f32_bf16 per step measured 9 % of this kernel. The last group's words come from the asm ops just
+      // above (no hazard padding for asm producers: two wait states by hand)
+      if constexpr (BIAS == FAT5_BIAS_RPE1D && (g == 12 || g == 20 || g == 28 || g == 31)) {
+        constexpr int grp = g == 31 ? 3 : (g - 12) >> 3;
+        if constexpr (g == 31) asm volatile("s_nop 1" ::: "memory");
+        // (asm, accumulating in place: a builtin may pick a fresh destination, and a C operand that is not the destination is still
+        // being read when the asm VALU ops behind it — which get no hazard padding — overwrite it)
+        if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(facc4) : "v"(ones), "v"(DSn[grp >> 1][grp & 1]));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(facc4) : "v"(ones), "v"(DSn[grp >> 1][grp & 1]));
+      }
+#endif
 #if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -660,8 +684,15 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
         j += 4;
         if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-          if (side > 0) far_pos += facc; else far_neg += facc;
+#if FAT5_B64_FARMFMA
+          asm volatile("s_nop 15" : "+v"(facc4));  // (asm MFMA -> VALU read of its result: no padding is generated; tied to the tuple so that no read moves above it)
+          const float fsum = ((facc4[0] + facc4[1]) + (facc4[2] + facc4[3])) * 0.0625f;
+          facc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+          const float fsum = facc;
           facc = 0.f;
+#endif
+          if (side > 0) far_pos += fsum; else far_neg += fsum;
         }
       }
       if (j < nsteps) {

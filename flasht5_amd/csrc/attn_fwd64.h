@@ -85,6 +85,15 @@ FAT5_DEV uint32_t asm_cvt_pk(float a, float b) {
   else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (gfx950: one instruction, round-to-nearest-even like the cast)
   return r;
 }
+#ifndef FAT5_F64_LMFMA
+#define FAT5_F64_LMFMA 1  // row sums of the pipelined blocks on the matrix pipe (0: two v_add_f32 per element pair)
+#endif
+// acc += A(16x32) . B(32x16), in place (asm: a builtin may pick a fresh destination, and no hazard padding exists between asm ops)
+template <bool BF16>
+FAT5_DEV void mfma16_acc(f32x4& acc, const u32x4 A, const u32x4 B) {
+  if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
+}
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #ifndef FAT5_F64_MINW
 #define FAT5_F64_MINW 2  // waves per SIMD the register allocator leaves room for
@@ -139,6 +148,21 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   f32x16 oacc[2][DB];
   float m_run[2];
   float l_run[2][2];
+#if FAT5_F64_LMFMA
+  // Row sums of the pipelined blocks: lacc[qb] += SEL . P^T words (the B operands of the P.V products, i.e. the ROUNDED
+  // probabilities) with one 16x16x32 MFMA per four packed words instead of 16 v_add_f32. As a 32x16 B operand the words of lanes
+  // n, n+16, n+32, n+48 form column n; SEL row 4G has ones for the k-groups of parity G%2, every other row is zero, so register 0 of
+  // lane l ends up with the sum over both key halves (lanes l%32 and l%32 + 32) of ITS query column; registers 1..3 stay zero.
+  f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  u32x4 sel;
+  {
+    const int li = (int)(threadIdx.x & 63), i16 = li & 15;
+    const uint32_t one2 = pack2<BF16>(1.f, 1.f);
+    const uint32_t wv = ((i16 & 3) == 0 && (((li >> 4) ^ (i16 >> 2)) & 1) == 0) ? one2 : 0u;
+    sel = u32x4{wv, wv, wv, wv};
+    asm volatile("" : "+v"(sel));  // (resident: never re-materialised by VALU moves right in front of an asm consumer)
+  }
+#endif
 
   DmaStage<D, BN, NT> kst, vst;
   kst.init(a.ks[2], tid);
@@ -391,8 +415,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         if constexpr (c == -2) { p0 = pc[0]; p1 = pc[1]; }
         else if constexpr (c == -1) { p0 = Pr[15][0]; p1 = Pr[15][1]; }  // (slot 15 of this block's array is free until gap 15)
         else { p0 = Pr[c][0]; p1 = Pr[c][1]; }
+#if !FAT5_F64_LMFMA
         asm_add(l_run[cq][0], p0);
         asm_add(l_run[cq][1], p1);
+#endif
         const uint32_t wd = asm_cvt_pk<BF16>(p0, p1);
         if constexpr (c < 0) PB[1][1][(cr & 7) >> 1] = wd;
         else PBn[cq][cr >> 3][(cr & 7) >> 1] = wd;
@@ -412,6 +438,14 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         X[g][0] = asm_fma(S[cq][cr], c2, ad);
         X[g][1] = asm_fma(S[cq][cr + 1], c2, ad);
       }
+#if FAT5_F64_LMFMA
+      // chunk c is packed in gap c + 2: a group of four words is summed two gaps after its last one (the previous block's last group,
+      // whose words 2, 3 were packed in gaps 0, 1, in gap 3); nothing reads lacc before the next block boundary, a full gap away
+      if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+      else if constexpr (g == 7) mfma16_acc<BF16>(lacc[0], sel, PBn[0][0]);
+      else if constexpr (g == 11) mfma16_acc<BF16>(lacc[0], sel, PBn[0][1]);
+      else if constexpr (g == 14) mfma16_acc<BF16>(lacc[1], sel, PBn[1][0]);
+#endif
 #if FAT5_F64_PIN
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -446,10 +480,16 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // finish the pending block: its last two chunks, then its product (V fragments are in registers already)
   auto pipe_drain = [&]() {
     const float q0 = fast_exp2(xc[0]), q1 = fast_exp2(xc[1]);
+#if !FAT5_F64_LMFMA
     l_run[1][0] += pc[0] + q0;
     l_run[1][1] += pc[1] + q1;
+#endif
     PB[1][1][2] = pack2<BF16>(pc[0], pc[1]);
     PB[1][1][3] = pack2<BF16>(q0, q1);
+#if FAT5_F64_LMFMA
+    asm volatile("s_nop 1" : "+v"(PB[1][1]));  // (VALU write -> asm MFMA read: two wait states by hand)
+    mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+#endif
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -461,10 +501,28 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
 
   // keep l (and O) below 2^40 by an exact power of two (optimistic tiles never rescale otherwise).  A pending product was
   // formed against the old reference point: finish it first (T13 hazard: everything at the old scale is scaled exactly once).
+#if FAT5_F64_LMFMA
+  // fold the matrix-pipe row sums into l_run (both key halves hold the full sum and pair_sum adds the halves: half each, exact)
+  auto merge_lacc = [&]() {
+    asm volatile("s_nop 7" : "+v"(lacc[0]), "+v"(lacc[1]));  // (asm MFMA -> VALU read: no padding is generated; tied so no read moves above it)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      l_run[qb][0] += 0.5f * lacc[qb][0];
+      lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#endif
   auto renorm = [&]() {
+#if FAT5_F64_LMFMA
+    const float lchk = fmaxf(l_run[0][0] + l_run[0][1] + lacc[0][0], l_run[1][0] + l_run[1][1] + lacc[1][0]);
+#else
     const float lchk = fmaxf(l_run[0][0] + l_run[0][1], l_run[1][0] + l_run[1][1]);
+#endif
     if (__builtin_expect(__any(!(lchk < 0x1p40f)), 0)) {
       pipe_drain();
+#if FAT5_F64_LMFMA
+      merge_lacc();
+#endif
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const float lc = pair_sum(l_run[qb][0] + l_run[qb][1]);
@@ -523,6 +581,9 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       }
     });
     pipe_drain();
+#if FAT5_F64_LMFMA
+    merge_lacc();
+#endif
   };
   auto exact_range = [&]<int MODE>(int& t, const int te, int& slot, const float cst) {
     for (; t < te; ++t) {

@@ -21,5 +21,6 @@ def t(S, mode, what, iters=30):
         e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) / iters * 1e3)
     return best
-for S in (1024, 2048, 4096):
+SIZES = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1024, 2048, 4096)
+for S in SIZES:
     print(f"S={S}: " + " | ".join(f"{w} {m} {t(S, m, w):7.1f}" for w in ("fwd", "bwd") for m in ("none", "rpe")), flush=True)
