@@ -85,7 +85,7 @@ def test_fwd64_optimistic_softmax_edge_cases(boost, rows, at):
 
 
 def test_fwd64_agrees_with_32row_body(monkeypatch):
-    """Both forward bodies on the same inputs: o equal to one output rounding, lse to fp32 summation order."""
+    """Both forward bodies on the same inputs: o equal to one output rounding, lse to the rounding of the summed probabilities."""
     from flasht5_amd.flash_attention_v2_bias import AttentionPlan
     from flasht5_amd import positional_encoding as pe
     q, k, v, _, do = make_inputs(2, 4, 2048, 2048, 64, torch.bfloat16, None, seed=3, strided=True)
@@ -98,7 +98,15 @@ def test_fwd64_agrees_with_32row_body(monkeypatch):
         torch.cuda.synchronize()
         outs.append((plan.o.float().clone(), plan.lse.clone()))
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2.0 ** -7 * max(1.0, outs[0][0].abs().max().item())
-    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-5
+    # lse: the pipelined blocks of the 64-row body sum the probabilities AS ROUNDED for the P.V product (row sums on the matrix pipe,
+    # attn_fwd64.h), the 32-row body the unrounded ones: the sums differ by sum_i eps_i p_i with |eps_i| <= 2^-9 (independent
+    # roundings), i.e. ln l by about 2^-9 / sqrt(3) * sqrt(sum p^2) / sum p per row; allow 5 sigma on top of the fp32 ordering noise
+    bias = oracle.compute_bias(table.cpu(), 2048, 2048, True, 32, 128).cuda().float()
+    s = torch.einsum("bhmd,bhnd->bhmn", q.float(), k.float()) * 0.125 + bias
+    p = torch.softmax(s, dim=-1)
+    sigma = 2.0 ** -9 / 3 ** 0.5 * p.square().sum(-1).sqrt()
+    dl = (outs[0][1] - outs[1][1]).abs()
+    assert bool((dl <= 5 * sigma + 2e-5).all()), (dl.max().item(), sigma.max().item())
 
 
 def test_fwd64_deterministic():
