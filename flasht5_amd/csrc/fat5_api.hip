@@ -323,7 +323,9 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.dss[0] = (int64_t)p->H * MN; a.dss[1] = MN; a.dss[2] = p->N;
     a.ds_vec4 = (p->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 7) == 0);
     a.ds_vec8 = (p->N % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.ds_out) & 15) == 0);
-    if (p->causal && (stages & FAT5_BWD_DQ)) {  // tiles above the diagonal are never visited (reference zero-fills too, :153,:160)
+    // tiles above the diagonal are never visited (reference zero-fills too, :153,:160). Staged dS: the reduction knows the mask and
+    // neither reads nor needs them (no 2-byte-per-score memset, half the reduction's reads); dS written straight into dbias: zero-fill
+    if (p->causal && (stages & FAT5_BWD_DQ) && !L.ds_staged) {
       // (unit u = h * B + b occupies row b * H + h of the (B, H, M, N) tensor: a range is not contiguous there -> per unit)
       if (p->unit_count > 0) {
         for (int u = p->unit_begin; u < p->unit_begin + p->unit_count; ++u) {
@@ -393,10 +395,10 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     const int grid = (int)((chunks + 255) / 256);
     if (bf16)
       hipLaunchKernelGGL(dbias_reduce_kernel<true>, dim3(grid), dim3(256), 0, stream, a.ds_out, (uint16_t*)p->dbias, p->B,
-                         p->H, p->dbias_batch, p->dbias_heads, MN);
+                         p->H, p->dbias_batch, p->dbias_heads, MN, p->causal ? p->N : 0, p->N - p->M);
     else
       hipLaunchKernelGGL(dbias_reduce_kernel<false>, dim3(grid), dim3(256), 0, stream, a.ds_out, (uint16_t*)p->dbias, p->B,
-                         p->H, p->dbias_batch, p->dbias_heads, MN);
+                         p->H, p->dbias_batch, p->dbias_heads, MN, p->causal ? p->N : 0, p->N - p->M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "dbias_reduce launch");
   }

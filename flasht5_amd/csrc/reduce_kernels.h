@@ -9,9 +9,13 @@ namespace fat5 {
 //  the head reduction the reference gets wrong for (1,1,M,N) biases -- SURVEY Q4).
 // ds is (B,H,MN) contiguous in the bias dtype (already rounded like the reference, :720); the sum
 // runs in fp32 in a fixed order => deterministic.
+// causal_n > 0: causal mask with N = causal_n keys per row and offset P = causal_p (key n is visible to row m iff n <= m + P).
+// The dQ body never visits the tiles above the diagonal, so the staging tensor holds garbage there: masked elements are
+// zeros by definition and are not read (a chunk whose first key is masked lies entirely above the diagonal; a chunk with a
+// visible first key sits in a visited tile, whose masked elements the kernel wrote as zeros).
 template <bool BF16>
 __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __restrict__ ds, uint16_t* __restrict__ out,
-                                                           int B, int H, int Bb, int Hb, int64_t MN) {
+                                                           int B, int H, int Bb, int Hb, int64_t MN, int causal_n, int causal_p) {
   // one thread = 8 consecutive elements of one (bb, hb) output slice
   const int64_t chunks = (MN + 7) / 8;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -23,11 +27,22 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
   const int b_lo = (Bb == 1) ? 0 : bb, b_hi = (Bb == 1) ? B : bb + 1;
   const int h_lo = (Hb == 1) ? 0 : hb, h_hi = (Hb == 1) ? H : hb + 1;
   const int64_t e0 = c * 8;
-  const bool full = (e0 + 8 <= MN) && ((MN & 7) == 0);
+  const bool full = (e0 + 8 <= MN) && ((MN & 7) == 0) && (causal_n <= 0 || (causal_n & 7) == 0);
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int b = b_lo; b < b_hi; ++b)
+  bool vis[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vis[j] = true;
+  if (causal_n > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t idx = e0 + j, m = idx / causal_n;
+      vis[j] = (idx - m * causal_n) <= m + causal_p;
+    }
+  }
+  const bool any_vis = vis[0] || !full;  // (full chunks lie inside one row: keys ascend, so the first one decides)
+  for (int b = b_lo; b < b_hi && any_vis; ++b)
     for (int h = h_lo; h < h_hi; ++h) {
       const uint16_t* src = ds + ((int64_t)b * H + h) * MN + e0;
       if (full) {
@@ -40,7 +55,7 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (e0 + j < MN) acc[j] += cvt16<BF16>(src[j]);
+          if (e0 + j < MN && vis[j]) acc[j] += cvt16<BF16>(src[j]);
       }
     }
   uint16_t* dst = out + ((int64_t)bb * Hb + hb) * MN + e0;
