@@ -812,7 +812,8 @@ def test_rpe_generator_cache_follows_table_updates():
 @pytest.mark.parametrize("B,H,M,N,D,causal,dtype", [
     (4, 3, 256, 256, 64, False, torch.bfloat16), (2, 2, 200, 333, 64, False, torch.bfloat16), (3, 2, 300, 300, 64, True, torch.bfloat16),
     (6, 2, 192, 256, 64, False, torch.bfloat16),   # batch beyond the kernel's 4-element register chunk: fp32 pass-through scratch
-    (9, 1, 130, 70, 32, True, torch.float16), (4, 2, 128, 192, 128, False, torch.bfloat16), (5, 2, 520, 77, 64, True, torch.bfloat16)])
+    (9, 1, 130, 70, 32, True, torch.float16), (4, 2, 128, 192, 128, False, torch.bfloat16), (5, 2, 520, 77, 64, True, torch.bfloat16),
+    (3, 2, 256, 320, 64, True, torch.bfloat16), (2, 2, 384, 256, 64, True, torch.bfloat16)])   # causal, N % 8 == 0, M != N: whole-chunk skips of the reduction
 def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatch):
     """(1, H, M, N) bias shared by the batch: the bias gradient comes from the batch-inner dBias kernel (attn_bwd_dbias.h) --
     no (B, H, M, N) staging (workspace O(B*H*M)), each term rounded to the bias dtype before the sum like the reference
@@ -828,6 +829,7 @@ def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatc
         plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=0.25)
         plan.forward()
         plan.dbias.fill_(float("nan"))
+        plan.ws.view(torch.uint8).fill_(255)  # (NaN patterns: with a causal mask the staged path must not read what the dQ kernel never wrote)
         dq, dk, dv, db = (t.clone() for t in plan.backward())
         torch.cuda.synchronize()
         res[mode] = (dq, dk, dv, db, plan.ws.numel())
