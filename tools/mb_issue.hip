@@ -155,6 +155,68 @@ void mix(const char* what) {
   hipFree(d); hipFree(c);
 }
 
+// ---- throughput at TWO waves per SIMD (the forward's regime), wall clock over the whole launch: ns per MFMA gap and SIMD ----
+template <int SEQ>
+__global__ __launch_bounds__(512) void kfwd(float* out, int iters) {
+  const int l = threadIdx.x;
+  u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float x[8], y[8];
+  f32x2 p[8];
+  f32x4 q[8];
+  unsigned u[8];
+  for (int j = 0; j < 8; ++j) { x[j] = 0.001f * (l + j); y[j] = -1.f - j; p[j] = f32x2{x[j], y[j]}; q[j] = f32x4{0.f, 0.f, 0.f, 0.f}; u[j] = l + j; }
+  const float c = 0.999f, d = 0.0001f;
+  __shared__ unsigned lds[8192];
+  for (int i = l; i < 8192; i += blockDim.x) lds[i] = i;
+  __syncthreads();
+  u32x4 fr[4] = {a, a, a, a};
+  const unsigned laddr = (unsigned)(size_t)(lds) + (l & 63) * 16;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+      if constexpr (SEQ == 1) { OP(FMA, 0); OP(FMA, 4); OP(EXP, 1); OP(EXP, 5); OP(ADD, 2); OP(ADD, 6); OP(CVTPK, 3); }
+      else if constexpr (SEQ >= 2 && SEQ <= 4) { OP(FMA, 0); OP(FMA, 4); OP(EXP, 1); OP(EXP, 5); OP(CVTPK, 3); if ((g & 3) == 3) OP(MFMA16, 7); }
+      else if constexpr (SEQ == 5) { OP(MUL, 0); OP(MUL, 4); OP(EXP, 1); OP(EXP, 5); OP(CVTPK, 3); if ((g & 3) == 3) OP(MFMA16, 7); }
+      else if constexpr (SEQ == 6) { OP(EXP, 1); OP(EXP, 5); }
+      else if constexpr (SEQ == 7) { OP(FMA, 0); OP(FMA, 4); OP(EXP, 1); OP(EXP, 5); }
+      else if constexpr (SEQ == 8) { OP(FMA, 0); OP(FMA, 4); OP(EXP, 1); OP(EXP, 5); OP(PERM, 3); if ((g & 3) == 3) OP(MFMA16, 7); }
+      if constexpr (SEQ == 3 || SEQ == 4) { if ((g & 3) != 3) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[g & 3]) : "v"(laddr)); }
+      if constexpr (SEQ == 4) { if ((g & 1) == 0) asm volatile("s_waitcnt lgkmcnt(2)"); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)");
+  float r = 0.f;
+  for (int i = 0; i < 4; ++i) r += acc[i][0] + __builtin_bit_cast(float, fr[i][0]);
+  for (int j = 0; j < 8; ++j) r += x[j] + y[j] + p[j][0] + q[j][0] + (float)u[j];
+  if (r == 123.456f) out[l] = r;
+}
+template <int SEQ>
+void fwdmix(const char* what) {
+  float* d;
+  hipMalloc(&d, 4096);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 4000;
+  for (int wps = 1; wps <= 2; ++wps) {
+    kfwd<SEQ><<<256, 256 * wps>>>(d, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kfwd<SEQ><<<256, 256 * wps>>>(d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("fwd-mix %-52s %d wave/SIMD: %6.2f ns per MFMA and SIMD (%5.1f cycles at 2.4 GHz)\n", what, wps, ms * 1e6 / (iters * 16.0 * wps),
+           ms * 1e6 / (iters * 16.0 * wps) * 2.4);
+  }
+  hipFree(d);
+}
+
 template <int KIND>
 void row() {
   for (int wps = 1; wps <= 2; ++wps) {
@@ -173,5 +235,8 @@ int main() {
   mix<9>("2fma 2exp 2mul cvt (dQ body)"); mix<10>("2fma 2exp 2add cvt (forward)"); mix<11>("2fma 2exp cvt (forward, sums on MFMA)");
   mix<12>("dK/dV gap + ds_read_b128"); mix<13>("dK/dV gap + 2 ds_read_b64"); mix<14>("dK/dV gap + ds_read_b128 + lgkmcnt(2)");
   mix<15>("dK/dV gap + ds_read_b128 + lgkmcnt(0)"); mix<16>("dK/dV gap + 2 ds_read_b64 + lgkmcnt(2)");
+  fwdmix<0>("MFMA only"); fwdmix<6>("2 exp"); fwdmix<7>("2 fma 2 exp"); fwdmix<1>("2 fma 2 exp 2 add cvt (round-2 forward gap)");
+  fwdmix<2>("2 fma 2 exp cvt + MFMA16 per 4 gaps"); fwdmix<3>("... + 3 ds_read_b128 per 4 gaps"); fwdmix<4>("... + s_waitcnt per 2 gaps");
+  fwdmix<5>("2 mul 2 exp cvt + MFMA16 per 4 gaps"); fwdmix<8>("2 fma 2 exp perm + MFMA16 per 4 gaps");
   return 0;
 }
