@@ -84,6 +84,10 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   int* sb = reinterpret_cast<int*>(sv + n1);            // [n1] bucket ids
   const int h = blockIdx.x, tid = threadIdx.x;
   const int nparts = B * nblk;                          // partial rows of this head: (b, blk) -> b*H*nblk + h*nblk + blk
+  // bucket ids: in flight together with the partial rows (loaded after the first barrier they cost a memory round trip of their own)
+  int bkr[5];  // (n1 <= 2 * 2048 + 1)
+#pragma unroll
+  for (int u = 0; u < 5; ++u) bkr[u] = (bucket && tid + 1024 * u < n1) ? bucket[tid + 1024 * u] : 0;
   for (int wv = tid; wv < 4 * n1; wv += 1024) {
     const int i = wv % n1, g = wv / n1;
     float acc = 0.f;
@@ -108,12 +112,14 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
     }
     sv4[g * n1 + i] = acc;
   }
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+    if (tid + 1024 * u < n1) sb[tid + 1024 * u] = bkr[u];
   __syncthreads();
   for (int i = tid; i < n1; i += 1024) {
     const float acc = (sv4[i] + sv4[n1 + i]) + (sv4[2 * n1 + i] + sv4[3 * n1 + i]);
     sv[i] = acc;
     if (out1d) out1d[(int64_t)h * n1 + i] = acc;
-    if (bucket) sb[i] = bucket[i];
   }
   if (!dtable) return;
   __syncthreads();
