@@ -504,7 +504,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
 #if FAT5_F64_LMFMA
   // fold the matrix-pipe row sums into l_run (both key halves hold the full sum and pair_sum adds the halves: half each, exact)
   auto merge_lacc = [&]() {
-    asm volatile("s_nop 7" : "+v"(lacc[0]), "+v"(lacc[1]));  // (asm MFMA -> VALU read: no padding is generated; tied so no read moves above it)
+    asm volatile("s_nop 11" : "+v"(lacc[0]), "+v"(lacc[1]));  // (asm MFMA -> VALU read: no padding is generated; tied so no read moves above it)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       l_run[qb][0] += 0.5f * lacc[qb][0];
