@@ -35,4 +35,6 @@ hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bia
   return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
 }
 
+size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D>::smem(R, bias); }
+
 }  // namespace fat5

@@ -168,7 +168,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   const int f64_env = env_int("FAT5_FWD64", -1);
   const long ctas256 = bh * ((p->M + 255) / 256);
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 && env_int("FAT5_FWD_NW", 0) == 0 &&
-      (f64_env == 1 || (p->dtype == FAT5_BF16 && ctas256 >= 512))) {
+      (f64_env == 1 || (p->dtype == FAT5_BF16 && ctas256 >= 512 &&
+                        // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
+                        smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     fn = launch_fwd64_d64;
     nw = 4;
     a.n_mblk = (p->M + 255) / 256;
