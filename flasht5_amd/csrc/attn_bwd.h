@@ -64,7 +64,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
+  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
   FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
@@ -180,7 +180,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
       if (bias_dma) bdm.issue(brs, 0, sB, tid);
   }
   // (table after the first tile's DMA is in flight: one memory round trip for the prologue)
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   __syncthreads();
   // see attn_fwd.h: keep the compiler's waitcnt model from chaining the loop's MFMAs to the tile prefetch
 #pragma unroll
@@ -240,30 +240,17 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bias_log2(bv[r]) + nL2);
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          // one straight-line path for far, edge and band blocks: four aligned 16-byte reads of this lane's padded table copy
+          // (the window start is clamped into the copy -- attn_common.h)
           const int R = a.R;
-          const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;
-          if (dmax <= -R || dmin >= R) {
-            const float ad = ((dmax <= -R) ? cst_neg : cst_pos) + nL2;
+          const float4* tp4 = reinterpret_cast<const float4*>(sTa + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, ad);
-          } else if (dmin > -R && dmax < R) {
-            // interior of the band: four aligned 16-byte reads of this lane's table copy
-            const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 bq = tp4[2 * g];
-              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nL2);
-              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nL2);
-              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nL2);
-              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nL2);
-            }
-          } else {
-            const int dl = nb + 4 * hi - qrow;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int d = dl + (r & 3) + 8 * (r >> 2);
-              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nL2);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const float4 bq = tp4[2 * g];
+            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nL2);
+            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nL2);
+            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nL2);
+            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nL2);
           }
         } else {
 #pragma unroll
@@ -479,9 +466,9 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   }
 
   // RPE: table + per-wave private diagonal accumulators in LDS
-  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE);
+  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int n1 = 2 * a.R + 1;
-  float* sD0 = sT + 4 * rpe_n1p(a.R);  // NW wave-private (2R+1) diagonal accumulators behind the four table copies
+  float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);  // NW wave-private (2R+1) diagonal accumulators behind the four table copies
   float* sD = sD0 + w * n1;
   // Per-wave 32x64 bf16 "skew tile": dS of a near block is stored with row q shifted by -q (element (q, k) at column
   // k - q + 31), so diagonals become columns.  Column sums = ones(32x32) x tile on the matrix pipe (4 MFMAs, operand
@@ -634,7 +621,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   }
   // (after the first tile's loads are in flight: ONE memory round trip for the whole prologue instead of two)
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
     for (int i = tid; i < n1 * NW; i += NT) sD0[i] = 0.f;
     for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
@@ -723,32 +710,18 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
             }
           }
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          // one straight-line path for far, edge and band blocks: entries of r = 4g..4g+3 are 4 consecutive DEscending entries of
+          // this lane's padded table copy (alignment (R + krow - 3) & 3 is constant): four aligned 16-byte reads, window clamped
           const int R = a.R;
-          const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
-          if (dmax <= -R || dmin >= R) {
-            const float c = (dmax <= -R) ? cst_neg : cst_pos;
+          const int al = (R + krow - 3) & 3;
+          const float* tb = sT + al * rpe_n1p(R) + rpe_clamp_desc(R + krow - mb - 4 * hi - 3 - al, R);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c);
-          } else if (dmin > -R && dmax < R) {
-            // interior of the band: entries of r = 4g..4g+3 are 4 consecutive DEscending table entries; this lane's
-            // alignment (R + krow - 3) & 3 is constant -> four aligned 16-byte reads of its table copy
-            const int al = (R + krow - 3) & 3;
-            const float* tb = sT + al * rpe_n1p(R) + (R + krow - mb - 4 * hi - 3 - al);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
-              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
-              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
-              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
-              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
-            }
-          } else {
-            const int d0 = krow - mb - 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int d = d0 - ((r & 3) + 8 * (r >> 2));
-              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
+            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
+            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
+            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
+            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
           }
         } else {
 #pragma unroll

@@ -133,9 +133,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   }
 
   // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators, skew tile) ----
-  float* sT = reinterpret_cast<float*>(smem + Cfg::RING);
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RING) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int n1 = 2 * a.R + 1;
-  float* sD0 = sT + 4 * rpe_n1p(a.R);
+  float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);
   char* sG = smem + Cfg::RING + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
   const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
   int sk_r[2];
@@ -228,7 +228,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   // slot 3 is read (against an all-zero P / dS) before anything lands in it: finite contents
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-    rpe_table_fill(sT, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
     for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
     for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
@@ -777,7 +777,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sT = reinterpret_cast<float*>(smem + Cfg::RING);
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RING) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
   int b, h, mblk;
@@ -888,7 +888,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   for (int i = 0; i < 3; ++i)
     if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   wait_dma_all();
   __syncthreads();
 #pragma unroll

@@ -206,10 +206,21 @@ FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile) {
 // (copy_c[m] = T[m + c]).  A lane's 16 gathers per 32x32 block are four runs of 4 consecutive entries whose
 // alignment (mod 4) is a per-lane constant, so it reads its own copy with 4 aligned ds_read_b128 instead of
 // 16 ds_read_b32.  Copy 0 doubles as the plain table (constants, clamped edge path).
+// Every copy is PADDED by kRpePad saturated entries on both sides (T[0] below, T[2R] above): a block that is partly or
+// entirely outside the band reads the same way as one inside it -- one straight-line bias path per block, the window
+// start clamped into the table (rpe_clamp_*) instead of a three-way branch over far / interior / edge blocks that keeps
+// hipcc from scheduling across it.  Kernels hold `sT` = raw base + kRpePad, so that sT[d + R] is entry d of copy 0 for
+// d in [-R - kRpePad, R + kRpePad] and copy c starts at sT + c * rpe_n1p(R) - c (the index expressions of the unpadded layout).
 // ------------------------------------------------------------------------------------------
-FAT5_DEV constexpr int rpe_n1p(int R) { return (2 * R + 1 + 3) & ~3; }
-__host__ __device__ constexpr size_t rpe_table_bytes(int R) { return (size_t)4 * ((2 * R + 1 + 3) & ~3) * 4; }
-FAT5_DEV void rpe_table_fill(float* sT, const float* rpe1d_h, int R, int tid, int nthreads) {
+constexpr int kRpePad = 96;  // >= 63 (an edge block's overhang) + 32 (a clamped window stays in the constant region); multiple of 4
+__host__ __device__ constexpr int rpe_n1p(int R) { return (2 * R + 1 + 2 * kRpePad + 3) & ~3; }
+__host__ __device__ constexpr size_t rpe_table_bytes(int R) { return (size_t)4 * rpe_n1p(R) * 4; }
+// window start (relative to sT + copy * rpe_n1p(R), a multiple of 4) of a lane's 28-entry run, clamped so that the run stays
+// inside the padded copy: ascending runs [pos, pos + 27], descending runs [pos - 24, pos + 3]
+FAT5_DEV int rpe_clamp_asc(int pos, int R) { return min(max(pos, -kRpePad), rpe_n1p(R) - kRpePad - 28); }
+FAT5_DEV int rpe_clamp_desc(int pos, int R) { return min(max(pos, -kRpePad + 24), rpe_n1p(R) - kRpePad - 4); }
+// `sT_raw`: the table's raw LDS base (16-byte aligned)
+FAT5_DEV void rpe_table_fill(float* sT_raw, const float* rpe1d_h, int R, int tid, int nthreads) {
   const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
   // eight global loads in flight per round (a prologue that waits for each load before the next costs a memory round
   // trip per iteration: +4.6 k cycles measured at cfg2)
@@ -217,14 +228,14 @@ FAT5_DEV void rpe_table_fill(float* sT, const float* rpe1d_h, int R, int tid, in
     float vv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthreads;
+      const int i = min(i0 + u * nthreads, 4 * n1p - 1);
       const int c = i / n1p, m = i - c * n1p;
-      vv[u] = (i < 4 * n1p && m + c < n1) ? rpe1d_h[m + c] : 0.f;
+      vv[u] = rpe1d_h[min(max(m + c - kRpePad, 0), n1 - 1)];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * nthreads;
-      if (i < 4 * n1p) sT[i] = vv[u] * kLog2e;
+      if (i < 4 * n1p) sT_raw[i] = vv[u] * kLog2e;
     }
   }
 }

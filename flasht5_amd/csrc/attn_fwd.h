@@ -117,7 +117,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + 2 * Cfg::STAGE);  // optimistic pass overflowed -> redo exactly
-  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + 16);
+  float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE + 16) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   constexpr int QG = SPLIT ? NW / 2 : NW;              // query groups (32 rows each) per workgroup
@@ -234,7 +234,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     }
   };
   stage_first();
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   __syncthreads();  // tile 0, sT, sFlag visible
   // Touch the Q fragments here: their global loads are otherwise still "pending" in the compiler's waitcnt model at
   // the loop header, and every QK^T MFMA inside the loop then waits on vmcnt, i.e. on the K/V PREFETCH of its own tile.
@@ -339,35 +339,18 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bias_log2(bv[r]));
         } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          // one straight-line path for far, edge and band blocks: four aligned 16-byte reads of this lane's padded table copy
+          // (entries of r = 4g .. 4g+3 are consecutive; the window start is clamped into the copy -- attn_common.h)
           const int R = a.R;
-          const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;  // wave-uniform
-          if (dmax <= -R || dmin >= R) {
-            cb = (dmax <= -R) ? cst_neg : cst_pos;
-            if (!folded) {
+          folded = false;
+          const float4* tp4 = reinterpret_cast<const float4*>(sTa + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
 #pragma unroll
-              for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, cb);
-            }
-          } else if (dmin > -R && dmax < R) {
-            // interior of the band: no clamping -> the 16 gathers are base + immediate offset, no index VALU
-            folded = false;
-            // entries of r = 4g .. 4g+3 are consecutive and 16-byte aligned in this lane's table copy
-            const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 bq = tp4[2 * g];
-              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
-              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y);
-              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z);
-              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
-            }
-          } else {
-            folded = false;
-            const int dl = nb + 4 * hi - qrow;  // delta of r = 0
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int d = dl + (r & 3) + 8 * (r >> 2);
-              s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
-            }
+          for (int g = 0; g < 4; ++g) {
+            const float4 bq = tp4[2 * g];
+            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
+            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y);
+            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z);
+            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
           }
         } else {
           if (!folded) {

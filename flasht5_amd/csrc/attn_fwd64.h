@@ -107,7 +107,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + Cfg::FLAG);
-  float* sT = reinterpret_cast<float*>(smem + Cfg::TAB);
+  float* sT = reinterpret_cast<float*>(smem + Cfg::TAB) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int b, h, mblk;
@@ -207,7 +207,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     __syncthreads();
   };
   stage_first();
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   wait_dma_all();
   __syncthreads();
   // per-lane LDS addresses of the fragment reads (ring base folded in; slot / block / step offsets are immediates)
