@@ -11,11 +11,11 @@
 
 namespace fat5 {
 
-template <int D, bool BF16, int BIAS, int NW>
+template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
 static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
   size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
   if (const char* e = getenv("FAT5_FWD_LDS_PAD")) smem += (size_t)atoi(e) * 1024;  // developer knob: limit occupancy
-  auto kern = attn_fwd_kernel<D, BF16, BIAS, NW>;
+  auto kern = attn_fwd_kernel<D, BF16, BIAS, NW, BDMA>;
   static size_t configured = 0;  // per instantiation; benign race (idempotent call)
   if (smem > 48 * 1024 && smem > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -26,10 +26,10 @@ static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool BDMA = false>
 static hipError_t launch_split(const AttnArgs& a, int grid, hipStream_t s) {
   size_t smem = FwdCfg<D, 4, true>::smem(a.R, BIAS);
-  auto kern = attn_fwd_split_kernel<D, BF16, BIAS, 4>;
+  auto kern = attn_fwd_split_kernel<D, BF16, BIAS, 4, BDMA>;
   static size_t configured = 0;
   if (smem > 48 * 1024 && smem > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -40,18 +40,20 @@ static hipError_t launch_split(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool BDMA = false>
 static hipError_t launch_nw(const AttnArgs& a, int nw, int grid, hipStream_t s) {
-  if (nw == -4) return launch_split<D, BF16, BIAS>(a, grid, s);  // two waves per 32 query rows (short sequences)
-  if (nw == 2) return launch_one<D, BF16, BIAS, 2>(a, grid, s);
-  if (nw == 8) return launch_one<D, BF16, BIAS, 8>(a, grid, s);
-  return launch_one<D, BF16, BIAS, 4>(a, grid, s);
+  if (nw == -4) return launch_split<D, BF16, BIAS, BDMA>(a, grid, s);  // two waves per 32 query rows (short sequences)
+  if (nw == 2) return launch_one<D, BF16, BIAS, 2, BDMA>(a, grid, s);
+  if (nw == 8) return launch_one<D, BF16, BIAS, 8, BDMA>(a, grid, s);
+  return launch_one<D, BF16, BIAS, 4, BDMA>(a, grid, s);
 }
 template <int D, bool BF16>
 static hipError_t launch_bias(const AttnArgs& a, int bias, int nw, int grid, hipStream_t s) {
   switch (bias) {
     case FAT5_BIAS_NONE: return launch_nw<D, BF16, FAT5_BIAS_NONE>(a, nw, grid, s);
-    case FAT5_BIAS_DENSE: return launch_nw<D, BF16, FAT5_BIAS_DENSE>(a, nw, grid, s);
+    case FAT5_BIAS_DENSE:  // (bias tiles by LDS-DMA -- aligned, unit-stride rows, no packed batch -- as a compile-time fact: attn_fwd.h)
+      return (a.bias_dma && a.cu_q == nullptr) ? launch_nw<D, BF16, FAT5_BIAS_DENSE, true>(a, nw, grid, s)
+                                                : launch_nw<D, BF16, FAT5_BIAS_DENSE>(a, nw, grid, s);
     default: return launch_nw<D, BF16, FAT5_BIAS_RPE1D>(a, nw, grid, s);
   }
 }
