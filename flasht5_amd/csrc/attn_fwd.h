@@ -347,7 +347,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
             const int R = a.R;
             folded = false;
             const float4* tp4 = reinterpret_cast<const float4*>(sTa + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
-  #pragma unroll
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 bq = tp4[2 * g];
               s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
@@ -362,7 +362,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
             if (dmax <= -R || dmin >= R) {
               cb = (dmax <= -R) ? cst_neg : cst_pos;
               if (!folded) {
-  #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, cb);
               }
             } else if (dmin > -R && dmax < R) {
@@ -370,7 +370,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
               folded = false;
               // entries of r = 4g .. 4g+3 are consecutive and 16-byte aligned in this lane's table copy
               const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-  #pragma unroll
+#pragma unroll
               for (int g = 0; g < 4; ++g) {
                 const float4 bq = tp4[2 * g];
                 s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
@@ -381,7 +381,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
             } else {
               folded = false;
               const int dl = nb + 4 * hi - qrow;  // delta of r = 0
-  #pragma unroll
+#pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int d = dl + (r & 3) + 8 * (r >> 2);
                 s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
