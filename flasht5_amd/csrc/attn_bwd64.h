@@ -331,31 +331,17 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       const f32x16& dp = DP[kb];
       const int k0 = kw0 + 32 * kb, krow = k0 + lq;
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
         const int R = a.R;
-        const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
-        if (dmax <= -R || dmin >= R) {
-          const float c = (dmax <= -R) ? cst_neg : cst_pos;
+        const int al = (R + krow - 3) & 3;
+        const float* tb = sT + al * rpe_n1p(R) + rpe_clamp_desc(R + krow - mb - 4 * hi - 3 - al, R);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, c);
-        } else if (dmin > -R && dmax < R) {
-          // interior of the band: four aligned 16-byte reads of this lane's table copy (see attn_bwd.h)
-          const int al = (R + krow - 3) & 3;
-          const float* tb = sT + al * rpe_n1p(R) + (R + krow - mb - 4 * hi - 3 - al);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
-            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
-            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
-            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
-            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
-          }
-        } else {
-          const int d0 = krow - mb - 4 * hi;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = d0 - ((r & 3) + 8 * (r >> 2));
-            s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
-          }
+        for (int g = 0; g < 4; ++g) {
+          const float4 bq = *reinterpret_cast<const float4*>(tb - 8 * g);
+          s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.w);
+          s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.z);
+          s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.y);
+          s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.x);
         }
       } else {
 #pragma unroll
@@ -964,29 +950,16 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       const int qr0 = qw0 + 32 * qb, qrow = qr0 + lq;
       const float nl = nL2[qb];
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
         const int R = a.R;
-        const int dmin = nb - (qr0 + 31), dmax = nb + 31 - qr0;
-        if (dmax <= -R || dmin >= R) {
-          const float ad = ((dmax <= -R) ? cst_neg : cst_pos) + nl;
+        const float4* tp4 = reinterpret_cast<const float4*>(sTa[qb] + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, ad);
-        } else if (dmin > -R && dmax < R) {
-          const float4* tp4 = reinterpret_cast<const float4*>(sTa[qb] + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 bq = tp4[2 * g];
-            s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nl);
-            s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nl);
-            s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nl);
-            s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nl);
-          }
-        } else {
-          const int dl = nb + 4 * hi - qrow;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int d = dl + (r & 3) + 8 * (r >> 2);
-            s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R] + nl);
-          }
+        for (int g = 0; g < 4; ++g) {
+          const float4 bq = tp4[2 * g];
+          s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x + nl);
+          s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y + nl);
+          s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z + nl);
+          s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w + nl);
         }
       } else {
 #pragma unroll
