@@ -281,33 +281,17 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
           bool folded = fold_ok;
           float cb = 0.f;
           if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+            // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
             const int R = a.R;
-            const int dmin = nb - (qr0 + 31), dmax = nb + 31 - qr0;  // wave-uniform
-            if (dmax <= -R || dmin >= R) {
-              cb = (dmax <= -R) ? cst_neg : cst_pos;
-              if (!folded) {
+            folded = false;
+            const float4* tp4 = reinterpret_cast<const float4*>(sTa + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sq[r] = fmaf(sq[r], c2, cb);
-              }
-            } else if (dmin > -R && dmax < R) {
-              folded = false;
-              const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float4 bq = tp4[2 * g];
-                sq[4 * g + 0] = fmaf(sq[4 * g + 0], c2, bq.x);
-                sq[4 * g + 1] = fmaf(sq[4 * g + 1], c2, bq.y);
-                sq[4 * g + 2] = fmaf(sq[4 * g + 2], c2, bq.z);
-                sq[4 * g + 3] = fmaf(sq[4 * g + 3], c2, bq.w);
-              }
-            } else {
-              folded = false;
-              const int dl = nb + 4 * hi - qrow;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int d = dl + (r & 3) + 8 * (r >> 2);
-                sq[r] = fmaf(sq[r], c2, sT[min(max(d, -R), R) + R]);
-              }
+            for (int g = 0; g < 4; ++g) {
+              const float4 bq = tp4[2 * g];
+              sq[4 * g + 0] = fmaf(sq[4 * g + 0], c2, bq.x);
+              sq[4 * g + 1] = fmaf(sq[4 * g + 1], c2, bq.y);
+              sq[4 * g + 2] = fmaf(sq[4 * g + 2], c2, bq.z);
+              sq[4 * g + 3] = fmaf(sq[4 * g + 3], c2, bq.w);
             }
           } else {
             if (!folded) {
