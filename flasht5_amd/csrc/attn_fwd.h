@@ -356,36 +356,19 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
               s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
             }
           } else {
-            // (the unsplit instantiations sit at the 168-register limit of three waves per SIMD: the straight-line form spills 55 registers there)
+            // (the unsplit instantiations sit at the 168-register limit of three waves per SIMD: left to itself hipcc hoists the table reads of
+            // the straight-line form far up and spills 55 registers -- they are pinned behind a scheduling barrier here)
             const int R = a.R;
-            const int dmin = nb - (qrow0 + 31), dmax = nb + 31 - qrow0;  // wave-uniform
-            if (dmax <= -R || dmin >= R) {
-              cb = (dmax <= -R) ? cst_neg : cst_pos;
-              if (!folded) {
+            folded = false;
+            __builtin_amdgcn_sched_barrier(0);
+            const float4* tp4 = reinterpret_cast<const float4*>(sTa + rpe_clamp_asc(R + nb + 4 * hi - qrow - ((R - qrow) & 3), R));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, cb);
-              }
-            } else if (dmin > -R && dmax < R) {
-              // interior of the band: no clamping -> the 16 gathers are base + immediate offset, no index VALU
-              folded = false;
-              // entries of r = 4g .. 4g+3 are consecutive and 16-byte aligned in this lane's table copy
-              const float4* tp4 = reinterpret_cast<const float4*>(sTa + (R + nb + 4 * hi - qrow - ((R - qrow) & 3)));
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const float4 bq = tp4[2 * g];
-                s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
-                s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y);
-                s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z);
-                s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
-              }
-            } else {
-              folded = false;
-              const int dl = nb + 4 * hi - qrow;  // delta of r = 0
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int d = dl + (r & 3) + 8 * (r >> 2);
-                s[r] = fmaf(s[r], c2, sT[min(max(d, -R), R) + R]);
-              }
+            for (int g = 0; g < 4; ++g) {
+              const float4 bq = tp4[2 * g];
+              s[4 * g + 0] = fmaf(s[4 * g + 0], c2, bq.x);
+              s[4 * g + 1] = fmaf(s[4 * g + 1], c2, bq.y);
+              s[4 * g + 2] = fmaf(s[4 * g + 2], c2, bq.z);
+              s[4 * g + 3] = fmaf(s[4 * g + 3], c2, bq.w);
             }
           }
         } else {
