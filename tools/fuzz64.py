@@ -1,13 +1,14 @@
 """developer fuzz of the 64-wide bodies (forward, dK/dV, dQ forced on): random ragged shapes, causal or not, no bias / T5 bias with a
 random radius; o, dq, dk, dv and the table gradient against the oracle with the bounds of tests/test_bwd64_gpu.py.
-usage: python tools/fuzz64.py [n_cases] [seed]"""
+usage: [FUZZ_FORCE64=0] python tools/fuzz64.py [n_cases] [seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["FAT5_FWD64"] = "1"; os.environ["FAT5_BWD64"] = "1"; os.environ["FAT5_BWDQ64"] = "1"
+if os.environ.get("FUZZ_FORCE64", "1") != "0":  # FUZZ_FORCE64=0: the default dispatch (32-row bodies at these sizes)
+    os.environ["FAT5_FWD64"] = "1"; os.environ["FAT5_BWD64"] = "1"; os.environ["FAT5_BWDQ64"] = "1"
 import torch
 import oracle
-from attn_helpers import make_inputs, oracle_all, maxdiff
+from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
 from test_attention_gpu import bound, gbound, _rpe_case
 from test_bwd64_gpu import _grads, _table_truth
 
@@ -32,11 +33,16 @@ for i in range(n):
     ref = oracle_all(q, k, v, bias, do, scale, causal)
     got = _grads(q, k, v, do, causal, scale, table, True, md)
     msgs = []
-    if maxdiff(got["o"], ref["o"]) > bound(ref["o"], dtype):
-        msgs.append(f"o {maxdiff(got['o'], ref['o']):.3e} > {bound(ref['o'], dtype):.3e}")
-    for key in ("dq", "dk", "dv"):
-        if not torch.isfinite(got[key].float()).all() or maxdiff(got[key], ref[key]) > gbound(ref[key], dtype):
-            msgs.append(f"{key} {maxdiff(got[key], ref[key]):.3e} > {gbound(ref[key], dtype):.3e}")
+    lp = None  # the reference's own rule beside the absolute bound: at most twice the error of eager attention in the input dtype
+    for key in ("o", "dq", "dk", "dv"):
+        lim = bound(ref[key], dtype) if key == "o" else gbound(ref[key], dtype)
+        e = maxdiff(got[key], ref[key])
+        if torch.isfinite(got[key].float()).all() and e <= lim:
+            continue
+        if lp is None:
+            lp = eager_lowprec_errors(q, k, v, bias, do, scale, causal, ref)
+        if not torch.isfinite(got[key].float()).all() or e > 2 * lp[key]:
+            msgs.append(f"{key} {e:.3e} > {lim:.3e} and > 2 x eager {lp[key]:.3e}")
     if table is not None:
         want, allow = _table_truth(q, k, v, bias, got["o"], ref["L"], do, scale, causal, table, M, N, True, md)
         err = (got["dtable"].cpu() - want).abs()
