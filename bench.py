@@ -289,6 +289,21 @@ def load_traffic(kernel_key, S, mode):
         return None
 
 
+def spawn_ranks(n):
+    """re-exec this command line under torch.distributed.run with n local ranks (127.0.0.1 rendezvous on a free port)"""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,11 +317,31 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: launch the N ranks ourselves, one process per GPU, exactly the way the driver's
+        # torchrun line would (the reference is launched by torchrun too and divides by torch.cuda.device_count(),
+        # train_flash_t5.py:95).  Rank 0 of the children prints the JSON line; this parent only forwards the exit code.
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("FAT5_BENCH_RENDEZVOUS_ONLY") == "1":
+        # control-flow check that runs without a GPU (tests/test_distributed_cpu.py): rendezvous + one all-reduce over gloo
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "n_gpus": world, "gpus_arg": args.gpus, "sum_of_ranks_plus_1": t.item(),
+                              "scaling": args.scaling}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    if world > 1 and os.environ.get("FAT5_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(FAT5_BENCH_SHARE_GPU=1 runs the N-rank control flow on one GPU over gloo: a developer dry run)")
     # developer dry run of the N > 1 control flow on a one-GPU box: FAT5_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # uses gloo (RCCL refuses two ranks on one device); never set by the driver
     share = os.environ.get("FAT5_BENCH_SHARE_GPU") == "1"
