@@ -39,14 +39,14 @@ class AttnParams(ctypes.Structure):
         ("dbias", ctypes.c_void_p), ("dbias_batch", ctypes.c_int32), ("dbias_heads", ctypes.c_int32),
         ("drpe1d", ctypes.c_void_p), ("rpe_bucket", ctypes.c_void_p), ("drpe_table", ctypes.c_void_p),
         ("rpe_num_buckets", ctypes.c_int32), ("unit_begin", ctypes.c_int32), ("unit_count", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("variant", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
 EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
-    "fat5_attn_bwd_stages",
+    "fat5_attn_bwd_stages", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
     "fat5_ce_fwd", "fat5_ce_bwd",
     "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
@@ -77,6 +77,9 @@ def load():
     lib.fat5_attn_bwd_launches.argtypes = [ctypes.POINTER(AttnParams)]
     lib.fat5_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.fat5_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(AttnParams)]
+    lib.fat5_rpe1d_from_table.restype = ctypes.c_int
+    lib.fat5_rpe1d_from_table.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_void_p]
     i64, f32, vp, i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
     lib.fat5_rmsnorm_fwd.restype = ctypes.c_int
     lib.fat5_rmsnorm_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, f32, i32, i32, vp]
@@ -94,9 +97,9 @@ def load():
     lib.fat5_ce_bwd.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, f32, f32, i64, i32, vp]
     lib.fat5_adamw_scale_step.restype = ctypes.c_int
     f64 = ctypes.c_double
-    lib.fat5_adamw_scale_step.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, vp]
+    lib.fat5_adamw_scale_step.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, i32, vp]
     lib.fat5_adamw_scale_step_clipped.restype = ctypes.c_int
-    lib.fat5_adamw_scale_step_clipped.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, vp, vp]
+    lib.fat5_adamw_scale_step_clipped.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, i32, vp, vp]
     lib.fat5_adamw_grad_sumsq.restype = ctypes.c_int
     lib.fat5_adamw_grad_sumsq.argtypes = [vp, i32, i32, vp, i32, vp]
     lib.fat5_sizeof_adamw_tensor.restype = ctypes.c_size_t
@@ -106,6 +109,37 @@ def load():
                           f"binding {ctypes.sizeof(AttnParams)} B")
     _lib = lib
     return lib
+
+
+# fat5_attn_params.variant bits (include/fat5.h `enum fat5_variant`): tests and profilers force / forbid a kernel body per call
+V_FWD64_ON, V_FWD64_OFF, V_KV64_ON, V_KV64_OFF, V_Q64_ON, V_Q64_OFF = 1, 2, 4, 8, 16, 32
+V_DBIAS_STAGED, V_DBIAS_INKERNEL, V_NO_FUSE, V_NO_SPLIT = 64, 128, 256, 512
+_variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)
+
+
+def set_variant(bits):
+    """Test / profiling hook: OR of V_* bits carried by every subsequent attention call of this process (ctypes path and the
+    C++ binding alike); returns the previous value.  Production code never calls this."""
+    global _variant
+    prev, _variant = _variant, int(bits)
+    nat = native()
+    if nat is not None:
+        nat.set_variant(int(bits))
+    return prev
+
+
+class variant:
+    """`with _lib.variant(_lib.V_FWD64_ON | _lib.V_KV64_ON): ...`"""
+
+    def __init__(self, bits):
+        self.bits = bits
+
+    def __enter__(self):
+        self.prev = set_variant(self.bits)
+
+    def __exit__(self, *exc):
+        set_variant(self.prev)
+        return False
 
 
 _native = False  # (False: not looked up yet; None: unavailable / disabled)

@@ -27,7 +27,8 @@ class _Desc(ctypes.Structure):
 
 class AdamWScale(Optimizer):
     """Same arguments as the reference class (:40-66).  `foreach` is accepted and ignored (the fused step replaces both of the
-    reference's paths); `use_state_dtype` other than None is not supported by the fused kernels.
+    reference's paths); `use_state_dtype` = torch.float16 / torch.bfloat16 keeps exp_avg / exp_avg_sq in that dtype beside
+    parameters of another one (reference :101-103; any other value = the parameter dtype, like the reference).
 
     Extension (keyword only): `max_grad_norm` folds `torch.nn.utils.clip_grad_norm_(params, max_grad_norm)` -- what the reference's
     trainer runs before every optimizer step (`max_grad_norm: 1.0`) -- into the step: one more pass over the gradients for the global
@@ -45,8 +46,6 @@ class AdamWScale(Optimizer):
             raise ValueError(f"Invalid beta parameter: {betas[1]} - should be in [0.0, 1.0)")
         if not 0.0 <= eps:
             raise ValueError(f"Invalid epsilon value: {eps} - should be >= 0.0")
-        if use_state_dtype is not None:
-            raise NotImplementedError("use_state_dtype: the fused step keeps m, v in the parameter dtype (the reference's default)")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=foreach, kahan_sum=kahan_sum,
                         correct_bias=correct_bias, use_state_dtype=use_state_dtype)
         super().__init__(params, defaults)
@@ -62,7 +61,7 @@ class AdamWScale(Optimizer):
         """lr [* sqrt(1 - beta2^t) / (1 - beta1^t)] with the reference's types (:177-181): `step` is an int32 tensor there, so the
         bias corrections are float32 tensors and the product is float32"""
         if not correct_bias:
-            return float(lr)
+            return float(lr)  # (the kernel rounds lr * rms(p) to the parameter dtype like the reference's Python-float x tensor product)
         st = torch.as_tensor(step, dtype=torch.int32)
         bc1 = 1.0 - beta1 ** st
         bc2 = 1.0 - beta2 ** st
@@ -90,19 +89,28 @@ class AdamWScale(Optimizer):
                     raise RuntimeError("flasht5_amd.AdamWScale needs parameters on the HIP device (no CPU fallback)")
                 state = self.state[p]
                 if "kahan_comp" not in state:  # reference :96-113
+                    # (the reference keeps `step` on p.device; it is only ever read on the host -- beta ** step -- so it lives there)
                     state["step"] = torch.tensor(0, dtype=torch.int32)
-                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if group["use_state_dtype"] in (torch.float16, torch.bfloat16):  # :101-103
+                        state["exp_avg"] = torch.zeros_like(p, dtype=group["use_state_dtype"])
+                        state["exp_avg_sq"] = torch.zeros_like(p, dtype=group["use_state_dtype"])
+                    else:
+                        state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     kah = group["kahan_sum"] and p.dtype in (torch.float16, torch.bfloat16)
                     state["kahan_comp"] = torch.zeros_like(p, memory_format=torch.preserve_format) if kah else None
+                elif state["step"].device.type != "cpu":  # a reference checkpoint (device-side steps): one read, then host-side
+                    state["step"] = state["step"].cpu()
+                if state["exp_avg"].dtype != state["exp_avg_sq"].dtype or not (state["exp_avg"].is_contiguous() and state["exp_avg_sq"].is_contiguous()):
+                    raise RuntimeError("AdamWScale: exp_avg / exp_avg_sq must be contiguous and share one dtype")
                 steps.append(state["step"])
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("AdamWScale: parameters and gradients must be contiguous")
                 g = p.grad if p.grad.dtype == p.dtype else p.grad.to(p.dtype)
-                buckets.setdefault((p.device, p.dtype, state["kahan_comp"] is not None), []).append((p, g, state))
+                buckets.setdefault((p.device, p.dtype, state["exp_avg"].dtype, state["kahan_comp"] is not None), []).append((p, g, state))
             if steps:
                 torch._foreach_add_(steps, 1)  # reference :120
-            for (device, dtype, kahan), items in buckets.items():
+            for (device, dtype, sdtype, kahan), items in buckets.items():
                 table = (_Desc * (len(items) + 1))()
                 chunk = 0
                 keep = []
@@ -122,7 +130,8 @@ class AdamWScale(Optimizer):
                     continue
                 raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
                 partials = torch.empty(chunk, dtype=torch.float32, device=device)
-                jobs.append((device, dtype, kahan, raw, len(items), chunk, partials, group, keep))
+                flags = (1 if kahan else 0) | (0 if group["correct_bias"] else 2)  # FAT5_ADAMW_KAHAN | FAT5_ADAMW_PLAIN_STEP
+                jobs.append((device, dtype, (sdtype, flags), raw, len(items), chunk, partials, group, keep))
         if not jobs:
             return loss
         coef = None
@@ -141,8 +150,9 @@ class AdamWScale(Optimizer):
             coef = (self.max_grad_norm / (norm + 1e-6)).clamp(max=1.0).float().contiguous()  # clip_grad_norm_'s clip_coef_clamped
         for device, dtype, kahan, raw, n, chunk, partials, group, keep in jobs:
             beta1, beta2 = group["betas"]
+            sdtype, flags = kahan
             args = (raw.data_ptr(), n, chunk, partials.data_ptr(), float(group["lr"]), float(beta1), float(beta2),
-                    float(group["weight_decay"]), float(group["eps"]), _lib.dtype_code(dtype), int(kahan))
+                    float(group["weight_decay"]), float(group["eps"]), _lib.dtype_code(dtype), _lib.dtype_code(sdtype), int(flags))
             with _lib.on_device(device):
                 if coef is None:
                     _lib.check(lib.fat5_adamw_scale_step(*args, _lib.stream_ptr(device)), "fat5_adamw_scale_step")

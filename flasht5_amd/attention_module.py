@@ -76,7 +76,12 @@ class FlashT5Attention(nn.Module):
             if position_bias is None and self.pe_encoding is not None:
                 position_bias = self.pe_encoding.forward_1d()
             if position_bias is None:
-                # no producer and nothing handed on: T5 cross-attention (reference :207,:324 -> bias=None, HAS_BIAS=False)
+                # no producer and nothing handed on: T5 cross-attention (reference :207,:324 -> bias=None, HAS_BIAS=False).
+                # A SELF-attention layer without a producer must be handed block 0's (rpe1d, radius): training it silently
+                # without the T5 bias would be a wiring bug of the caller, not a mode.
+                if key_value_states is None and self.position_encoding_type == "t5":
+                    raise ValueError("fat5_rpe self-attention without a bias producer needs position_bias=(rpe1d, radius) from the "
+                                     "block that owns the RelativePositionalEncoding")
                 out = flash_attention_v2_bias(q, k, v, None, self.is_causal, self.softmax_scale)
             else:
                 rpe1d, radius = position_bias

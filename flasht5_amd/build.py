@@ -97,7 +97,7 @@ def build_torch_binding(force=False, verbose=True):
            "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
            "-I", "/opt/rocm/include", "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include(), "-I", INCLUDE,
            src, "-o", TORCH_EXT, "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
-           "-ltorch_python", "-L", os.path.dirname(LIB), "-l:" + os.path.basename(LIB),
+           "-ltorch_python", "-L", os.path.dirname(LIB), "-l:" + os.path.basename(LIB), "-L", "/opt/rocm/lib", "-lamdhip64",
            "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -79,11 +79,21 @@ __global__ __launch_bounds__(256) void adamw_sumsq_kernel(const fat5_adamw_tenso
   if (threadIdx.x == 0) partial[c] = s;
 }
 
-template <int DT, bool KAHAN>
+template <typename T, int N>
+struct __attribute__((aligned(sizeof(T) * N))) avec { T x[N]; };
+
+// DT: dtype of parameters, gradients and the Kahan compensation; SDT: dtype of m, v and of the denominator (the reference's
+// `use_state_dtype`, adamw_scaled.py:101-103: fp16 / bf16 states beside parameters of another dtype; SDT == DT otherwise)
+// plain_step: `correct_bias=False` (:177): the reference's step size is then `lr * max(1e-3, rms(p))` = a Python float times a
+// 0-dim tensor of p's dtype -> ROUNDED to p's dtype (with bias correction a float32 tensor enters the product and it stays fp32);
+// when rms < 1e-3 Python's max() returns the float and the product lr * 1e-3 is a double (`lr_small`, cast once)
+template <int DT, int SDT, bool KAHAN>
 __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tensor* __restrict__ tab, int n,
                                                            const float* __restrict__ partial, float beta1, float beta2, float a1,
-                                                           float a2, float wdf, float eps, const float* __restrict__ grad_coef = nullptr) {
+                                                           float a2, float wdf, float eps, const float* __restrict__ grad_coef,
+                                                           int plain_step, float lr_small) {
   typedef typename adt<DT>::type T;
+  typedef typename adt<SDT>::type S;
   __shared__ float red[4];
   const int c = blockIdx.x;
   const int ti = tensor_of_chunk(tab, n, c);
@@ -100,25 +110,26 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tens
   // p.norm(2): fp32 accumulation, result in p's dtype; "/ numel ** 0.5": one more op in p's dtype
   const float norm = rnd<DT>(sqrtf(sumsq));
   const float rms = rnd<DT>(norm / (float)sqrt((double)t.numel));
-  const float neg_step = -(t.step_prefactor * fmaxf(1e-3f, rms));  // float32 x p-dtype scalars promote to float32 (:184)
+  float neg_step = -(t.step_prefactor * fmaxf(1e-3f, rms));  // float32 x p-dtype scalars promote to float32 (:184)
+  if (plain_step) neg_step = rms > 1e-3f ? -rnd<DT>(t.step_prefactor * rms) : -lr_small;  // (max(1e-3, rms): the tensor only when it is larger)
   // (a1 = 1 - beta1, a2 = 1 - beta2, wdf = -lr * weight_decay: formed in double by the host like the reference's Python, cast once)
 
   const int64_t e0 = (int64_t)(c - t.chunk_begin) * kAdamChunk;
   const int64_t cnt = min((int64_t)kAdamChunk, t.numel - e0);
   T* p = reinterpret_cast<T*>(t.p) + e0;
   const T* g = reinterpret_cast<const T*>(t.g) + e0;
-  T* m = reinterpret_cast<T*>(t.m) + e0;
-  T* v = reinterpret_cast<T*>(t.v) + e0;
+  S* m = reinterpret_cast<S*>(t.m) + e0;
+  S* v = reinterpret_cast<S*>(t.v) + e0;
   T* k = KAHAN ? reinterpret_cast<T*>(t.k) + e0 : nullptr;
 
   auto one = [&](float pf, float gf, float mf, float vf, float kf, float& po, float& mo, float& vo, float& ko) {
     if (clip) gf = rnd<DT>(gf * gcoef);
-    mf = rnd<DT>(mf * beta1);                         // exp_avg.mul_(beta1)                         :173
-    mf = rnd<DT>(fmaf(a1, gf, mf));                   //        .add_(grad, alpha=1-beta1)
-    vf = rnd<DT>(vf * beta2);                         // exp_avg_sq.mul_(beta2)                      :174
-    vf = rnd<DT>(fmaf(a2 * gf, gf, vf));              //        .addcmul_(grad, grad, value=1-beta2)
-    float den = rnd<DT>(sqrtf(vf));                   // exp_avg_sq.sqrt()                           :175
-    den = rnd<DT>(den + eps);                         //        .add_(eps)
+    mf = rnd<SDT>(mf * beta1);                        // exp_avg.mul_(beta1)                         :173
+    mf = rnd<SDT>(fmaf(a1, gf, mf));                  //        .add_(grad, alpha=1-beta1)
+    vf = rnd<SDT>(vf * beta2);                        // exp_avg_sq.mul_(beta2)                      :174
+    vf = rnd<SDT>(fmaf(a2 * gf, gf, vf));             //        .addcmul_(grad, grad, value=1-beta2)
+    float den = rnd<SDT>(sqrtf(vf));                  // exp_avg_sq.sqrt()                           :175
+    den = rnd<SDT>(den + eps);                        //        .add_(eps)
     const float upd = neg_step * (mf / den);          // value * (exp_avg / denom)
     if constexpr (KAHAN) {
       kf = rnd<DT>(kf + upd);                         // kahan_comp.addcdiv_(exp_avg, denom, value=-step_size)   :190
@@ -133,39 +144,37 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tens
     po = pf; mo = mf; vo = vf; ko = kf;
   };
 
-  constexpr int V = 16 / sizeof(T);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                         reinterpret_cast<uintptr_t>(v) | (KAHAN ? reinterpret_cast<uintptr_t>(k) : 0)) & 15) == 0;
+  constexpr int V = 16 / sizeof(T);  // elements per thread and trip: 16 bytes of p / g / k, V state elements (8, 16 or 32 bytes)
+  typedef avec<T, V> PV;
+  typedef avec<S, V> SV;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | (KAHAN ? reinterpret_cast<uintptr_t>(k) : 0)) & 15) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & (sizeof(SV) - 1)) == 0;
   int64_t done = 0;
   if (aligned) {
     const int64_t nv = cnt / V;
     for (int64_t i = threadIdx.x; i < nv; i += 256) {
-      uint4 wp = reinterpret_cast<uint4*>(p)[i], wg = reinterpret_cast<const uint4*>(g)[i], wm = reinterpret_cast<uint4*>(m)[i],
-            wv = reinterpret_cast<uint4*>(v)[i], wk = {0, 0, 0, 0};
-      if constexpr (KAHAN) wk = reinterpret_cast<uint4*>(k)[i];
-      T* xp = reinterpret_cast<T*>(&wp);
-      const T* xg = reinterpret_cast<const T*>(&wg);
-      T* xm = reinterpret_cast<T*>(&wm);
-      T* xv = reinterpret_cast<T*>(&wv);
-      T* xk = reinterpret_cast<T*>(&wk);
+      PV wp = reinterpret_cast<PV*>(p)[i], wk;
+      const PV wg = reinterpret_cast<const PV*>(g)[i];
+      SV wm = reinterpret_cast<SV*>(m)[i], wv = reinterpret_cast<SV*>(v)[i];
+      if constexpr (KAHAN) wk = reinterpret_cast<PV*>(k)[i];
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float po, mo, vo, ko;
-        one((float)xp[j], (float)xg[j], (float)xm[j], (float)xv[j], KAHAN ? (float)xk[j] : 0.f, po, mo, vo, ko);
-        xp[j] = (T)po; xm[j] = (T)mo; xv[j] = (T)vo;
-        if constexpr (KAHAN) xk[j] = (T)ko;
+        one((float)wp.x[j], (float)wg.x[j], (float)wm.x[j], (float)wv.x[j], KAHAN ? (float)wk.x[j] : 0.f, po, mo, vo, ko);
+        wp.x[j] = (T)po; wm.x[j] = (S)mo; wv.x[j] = (S)vo;
+        if constexpr (KAHAN) wk.x[j] = (T)ko;
       }
-      reinterpret_cast<uint4*>(p)[i] = wp;
-      reinterpret_cast<uint4*>(m)[i] = wm;
-      reinterpret_cast<uint4*>(v)[i] = wv;
-      if constexpr (KAHAN) reinterpret_cast<uint4*>(k)[i] = wk;
+      reinterpret_cast<PV*>(p)[i] = wp;
+      reinterpret_cast<SV*>(m)[i] = wm;
+      reinterpret_cast<SV*>(v)[i] = wv;
+      if constexpr (KAHAN) reinterpret_cast<PV*>(k)[i] = wk;
     }
     done = nv * V;
   }
   for (int64_t i = done + threadIdx.x; i < cnt; i += 256) {
     float po, mo, vo, ko;
     one((float)p[i], (float)g[i], (float)m[i], (float)v[i], KAHAN ? (float)k[i] : 0.f, po, mo, vo, ko);
-    p[i] = (T)po; m[i] = (T)mo; v[i] = (T)vo;
+    p[i] = (T)po; m[i] = (S)mo; v[i] = (S)vo;
     if constexpr (KAHAN) k[i] = (T)ko;
   }
 }

@@ -19,13 +19,9 @@ static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  // One workgroup per item by default.  FAT5_F64_RESIDENT=n (developer knob) launches n persistent workgroups (a multiple of 8,
-  // so an item keeps its XCD) that walk the items with stride n: measured no faster at (4,12,8192,64) -- 1536 equal items over
-  // 512 slots balance by themselves.
-  int resident = 0;
-  if (const char* e = getenv("FAT5_F64_RESIDENT")) resident = atoi(e) / 8 * 8;
-  const int launch = resident <= 0 || grid < resident ? grid : resident;
-  hipLaunchKernelGGL(kern, dim3(launch), dim3(256), smem, s, a, grid);
+  // One workgroup per item (persistent workgroups walking the items were measured no faster at (4,12,8192,64): 1536 equal items
+  // over 512 slots balance by themselves).
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, grid);
   return hipGetLastError();
 }
 

@@ -14,7 +14,6 @@ namespace fat5 {
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
 static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
   size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
-  if (const char* e = getenv("FAT5_FWD_LDS_PAD")) smem += (size_t)atoi(e) * 1024;  // developer knob: limit occupancy
   auto kern = attn_fwd_kernel<D, BF16, BIAS, NW, BDMA>;
   static size_t configured = 0;  // per instantiation; benign race (idempotent call)
   if (smem > 48 * 1024 && smem > configured) {

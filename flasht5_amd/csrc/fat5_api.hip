@@ -33,10 +33,8 @@ int hip_fail(hipError_t e, const char* what) {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
+// kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
+inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
 
 struct BwdLayout {
   size_t delta_off, stat2_off, ds_off, drpe_off, scratch_off, total;
@@ -48,13 +46,9 @@ struct BwdLayout {
   int nw_q, nw_kv;
 };
 
-int pick_nw(long ctas_at_nw4, const char* env, bool allow8 = false) {
-  const int forced = env_int(env, 0);
-  if (forced == 2 || forced == 4 || (forced == 8 && allow8)) return forced;
-  // measured at S = 512 (tools/time_b.py): the 4-wave tile wins down to ~0.75 workgroups per CU
-  if (ctas_at_nw4 < 160) return 2;
-  if (allow8 && ctas_at_nw4 >= 2048) return env_int("FAT5_DEFAULT_BIG_NW", 4);
-  return 4;
+int pick_nw(long ctas_at_nw4) {
+  // measured at S = 512: the 4-wave tile wins down to ~0.75 workgroups per CU
+  return ctas_at_nw4 < 160 ? 2 : 4;
 }
 
 int check_common(const fat5_attn_params* p) {
@@ -97,17 +91,15 @@ void fill_common(const fat5_attn_params* p, AttnArgs& a) {
   a.cu_q = p->cu_seqlens_q; a.cu_k = p->cu_seqlens_k;
   a.total_q = p->total_q; a.total_k = p->total_k;
   a.unit_begin = p->unit_begin; a.unit_count = p->unit_count;
-  static const int binner_env = [] { const char* e = getenv("FAT5_BATCH_INNER"); return e ? atoi(e) : 1; }();
   // (pays once the bias no longer sits in the 256 MB Infinity Cache: measured +18 % forward at S = 8192 (1.6 GB), neutral at
   //  S = 2048 (100 MB), -10 % at S = 512 where the per-(b,h) mapping keeps K/V in one L2)
-  a.batch_inner = binner_env && p->bias_mode == FAT5_BIAS_DENSE && p->bias_stride[0] == 0 && p->B > 1 && p->unit_count == 0 &&
+  a.batch_inner = p->bias_mode == FAT5_BIAS_DENSE && p->bias_stride[0] == 0 && p->B > 1 && p->unit_count == 0 &&
                   !p->cu_seqlens_q &&
-                  (binner_env > 1 || (int64_t)(p->bias_stride[1] ? p->H : 1) * p->M * p->N * 2 > (int64_t(256) << 20));
+                  (int64_t)(p->bias_stride[1] ? p->H : 1) * p->M * p->N * 2 > (int64_t(256) << 20);
   if (p->bias_mode == FAT5_BIAS_DENSE) {
     a.bias_vec4 = ((reinterpret_cast<uintptr_t>(p->bias) & 7) == 0) && (p->bias_stride[0] % 4 == 0) &&
                   (p->bias_stride[1] % 4 == 0) && (p->bias_stride[2] % 4 == 0);
-    static const int bdma_env = [] { const char* e = getenv("FAT5_BIAS_DMA"); return e ? atoi(e) : 1; }();
-    a.bias_dma = bdma_env && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
+    a.bias_dma = ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
                  (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0);
   }
 }
@@ -152,22 +144,21 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   // units: a unit-range call runs exactly the code the whole-problem call would run on those units, so sharded and unsharded
   // results are bit-identical.
   const long bh = (long)p->B * p->H;
-  int nw = pick_nw(bh * ((p->M + 127) / 128), "FAT5_FWD_NW", true);
+  int nw = pick_nw(bh * ((p->M + 127) / 128));
   a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
   // short sequences: with 4-wave tiles the grid is smaller than the chip and every wave walks all keys alone -> two
-  // waves per 32 query rows, each taking one 32-key block of every tile (attn_fwd_split_kernel; FAT5_FWD_SPLIT=0 disables)
-  static const int split_env = env_int("FAT5_FWD_SPLIT", 1);
+  // waves per 32 query rows, each taking one 32-key block of every tile (attn_fwd_split_kernel)
   const long ctas4 = bh * ((p->M + 127) / 128);
-  if (split_env && env_int("FAT5_FWD_NW", 0) == 0 && ctas4 <= 256 && bh * ((p->M + 63) / 64) >= 96 && p->N >= 128) {
+  if (!(p->variant & FAT5_V_NO_SPLIT) && ctas4 <= 256 && bh * ((p->M + 63) / 64) >= 96 && p->N >= 128) {
     nw = -4;
     a.n_mblk = (p->M + 63) / 64;
   }
   launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
   // long sequences: 64 query rows per wave, software-pipelined tile loop (attn_fwd64.h) once its 256-row workgroups fill
-  // the chip (FAT5_FWD64=0 disables, =1 forces wherever the body applies)
-  const int f64_env = env_int("FAT5_FWD64", -1);
+  // the chip (fat5_attn_params.variant: FAT5_V_FWD64_OFF disables, FAT5_V_FWD64_ON forces wherever the body applies)
+  const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
   const long ctas256 = bh * ((p->M + 255) / 256);
-  if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 && env_int("FAT5_FWD_NW", 0) == 0 &&
+  if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
       (f64_env == 1 || (p->dtype == FAT5_BF16 && ctas256 >= 512 &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
@@ -184,22 +175,22 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
 
 static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   const long bh = (long)p->B * p->H;  // workspace layout and kernel variants follow the full problem also for a unit range
-  L.nw_q = pick_nw(bh * ((p->M + 127) / 128), "FAT5_BWDQ_NW");
-  L.nw_kv = pick_nw(bh * ((p->N + 127) / 128), "FAT5_BWDKV_NW");
+  L.nw_q = pick_nw(bh * ((p->M + 127) / 128));
+  L.nw_kv = pick_nw(bh * ((p->N + 127) / 128));
   L.n_nblk = (p->N + 32 * L.nw_kv - 1) / (32 * L.nw_kv);
   // long sequences: 64 keys per wave, software-pipelined (attn_bwd64.h) once its 256-key workgroups (one per CU) cover the
-  // chip twice (FAT5_BWD64=0 disables, =1 forces wherever the body applies)
-  const int b64_env = env_int("FAT5_BWD64", -1);
+  // chip twice (variant: FAT5_V_KV64_OFF disables, FAT5_V_KV64_ON forces wherever the body applies; FAT5_V_Q64_* likewise)
+  const int b64_env = vsel(p->variant, FAT5_V_KV64_ON, FAT5_V_KV64_OFF);
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
-           env_int("FAT5_BWDKV_NW", 0) == 0 && (b64_env == 1 || bh * ((p->N + 255) / 256) >= 512) &&
+           (b64_env == 1 || bh * ((p->N + 255) / 256) >= 512) &&
            smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024;
   if (L.kv64) {
     L.nw_kv = 4;
     L.n_nblk = (p->N + 255) / 256;
   }
-  const int q64_env = env_int("FAT5_BWDQ64", -1);
+  const int q64_env = vsel(p->variant, FAT5_V_Q64_ON, FAT5_V_Q64_OFF);
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
-          env_int("FAT5_BWDQ_NW", 0) == 0 && (q64_env == 1 || bh * ((p->M + 255) / 256) >= 512);
+          (q64_env == 1 || bh * ((p->M + 255) / 256) >= 512);
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;
@@ -213,7 +204,8 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   L.scratch_off = off;
   if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
     const bool reduced = (p->dbias_batch != p->B) || (p->dbias_heads != p->H);
-    const int inker_env = env_int("FAT5_DBIAS_INKERNEL", 1);  // (0: the staged (B, H, M, N) + reduction path it replaces; developer A/B)
+    // (variant FAT5_V_DBIAS_STAGED: the staged (B, H, M, N) + reduction path; FAT5_V_DBIAS_INKERNEL: the batch-inner kernel at any size)
+    const int inker_env = (p->variant & FAT5_V_DBIAS_STAGED) ? 0 : ((p->variant & FAT5_V_DBIAS_INKERNEL) ? 2 : 1);
     // the model's case -- one bias per head shared by the batch -- reduces over the batch inside the dBias kernel: the
     // workspace stays O(B*H*M) (+ an fp32 (H, M, N) pass-through when the batch exceeds the kernel's 4-element register chunk)
     // (measured at (4,12,S,64): S = 512 staged 50 us vs 71 us; S = 2048 492 vs 461 us; S = 8192 6.26 vs 6.32 ms with a
@@ -245,11 +237,10 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
   return L.total;
 }
 
-static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D) {
+static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D, int variant) {
   if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
-  static const int fuse_env = [] { const char* e = getenv("FAT5_BWD_FUSE"); return e ? atoi(e) : 1; }();
-  static const long fuse_max = [] { const char* e = getenv("FAT5_BWD_FUSE_MAX"); return e ? atol(e) : 4L * 256; }();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
-  return fuse_env && !L.kv64 && !L.q64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
+  const long fuse_max = 4L * 256;  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
+  return !(variant & FAT5_V_NO_FUSE) && !L.kv64 && !L.q64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
 int fat5_attn_bwd_launches(const fat5_attn_params* p) {
@@ -258,7 +249,7 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  return bwd_fusable(L, grid_q, grid_kv, p->D) ? 1 : 2;
+  return bwd_fusable(L, grid_q, grid_kv, p->D, p->variant) ? 1 : 2;
 }
 
 int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) { return fat5_attn_bwd_stages(p, FAT5_BWD_ALL, stream_); }
@@ -354,7 +345,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const long full_q = bh * a.n_mblk, full_kv = bh * a.n_nblk;  // (variant choice: see fat5_attn_fwd)
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
   // side by side (attn_bwd_fused_kernel).  FAT5_BWD_FUSE=0 disables (developer A/B).
-  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, p->D);
+  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, p->D, p->variant);
   if (fuse) {
     a.n_kv_blocks = (int)grid_kv;
     launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
@@ -416,6 +407,23 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
   }
+  return FAT5_OK;
+}
+
+int fat5_rpe1d_from_table(const void* table, int table_dtype, const int32_t* rpe_bucket, float* rpe1d, int32_t H, int32_t rpe_radius,
+                          int32_t num_buckets, void* stream_) {
+  if (!table || !rpe_bucket || !rpe1d) return fail(FAT5_EINVAL, "rpe1d_from_table: null pointer");
+  if (table_dtype != FAT5_F32 && table_dtype != FAT5_F16 && table_dtype != FAT5_BF16) return fail(FAT5_EINVAL, "rpe1d_from_table: bad dtype");
+  if (H <= 0 || num_buckets <= 0 || rpe_radius < 1 || rpe_radius > 2048) return fail(FAT5_EINVAL, "rpe1d_from_table: bad shape");
+  const int n1 = 2 * rpe_radius + 1;
+  const int grid = (H * n1 + 255) / 256;
+  hipStream_t stream = (hipStream_t)stream_;
+  dispatch_dtype(table_dtype, [&](auto dt_) {
+    constexpr int DT = decltype(dt_)::value;
+    hipLaunchKernelGGL(rpe1d_gather_kernel<DT>, dim3(grid), dim3(256), 0, stream, table, rpe_bucket, rpe1d, H, n1, num_buckets);
+  });
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rpe1d_gather launch");
   return FAT5_OK;
 }
 
@@ -482,11 +490,11 @@ int fat5_add_rmsnorm_fwd(const void* x, const void* r, const void* w, void* h, v
 }
 
 static int rms_bwd_blocks(int64_t rows) {
-  // persistent 8-wave workgroups, one row per wave and trip: two (FAT5_RMS_BWD_BLOCKS per chip) per CU keep enough 16-byte
+  // persistent 8-wave workgroups, one row per wave and trip: two per CU keep enough 16-byte
   // loads in flight to cover the HBM latency (one per CU: 4.5 TB/s at (65536, 1024))
   // (measured: 256 / 384 / 512 / 768 workgroups -> 4.48 / 4.98 / 5.08 / 4.78 TB/s; small inputs keep >= 2 rows per wave so that
   //  the dw reduction over the workgroups' partial sums stays short)
-  static const int cap = env_int("FAT5_RMS_BWD_BLOCKS", 512);
+  const int cap = 512;
   int64_t b = (rows + 15) / 16;
   return (int)(b < cap ? b : cap);
 }
@@ -611,41 +619,52 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
 size_t fat5_sizeof_adamw_tensor(void) { return sizeof(fat5_adamw_tensor); }
 
 static int adamw_step_impl(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr_, double beta1_,
-                           double beta2_, double weight_decay_, double eps_, int dtype, int kahan, const float* grad_coef, void* stream_) {
+                           double beta2_, double weight_decay_, double eps_, int dtype, int state_dtype, int flags, const float* grad_coef,
+                           void* stream_) {
   // scalars reach the kernels as the fp32 "opmath" values the reference's ops see: each Python double is cast once
   const float beta1 = (float)beta1_, beta2 = (float)beta2_, eps = (float)eps_;
-  const float a1 = (float)(1.0 - beta1_), a2 = (float)(1.0 - beta2_), wdf = (float)(-lr_ * weight_decay_);
+  const float a1 = (float)(1.0 - beta1_), a2 = (float)(1.0 - beta2_);
+  const float wdf = weight_decay_ > 0.0 ? (float)(-lr_ * weight_decay_) : 0.f;  // (the reference decays only `if weight_decay > 0.0`, :209)
+  const float lr_small = (float)(lr_ * 1e-3);
+  const int kahan = flags & FAT5_ADAMW_KAHAN, plain = (flags & FAT5_ADAMW_PLAIN_STEP) ? 1 : 0;
   if (!table || !partials) return fail(FAT5_EINVAL, "adamw: null table / partials");
   if (n_tensors <= 0 || n_chunks <= 0) return fail(FAT5_EINVAL, "adamw: empty group");
-  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "adamw: bad dtype");
+  if (!dtype_ok(dtype) || !dtype_ok(state_dtype)) return fail(FAT5_EINVAL, "adamw: bad dtype");
+  if (state_dtype == FAT5_F32 && dtype != FAT5_F32)
+    return fail(FAT5_EINVAL, "adamw: fp32 states beside 16-bit parameters do not exist in the reference (use_state_dtype is fp16 / bf16, :101-103)");
   if (kahan && dtype == FAT5_F32) return fail(FAT5_EINVAL, "adamw: Kahan compensation is for 16-bit parameters (reference :107-113)");
   hipStream_t stream = (hipStream_t)stream_;
   dispatch_dtype(dtype, [&](auto dt_) {
     constexpr int DT = decltype(dt_)::value;
     hipLaunchKernelGGL((adamw_sumsq_kernel<DT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials);
-    if constexpr (DT != FAT5_F32) {
-      if (kahan) {
-        hipLaunchKernelGGL((adamw_update_kernel<DT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2,
-                           a1, a2, wdf, eps, grad_coef);
-        return;
+    dispatch_dtype(state_dtype, [&](auto st_) {
+      constexpr int SDT = decltype(st_)::value;
+      if constexpr (SDT != FAT5_F32 || DT == FAT5_F32) {
+        if constexpr (DT != FAT5_F32) {
+          if (kahan) {
+            hipLaunchKernelGGL((adamw_update_kernel<DT, SDT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1,
+                               beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((adamw_update_kernel<DT, SDT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1,
+                           beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small);
       }
-    }
-    hipLaunchKernelGGL((adamw_update_kernel<DT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1, beta2, a1,
-                       a2, wdf, eps, grad_coef);
+    });
   });
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "adamw launch");
   return FAT5_OK;
 }
 int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr, double beta1,
-                          double beta2, double weight_decay, double eps, int dtype, int kahan, void* stream) {
-  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, kahan, nullptr, stream);
+                          double beta2, double weight_decay, double eps, int dtype, int state_dtype, int flags, void* stream) {
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, nullptr, stream);
 }
 int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
-                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan,
+                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int state_dtype, int flags,
                                   const float* grad_coef, void* stream) {
   if (!grad_coef) return fail(FAT5_EINVAL, "adamw: grad_coef is NULL");
-  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, kahan, grad_coef, stream);
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, grad_coef, stream);
 }
 int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, int dtype, void* stream_) {
   if (!table || !partials) return fail(FAT5_EINVAL, "adamw: null table / partials");

@@ -135,4 +135,21 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   }
 }
 
+// rpe1d[h][i] = table[bucket[i]][h] as fp32: the (H, 2R+1) Toeplitz generator of the T5 bias from the (num_buckets, H) table
+// (reference: the embedding lookup + permute of RelativePositionalEncoding.compute_bias, src/utils/positional_encoding.py:100-101,
+//  restricted to the 2R+1 distinct relative positions).  One launch per forward call: the generator is never cached across
+// calls, so whatever updates the table in place (an optimizer writing through raw pointers) is seen by the next forward.
+template <int DT>
+__global__ __launch_bounds__(256) void rpe1d_gather_kernel(const void* __restrict__ table, const int32_t* __restrict__ bucket,
+                                                           float* __restrict__ rpe1d, int H, int n1, int nbuckets) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * n1) return;
+  const int h = i / n1, j = i - h * n1;
+  const int bk = min(max(bucket[j], 0), nbuckets - 1);
+  float v;
+  if constexpr (DT == FAT5_F32) v = reinterpret_cast<const float*>(table)[(int64_t)bk * H + h];
+  else v = cvt16<DT == FAT5_BF16>(reinterpret_cast<const uint16_t*>(table)[(int64_t)bk * H + h]);
+  rpe1d[i] = v;
+}
+
 }  // namespace fat5

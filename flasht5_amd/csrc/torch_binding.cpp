@@ -10,9 +10,12 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
+
+#include <hip/hip_runtime_api.h>
 
 #include "fat5.h"
 
@@ -44,8 +47,13 @@ int dtype_code(const Tensor& t) {
 }
 void check_rc(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (fat5 status ", rc, "): ", fat5_last_error()); }
 
+// fat5_attn_params.variant of every descriptor built here: 0 in production; tests / profilers set it through
+// flasht5_amd._lib.set_variant (the same hook drives the ctypes path)
+std::atomic<int> g_variant{0};
+
 void base_params(fat5_attn_params& p, const Tensor& q, const Tensor& k, const Tensor& v, bool causal, double scale) {
   memset(&p, 0, sizeof(p));
+  p.variant = g_variant.load(std::memory_order_relaxed);
   p.B = (int)q.size(0); p.H = (int)q.size(1); p.M = (int)q.size(2); p.N = (int)k.size(2); p.D = (int)q.size(3);
   p.dtype = dtype_code(q);
   p.causal = causal ? 1 : 0;
@@ -61,16 +69,23 @@ void set_bias(fat5_attn_params& p, const Tensor& bias) {  // broadcast (1|B, 1|H
   p.bias_stride[2] = bias.stride(2);
 }
 
-// backward scratch: one growing buffer per (device, stream) -- launches on one stream are ordered
+// backward scratch: one growing buffer per (device, stream) -- eager launches on one stream are ordered, so consecutive calls
+// share it.  While the stream is being CAPTURED into a HIP graph the buffer comes from the caching allocator instead (the
+// graph's private pool): a cached buffer baked into a graph would be freed by a later, larger eager call and the replays would
+// write into memory someone else owns.  The map is leaked on purpose (no Tensor destructors after HIP has shut down).
 Tensor workspace(size_t nbytes, const Tensor& like, hipStream_t stream) {
+  const int64_t n = (int64_t)std::max<size_t>(nbytes, 256);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return at::empty({n}, like.options().dtype(at::kByte));
   static std::mutex mu;
-  static std::map<std::pair<int, void*>, Tensor> cache;
+  static auto* cache = new std::map<std::pair<int, void*>, Tensor>();
   std::lock_guard<std::mutex> g(mu);
   auto key = std::make_pair((int)like.get_device(), (void*)stream);
-  auto it = cache.find(key);
-  if (it == cache.end() || (size_t)it->second.numel() < nbytes) {
-    Tensor ws = at::empty({(int64_t)std::max<size_t>(nbytes, 256)}, like.options().dtype(at::kByte));
-    cache[key] = ws;
+  auto it = cache->find(key);
+  if (it == cache->end() || it->second.numel() < n) {
+    Tensor ws = at::empty({n}, like.options().dtype(at::kByte));
+    (*cache)[key] = ws;
     return ws;
   }
   return it->second;
@@ -158,11 +173,34 @@ struct BiasFn : public torch::autograd::Function<BiasFn> {
   }
 };
 
-// RPE mode on the (num_buckets, H) table: the kernels read the (H, 2R+1) generator `rpe1d` built (and cached) by the caller;
-// the table gradient comes scattered into buckets from the reduction launch (`bucket`: (2R+1,) int32)
+// (num_buckets, H) table -> (H, 2R+1) fp32 generator, one launch.  Built on EVERY forward call and never cached: whatever
+// updates the table in place without touching its autograd version counter (this package's fused AdamWScale writes parameters
+// through raw pointers; `p.data = ...` swaps) is seen by the next forward.
+Tensor rpe1d_of(const Tensor& table_, const Tensor& bucket, int64_t radius, int64_t num_buckets) {
+  Tensor table = table_.detach();
+  const auto st = table.scalar_type();
+  if (!(st == at::kFloat || st == at::kHalf || st == at::kBFloat16)) table = table.to(at::kFloat);
+  table = table.contiguous();
+  const int64_t H = table.size(1);
+  Tensor r1 = at::empty({H, 2 * radius + 1}, table.options().dtype(at::kFloat));
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(table.device());
+  check_rc(fat5_rpe1d_from_table(table.data_ptr(), st == at::kHalf ? FAT5_F16 : (st == at::kBFloat16 ? FAT5_BF16 : FAT5_F32),
+                                 (const int32_t*)bucket.data_ptr(), (float*)r1.data_ptr(), (int)H, (int)radius, (int)num_buckets,
+                                 c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(table.get_device()).stream()),
+           "fat5_rpe1d_from_table");
+  return r1;
+}
+
+// RPE mode on the (num_buckets, H) table: the kernels read the (H, 2R+1) generator built above; the table gradient comes
+// scattered into buckets from the reduction launch (`bucket`: (2R+1,) int32)
 struct RpeTableFn : public torch::autograd::Function<RpeTableFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& table,
-                        const Tensor& rpe1d, const Tensor& bucket, int64_t radius, int64_t num_buckets, bool causal, double scale) {
+                        const Tensor& bucket, int64_t radius, int64_t num_buckets, bool causal, double scale) {
+    TORCH_CHECK(bucket.scalar_type() == at::kInt && bucket.is_contiguous() && bucket.numel() == 2 * radius + 1 && bucket.device() == q.device(),
+                "rpe bucket index must be a contiguous int32 (2R+1,) vector on q's device");
+    TORCH_CHECK(table.dim() == 2 && table.size(0) == num_buckets && table.size(1) == q.size(1) && table.device() == q.device(),
+                "rpe_table must be (num_buckets, n_heads) on q's device");
+    Tensor rpe1d = rpe1d_of(table, bucket, radius, num_buckets);
     auto [o, L] = attn_fwd(q, k, v, c10::nullopt, rpe1d, radius, causal, scale);
     ctx->save_for_backward({q, k, v, o, L, rpe1d, bucket});
     ctx->saved_data["causal"] = causal;
@@ -179,7 +217,7 @@ struct RpeTableFn : public torch::autograd::Function<RpeTableFn> {
                                      ctx->saved_data["causal"].toBool(), ctx->saved_data["scale"].toDouble(), need, s[6],
                                      ctx->saved_data["num_buckets"].toInt());
     if (need) dt = dt.to((at::ScalarType)ctx->saved_data["tdtype"].toInt());
-    return {dq, dk, dv, need ? dt : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {dq, dk, dv, need ? dt : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -310,9 +348,9 @@ std::tuple<Tensor, Tensor> add_rmsnorm_apply(const Tensor& X, const Tensor& R, c
 Tensor bias_apply(const Tensor& q, const Tensor& k, const Tensor& v, const OptT& bias, bool causal, double scale) {
   return BiasFn::apply(q, k, v, bias, causal, scale);
 }
-Tensor rpe_table_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& table, const Tensor& rpe1d, const Tensor& bucket,
-                       int64_t radius, int64_t num_buckets, bool causal, double scale) {
-  return RpeTableFn::apply(q, k, v, table, rpe1d, bucket, radius, num_buckets, causal, scale);
+Tensor rpe_table_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& table, const Tensor& bucket, int64_t radius,
+                       int64_t num_buckets, bool causal, double scale) {
+  return RpeTableFn::apply(q, k, v, table, bucket, radius, num_buckets, causal, scale);
 }
 Tensor rpe1d_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& rpe1d, const Tensor& r1, int64_t radius, bool causal,
                    double scale) {
@@ -328,7 +366,9 @@ PYBIND11_MODULE(_fat5_torch, m) {
   m.def("bias_apply", &bias_apply);
   m.def("rpe_table_apply", &rpe_table_apply);
   m.def("rpe1d_apply", &rpe1d_apply);
+  m.def("rpe1d_of", &rpe1d_of);
   m.def("rmsnorm_apply", &rmsnorm_apply);
   m.def("add_rmsnorm_apply", &add_rmsnorm_apply);
   m.def("sizeof_attn_params", []() { return (int64_t)sizeof(fat5_attn_params); });
+  m.def("set_variant", [](int64_t bits) { g_variant.store((int)bits); });
 }

@@ -48,6 +48,7 @@ def _base_params(q, k, v, causal, sm_scale):
     p.sm_scale = float(sm_scale)
     p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
     p.q_stride, p.k_stride, p.v_stride = _lib.strides3(q), _lib.strides3(k), _lib.strides3(v)
+    p.variant = _lib._variant
     return p
 
 
@@ -81,13 +82,18 @@ def _check_rpe1d(rpe1d, H, radius, device):
         raise ValueError(f"rpe1d must be (n_heads, 2 * radius + 1) = ({H}, {2 * int(radius) + 1}), got {tuple(rpe1d.shape)}")
 
 
-# Backward scratch: one growing buffer per (device, stream).  Launches on one stream are ordered, so consecutive backward
+# Backward scratch: one growing buffer per (device, stream).  Eager launches on one stream are ordered, so consecutive backward
 # calls can share it; a call on another stream gets its own.  (A torch.empty per call cost ~4 us of the ~14 us host time of
 # an eager call and made the caching allocator the busiest part of a 12 us kernel's launch.)
+# NOT while the stream is being captured into a HIP graph (torch.cuda.graph, torch.compile(mode="reduce-overhead")): a cached
+# buffer baked into a graph would be freed when a later, larger eager call regrows the cache, and the graph's replays would
+# write into memory that belongs to someone else -- there the buffer comes from the allocator (the graph's private pool).
 _WS_CACHE = {}
 
 
 def _workspace(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device()))
     ws = _WS_CACHE.get(key)
@@ -319,22 +325,24 @@ def _rpe_bwd(o, do, q, k, v, r1, L, radius, causal, sm_scale, need, bucket=None,
     return _attn_bwd(o, do, q, k, v, None, r1, int(radius), L, bool(causal), float(sm_scale), bool(need), bucket, int(num_buckets))
 
 
-# (H, 2R+1) generator of a table, remembered until the table changes (its autograd version counter moves on every in-place
-# update, e.g. an optimizer step): a 12-layer stack that calls flash_attention_v2_rpe with one table builds it once per step
-_RPE1D_CACHE = {}
-
-
 def _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance):
-    import weakref
-    key = (R, bool(bidirectional), num_buckets, max_distance, rpe_table.device, rpe_table.dtype)
-    hit = _RPE1D_CACHE.get(id(rpe_table))
-    if hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version and hit[2] == key:
-        return hit[3]
-    idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, rpe_table.device)
-    r1 = rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()  # (H, 2R+1)
-    if len(_RPE1D_CACHE) > 64:
-        _RPE1D_CACHE.clear()
-    _RPE1D_CACHE[id(rpe_table)] = (weakref.ref(rpe_table), rpe_table._version, key, r1)
+    """(H, 2R+1) fp32 generator of the table: ONE launch (fat5_rpe1d_from_table) on every call.  Deliberately not cached across
+    calls: an autograd version counter does not see every update of the table (this package's fused AdamWScale writes parameters
+    through raw pointers; `p.data = ...` swaps), and a stale generator would train silently wrong.  A layer stack that wants to
+    build it once per step does so explicitly: `RelativePositionalEncoding.forward_1d()` + `flash_attention_v2_rpe1d`."""
+    if _tracing():  # torch ops a compiler can trace
+        idx = _pe.bucket_index(R, bidirectional, num_buckets, max_distance, rpe_table.device)
+        return rpe_table.detach().index_select(0, idx).transpose(0, 1).float().contiguous()
+    t = rpe_table.detach()
+    if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        t = t.float()
+    t = t.contiguous()
+    H = t.shape[1]
+    idx32 = _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, t.device)
+    r1 = torch.empty((H, 2 * R + 1), dtype=torch.float32, device=t.device)
+    with _lib.on_device(t.device):
+        _lib.check(_lib.load().fat5_rpe1d_from_table(t.data_ptr(), _lib.dtype_code(t.dtype), idx32.data_ptr(), r1.data_ptr(), H, R,
+                                                     int(num_buckets), _lib.stream_ptr(t.device)), "fat5_rpe1d_from_table")
     return r1
 
 
@@ -396,10 +404,11 @@ def flash_attention_v2_rpe(q, k, v, rpe_table, bidirectional=True, num_buckets=3
         sm_scale = 1.0 / math.sqrt(D)
     if D == 16:
         q, k, v = _pad16((q, k, v))
-    rpe1d = _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance)
-    _check_rpe1d(rpe1d, q.shape[1], R, q.device)
+    if rpe_table.device != q.device:
+        raise ValueError("rpe_table must live on q's device")
     idx = _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device)
-    o = nat.rpe_table_apply(q, k, v, rpe_table, rpe1d, idx, R, int(num_buckets), bool(causal), float(sm_scale))
+    # (the C++ function builds the (H, 2R+1) generator from the table itself, one launch per call, never cached)
+    o = nat.rpe_table_apply(q, k, v, rpe_table, idx, R, int(num_buckets), bool(causal), float(sm_scale))
     return o[..., :16] if D == 16 else o
 
 
@@ -498,6 +507,7 @@ def _varlen_params(q, k, v, cu_q, cu_k, max_q, max_k, causal, sm_scale):
     for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v)):
         setattr(p, name, _lib.c_i64x3(0, t.stride(1), t.stride(0)))
     p.cu_seqlens_q, p.cu_seqlens_k, p.total_q, p.total_k = cu_q.data_ptr(), cu_k.data_ptr(), Tq, k.shape[0]
+    p.variant = _lib._variant
     return p
 
 
@@ -651,7 +661,7 @@ class AttentionPlan:
     mode: "none" | "dense" (bias tensor) | "rpe" (rpe1d (H, 2R+1) fp32 + radius)."""
 
     def __init__(self, q, k, v, do, *, bias=None, rpe1d=None, radius=0, causal=False, sm_scale=None, need_dbias=True,
-                 rpe_bucket=None, num_buckets=0, units=None):
+                 rpe_bucket=None, num_buckets=0, units=None, variant=None):
         """units = (begin, count): run only the head-major unit range u = h * B + b in [begin, begin + count) (a rank's shard,
         `flasht5_amd.sharding.unit_range`); the bias gradient then holds this range's partial sums."""
         _check_inputs(q, k, v)
@@ -682,8 +692,17 @@ class AttentionPlan:
             elif need_dbias:
                 self.dbias = torch.empty_like(rpe1d)
                 p.drpe1d = self.dbias.data_ptr()
+        # an EMPTY shard (more ranks than units): the C ABI reads unit_count == 0 as "the whole problem", so such a plan launches
+        # nothing at all -- its outputs stay untouched and its bias gradient is zero (the rank still joins the all-reduce)
+        self.empty = units is not None and int(units[1]) == 0
         if units is not None:
+            if int(units[1]) < 0 or int(units[0]) < 0 or int(units[0]) + int(units[1]) > B * H:
+                raise ValueError(f"unit range {tuple(units)} outside the {B * H} (batch, head) units")
             p.unit_begin, p.unit_count = int(units[0]), int(units[1])
+        if self.empty and self.dbias is not None:
+            self.dbias.zero_()
+        if variant is not None:  # tests / profilers: force or forbid a kernel body for this plan (include/fat5.h `enum fat5_variant`)
+            p.variant = int(variant)
         self.lib = _lib.load()
         nbytes = self.lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(p))
         self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
@@ -691,7 +710,17 @@ class AttentionPlan:
         self.p = p
         self.device = dev
 
+    def set_variant(self, bits):
+        """tests / profilers: kernel-variant bits of this plan's calls; the workspace is re-sized for the new choice"""
+        self.p.variant = int(bits)
+        nbytes = self.lib.fat5_attn_bwd_workspace_bytes(ctypes.byref(self.p))
+        if nbytes > self.ws.numel():
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.p.workspace, self.p.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+
     def forward(self):
+        if self.empty:
+            return self.o
         _lib.check(self.lib.fat5_attn_fwd(ctypes.byref(self.p), _lib.stream_ptr(self.device)), "fat5_attn_fwd")
         return self.o
 
@@ -700,6 +729,8 @@ class AttentionPlan:
         return int(self.lib.fat5_attn_bwd_launches(ctypes.byref(self.p)))
 
     def backward(self, stages=7):
+        if self.empty:
+            return self.dq, self.dk, self.dv, self.dbias
         _lib.check(self.lib.fat5_attn_bwd_stages(ctypes.byref(self.p), int(stages), _lib.stream_ptr(self.device)),
                    "fat5_attn_bwd")
         return self.dq, self.dk, self.dv, self.dbias

@@ -28,7 +28,9 @@ def shard_units(B: int, H: int, world: int, rank: int) -> List[Tuple[int, int]]:
 
 def unit_range(B: int, H: int, world: int, rank: int) -> Tuple[int, int]:
     """(unit_begin, unit_count) of this rank's chunk in head-major unit order -- what `fat5_attn_params.unit_begin/unit_count`
-    (and `AttentionPlan(units=...)`) take: the shard of `shard_units` runs in ONE forward and ONE backward call."""
+    (and `AttentionPlan(units=...)`) take: the shard of `shard_units` runs in ONE forward and ONE backward call.
+    world > B * H leaves the trailing ranks an EMPTY chunk (count 0): `AttentionPlan` then launches nothing (in the raw C ABI
+    unit_count == 0 means "the whole problem" -- never pass an empty chunk there)."""
     total = B * H
     base, rem = divmod(total, world)
     start = rank * base + min(rank, rem)

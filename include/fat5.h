@@ -12,8 +12,8 @@
  *  - plain pointers and sizes only; no torch / HIP C++ types (hipStream_t is passed as void*).
  *  - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or
  *    frees device memory.  Its only process-wide state is idempotent launch configuration (the largest dynamic-LDS size
- *    already requested per kernel, a few developer environment knobs read on first use): results never depend on call
- *    history and every entry point is safe to call from several threads.  All launches are asynchronous on the given
+ *    already requested per kernel).  It reads NO environment variables: results depend on the arguments of the call alone,
+ *    never on call history, and every entry point is safe to call from several threads.  All launches are asynchronous on the given
  *    stream; the library never synchronises.
  *  - return value: FAT5_OK (0) or a negative error; the message of the last error on the
  *    calling thread is available from fat5_last_error().  Nothing throws across the ABI.
@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 100 /* 0.1.0 */
+#define FAT5_VERSION 110 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+                            AdamWScale state dtype / flags */
 
 enum fat5_status {
   FAT5_OK = 0,
@@ -39,6 +40,16 @@ enum fat5_status {
 };
 
 enum fat5_dtype { FAT5_F16 = 1, FAT5_BF16 = 2, FAT5_F32 = 0 };
+
+/* fat5_attn_params.variant bits (testing / profiling only) */
+enum fat5_variant {
+  FAT5_V_FWD64_ON = 1, FAT5_V_FWD64_OFF = 2,   /* forward: 64-rows-per-wave pipelined body (attn_fwd64.h) wherever it applies / never */
+  FAT5_V_KV64_ON = 4, FAT5_V_KV64_OFF = 8,     /* backward dK/dV: 64-keys-per-wave pipelined body (attn_bwd64.h) */
+  FAT5_V_Q64_ON = 16, FAT5_V_Q64_OFF = 32,     /* backward dQ: 64-rows-per-wave pipelined body */
+  FAT5_V_DBIAS_STAGED = 64, FAT5_V_DBIAS_INKERNEL = 128, /* dense (1,H,M,N) dbias: staged dS + reduction / batch-inner kernel */
+  FAT5_V_NO_FUSE = 256,                         /* backward: never the single side-by-side dQ | dK/dV launch */
+  FAT5_V_NO_SPLIT = 512                         /* forward: never the two-waves-per-32-rows short-sequence body */
+};
 
 enum fat5_bias_mode {
   FAT5_BIAS_NONE = 0,  /* bias=None (reference HAS_BIAS=False, e.g. T5 cross-attention) */
@@ -111,7 +122,9 @@ typedef struct fat5_attn_params {
    * its unreduced (B, H, M, N) form.  unit_count == 0: the whole problem. */
   int32_t unit_begin;
   int32_t unit_count;
-  int32_t reserved0;
+  int32_t variant;          /* 0 in production: the library picks every kernel variant from the problem alone.  Tests and
+                               profilers OR fat5_variant bits here to force / forbid a body for THIS call (no environment
+                               variables, no process-wide switches: the choice is part of the call). */
   void* workspace;          /* size from fat5_attn_bwd_workspace_bytes(); 256-B aligned */
   size_t workspace_bytes;
 } fat5_attn_params;
@@ -137,6 +150,13 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p);
  * FAT5_BWD_DQ | FAT5_BWD_DKDV in one call may use the single side-by-side launch (fat5_attn_bwd_launches). */
 enum fat5_bwd_stage { FAT5_BWD_DQ = 1, FAT5_BWD_DKDV = 2, FAT5_BWD_REDUCE = 4, FAT5_BWD_ALL = 7 };
 int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* hip_stream);
+
+/* T5 table -> Toeplitz generator of FAT5_BIAS_RPE1D: rpe1d[h][i] = (float) table[rpe_bucket[i]][h], i in [0, 2R]
+ * (the embedding lookup of RelativePositionalEncoding.compute_bias, src/utils/positional_encoding.py:100-101, on the
+ * 2R+1 distinct clamped relative positions instead of M*N of them).  table: (num_buckets, H) contiguous, table_dtype in
+ * {FAT5_F32, FAT5_F16, FAT5_BF16}; rpe_bucket: (2R+1,) int32; rpe1d: (H, 2R+1) fp32, overwritten.  One small launch. */
+int fat5_rpe1d_from_table(const void* table, int table_dtype, const int32_t* rpe_bucket, float* rpe1d, int32_t H,
+                          int32_t rpe_radius, int32_t num_buckets, void* hip_stream);
 
 /*
  * T5 RMSNorm.  Replaces flasht5::rmsnorm_triton_fwd / _bwd (src/model/ops/rms_norm.py:134-236).
@@ -190,7 +210,10 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
  *   step = step_prefactor * max(1e-3, rms(p));     step_prefactor = lr [* sqrt(1-beta2^t) / (1-beta1^t)], computed by the caller
  *   p -= step * m / denom   (with `kahan`: through the compensation tensor k, :188-198);   p += -lr * weight_decay * p
  * Intermediate roundings are the reference's (every in-place op rounds to the tensor dtype; fp32 math inside an op).
- * All tensors of one call share `dtype` (parameters, gradients, m, v, k alike, as in the reference's default state dtype);
+ * Parameters, gradients and k of one call share `dtype`; m and v have `state_dtype` (== dtype by default; FAT5_F16 / FAT5_BF16 for the
+ * reference's `use_state_dtype`, :101-103 -- 16-bit moments beside parameters of another dtype; every op then rounds to the dtype
+ * of the tensor it writes, fp32 math inside).  `flags`: FAT5_ADAMW_KAHAN (16-bit parameters only); FAT5_ADAMW_PLAIN_STEP =
+ * `correct_bias=False` (the reference's step size lr * max(1e-3, rms(p)) is then rounded to the parameter dtype, :177-184).
  * `table` is a DEVICE array of n_tensors descriptors (+ one terminator whose chunk_begin is the total chunk count);
  * chunk_begin[i] = sum over j < i of ceil(numel[j] / 8192);  `partials` = device scratch of total-chunks floats.
  */
@@ -198,15 +221,17 @@ typedef struct fat5_adamw_tensor {
   void* p;              /* parameters, updated in place */
   const void* g;        /* gradients */
   void* m;              /* exp_avg */
-  void* v;              /* exp_avg_sq */
+  void* v;              /* exp_avg_sq (m, v: state_dtype) */
   void* k;              /* Kahan compensation (kahan != 0), else NULL */
   int64_t numel;
   int32_t chunk_begin;
   float step_prefactor;
 } fat5_adamw_tensor;
+enum fat5_adamw_flags { FAT5_ADAMW_KAHAN = 1, FAT5_ADAMW_PLAIN_STEP = 2 };
 /* hyper-parameters as doubles: the reference passes Python floats, and e.g. (1 - beta2) is formed in double before the op casts it */
 int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
-                          double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan, void* hip_stream);
+                          double beta1, double beta2, double weight_decay, double eps, int dtype, int state_dtype, int flags,
+                          void* hip_stream);
 /* Global-norm gradient clipping folded into the step (torch.nn.utils.clip_grad_norm_ + AdamWScale.step in one pass; the
  * reference trains with `max_grad_norm: 1.0`, configs/flan/fat5-flan-base.yaml): fat5_adamw_grad_sumsq writes one partial sum of
  * squares of the GRADIENTS per 8192-element chunk (the caller sums them over every group, forms
@@ -216,8 +241,8 @@ int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int
 int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, int dtype,
                           void* hip_stream);
 int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
-                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int kahan,
-                                  const float* grad_coef, void* hip_stream);
+                                  double beta1, double beta2, double weight_decay, double eps, int dtype, int state_dtype,
+                                  int flags, const float* grad_coef, void* hip_stream);
 size_t fat5_sizeof_adamw_tensor(void);
 
 #ifdef __cplusplus

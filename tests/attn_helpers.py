@@ -53,13 +53,20 @@ def oracle_all(q, k, v, b, do, sm_scale, causal):
 
 
 def run_dense(q, k, v, b, do, sm_scale, causal):
-    """Run the product path (HIP kernels through the C ABI) forward + backward."""
+    """Run the product path (HIP kernels through the C ABI) forward + backward; "L" = the forward's log-sum-exp output (part of
+    the operator contract, reference flash_attention_v2_bias.py:59,:476), from the same forward entry point the backward reads it from."""
     from flasht5_amd import flash_attention_v2_bias
+    from flasht5_amd.flash_attention_v2_bias import _attn_fwd
     leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
     bb = b.detach().clone().requires_grad_() if b is not None else None
     o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], bb, causal, sm_scale)
     grads = torch.autograd.grad(o, leaves + ([bb] if bb is not None else []), do)
-    out = {"o": o.detach(), "dq": grads[0], "dk": grads[1], "dv": grads[2]}
+    qq, kk, vv = (t.detach() for t in leaves)
+    if q.shape[-1] == 16:
+        qq, kk, vv = (torch.nn.functional.pad(t, (0, 16)) for t in (qq, kk, vv))
+    o2, L = _attn_fwd(qq, kk, vv, b, None, 0, bool(causal), float(sm_scale))
+    assert torch.equal(o2[..., :q.shape[-1]], o.detach())  # (deterministic: the second forward is the first one bit for bit)
+    out = {"o": o.detach(), "L": L, "dq": grads[0], "dk": grads[1], "dv": grads[2]}
     if bb is not None:
         out["db"] = grads[3]
     return out

@@ -151,6 +151,21 @@ def gen_attn_case(name, seed, B, H, M, N, D, dtype, bias_kind, causal, sm_scale,
         grads = None  # reference eager gives NaN rows (Q2); pinned to the oracle's 0/-inf convention
     o_lp = ref_attn_ref(q, k, v, b, sm_scale, causal=causal, upcast=False)
     lp_err = [maxdiff(o_lp, o_ref.detach()) if not (causal and M > N) else 0.0, 0.0, 0.0, 0.0, 0.0]
+    if larger_m_causal and dtype != torch.float32:
+        # The reference's eager path NaNs on the M - N query rows that see no key (Q2).  Its low-precision error is still defined
+        # on the rows that do: rows m >= M - N alone form the square causal problem (same keys, same bias rows), whose o, dq and
+        # dbias rows are the full problem's rows and whose dk / dv are the full problem's (empty rows contribute nothing).
+        lo = M - N
+        qs, dos = q[:, :, lo:], do[:, :, lo:]
+        bs = b[:, :, lo:] if b is not None else None
+        lv32 = [t.float().requires_grad_() for t in (qs, k, v)] + ([bs.float().requires_grad_()] if b is not None else [])
+        o32 = ref_attn_ref(lv32[0], lv32[1], lv32[2], lv32[3] if b is not None else None, sm_scale, causal=True, upcast=True)
+        g32 = torch.autograd.grad(o32, lv32, dos.float())
+        lvl = [t.clone().requires_grad_() for t in (qs, k, v)] + ([bs.clone().requires_grad_()] if b is not None else [])
+        olp = ref_attn_ref(lvl[0], lvl[1], lvl[2], lvl[3] if b is not None else None, sm_scale, causal=True, upcast=False)
+        glp = torch.autograd.grad(olp, lvl, dos)
+        assert torch.isfinite(o32).all() and all(torch.isfinite(t).all() for t in g32)
+        lp_err = [maxdiff(olp, o32.detach())] + [maxdiff(a_, b_) for a_, b_ in zip(glp, g32)] + [0.0] * (4 - len(g32))
     if dtype != torch.float32 and not (causal and M > N):
         lv = [t.clone().requires_grad_() for t in (q, k, v)] + ([b.clone().requires_grad_()] if b is not None else [])
         o_lp2 = ref_attn_ref(lv[0], lv[1], lv[2], lv[3] if b is not None else None, sm_scale, causal=causal, upcast=False)
@@ -241,11 +256,11 @@ def run_triton_interp(q, k, v, b, do, causal, sm_scale, BM=32, BN=32):
     return o, L, dq, dk, dv, ds
 
 
-def gen_triton_case(name, seed, B, H, M, N, D, bias_kind, causal, sm_scale):
+def gen_triton_case(name, seed, B, H, M, N, D, bias_kind, causal, sm_scale, BM=32, BN=32):
     dtype = torch.float16
     bias_shape = {"1h": (1, H, M, N), "bh": (B, H, M, N)}[bias_kind]
     q, k, v, b, do = attn_inputs(seed, B, H, M, N, D, dtype, bias_shape)
-    o, L, dq, dk, dv, ds = run_triton_interp(q, k, v, b, do, causal, sm_scale)
+    o, L, dq, dk, dv, ds = run_triton_interp(q, k, v, b, do, causal, sm_scale, BM, BN)
     o_mine, L_mine = oracle.attn_fwd_oracle(q, k, v, b, sm_scale, causal)
     gq, gk, gv, _, gb = oracle.attn_bwd_oracle(q, k, v, b, o_mine, L_mine, do, sm_scale, causal)
     errs = dict(o=maxdiff(o, o_mine), L=maxdiff(L, L_mine), dq=maxdiff(dq, gq), dk=maxdiff(dk, gk),
@@ -352,28 +367,35 @@ def gen_adamw():
     from src.utils.adamw_scaled import AdamWScale
     out = {}
     cases = [("fp32", torch.float32, False, 0.0), ("fp32_wd", torch.float32, False, 0.03), ("bf16", torch.bfloat16, False, 0.0),
-             ("bf16_kahan_wd", torch.bfloat16, True, 0.03), ("fp16_kahan", torch.float16, True, 0.0)]
-    for name, dtype, kahan, wd in cases:
+             ("bf16_kahan_wd", torch.bfloat16, True, 0.03), ("fp16_kahan", torch.float16, True, 0.0),
+             # round 3: `use_state_dtype` (:101-103) and `correct_bias=False` (:177)
+             ("fp32_sbf16_wd", torch.float32, False, 0.03, torch.bfloat16, True), ("bf16_kahan_sfp16", torch.bfloat16, True, 0.0, torch.float16, True),
+             ("bf16_plain", torch.bfloat16, False, 0.0, None, False), ("fp32_plain_wd", torch.float32, False, 0.03, None, False),
+             ("fp16_kahan_plain_sbf16", torch.float16, True, 0.0, torch.bfloat16, False)]
+    for case in cases:
+        name, dtype, kahan, wd = case[:4]
+        sdtype, correct = (case[4], case[5]) if len(case) > 4 else (None, True)
         g = torch.Generator().manual_seed(len(name) * 7 + 1)
         shapes = [(257, 33), (64,), (1, 12), (1000, 8)]
         p0 = [(torch.randn(*s, generator=g) * (0.02 if i != 2 else 1e-5)).to(dtype) for i, s in enumerate(shapes)]  # tensor 2: rms below the 1e-3 floor
         grads = [[(torch.randn(*s, generator=g) * 0.1).to(dtype) for s in shapes] for _ in range(3)]
         # the reference
         rp = [torch.nn.Parameter(t.clone()) for t in p0]
-        opt = AdamWScale(rp, lr=0.01, betas=(0.9, 0.999), eps=1e-6, weight_decay=wd, kahan_sum=kahan, foreach=False)
+        opt = AdamWScale(rp, lr=0.01, betas=(0.9, 0.999), eps=1e-6, weight_decay=wd, kahan_sum=kahan, foreach=False,
+                         correct_bias=correct, use_state_dtype=sdtype)
         for step in range(3):
             for t, gr in zip(rp, grads[step]):
                 t.grad = gr.clone()
             opt.step()
         # the oracle
         mp = [t.clone() for t in p0]
-        m = [torch.zeros_like(t) for t in p0]
-        v = [torch.zeros_like(t) for t in p0]
+        m = [torch.zeros_like(t, dtype=sdtype or t.dtype) for t in p0]
+        v = [torch.zeros_like(t, dtype=sdtype or t.dtype) for t in p0]
         use_k = kahan and dtype in (torch.float16, torch.bfloat16)
         kc = [torch.zeros_like(t) if use_k else None for t in p0]
         for step in range(3):
             for i in range(len(mp)):
-                oracle.adamw_scale_step(mp[i], grads[step][i].clone(), m[i], v[i], kc[i], step + 1, 0.01, 0.9, 0.999, wd, 1e-6, True)
+                oracle.adamw_scale_step(mp[i], grads[step][i].clone(), m[i], v[i], kc[i], step + 1, 0.01, 0.9, 0.999, wd, 1e-6, correct)
         for i in range(len(mp)):
             st = opt.state[rp[i]]
             assert torch.equal(mp[i], rp[i].detach()), (name, i, "p")
@@ -388,12 +410,30 @@ def gen_adamw():
                 out[f"{name}__k_{i}"] = npy(kc[i])
             for step in range(3):
                 out[f"{name}__g{step}_{i}"] = npy(grads[step][i])
-        out[f"{name}__cfg"] = np.array([{torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype], int(kahan), wd, 0.01, 0.9, 0.999, 1e-6])
+        code = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+        out[f"{name}__cfg"] = np.array([code[dtype], int(kahan), wd, 0.01, 0.9, 0.999, 1e-6, code[sdtype] if sdtype is not None else -1, int(correct)])
     save("adamw_scale", **out)
+
+
+def gen_triton_round3():
+    """head dims 128 and 32, and M > N non-causal with a per-batch (B, H, M, N) bias (parity hole iii)"""
+    gen_triton_case("triton_d128_nc_1h_fp16", 24, 1, 2, 64, 72, 128, "1h", False, 1.0 / math.sqrt(128))  # (the default scale)
+    gen_triton_case("triton_d32_c_1h_fp16", 25, 2, 2, 64, 64, 32, "1h", True, 0.5)
+    gen_triton_case("triton_mgtn_nc_bh_fp16", 26, 2, 2, 96, 48, 64, "bh", False, 1.0)
 
 
 def main():
     torch.set_num_threads(8)
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
+    if only is not None:  # regenerate a subset: `--only adamw,triton3,mgtn` (every generator is seeded: the others are unchanged)
+        f16 = torch.float16
+        if "adamw" in only:
+            gen_adamw()
+        if "mgtn" in only:
+            gen_attn_case("attn_mgtn_c_1h_fp16", 5, 2, 2, 96, 64, 64, f16, "1h", True, 1.0)
+        if "triton3" in only:
+            gen_triton_round3()
+        return
     gen_rpe()
     f32, f16, bf16 = torch.float32, torch.float16, torch.bfloat16
     # cfg1: t5-small encoder self-attn fwd (2,8,128,64) fp32 eager CPU numerics baseline
@@ -413,6 +453,7 @@ def main():
     gen_triton_case("triton_t80_nc_1h_fp16", 21, 2, 2, 64, 80, 64, "1h", False, 1.0)
     gen_triton_case("triton_t80_c_bh_fp16", 22, 2, 2, 64, 80, 64, "bh", True, 1.0)
     gen_triton_case("triton_t100_nc_1h_fp16", 23, 1, 2, 96, 100, 64, "1h", False, 0.5)
+    gen_triton_round3()
     gen_rmsnorm()
     gen_ce()
     gen_adamw()

@@ -41,4 +41,5 @@ ATTN_CASES = [
     "attn_mgtn_nc_bh_bf16", "attn_mgtn_c_1h_fp16", "attn_nobias_c_bf16", "attn_11_nc_bf16",
     "attn_d128_nc_bf16", "attn_d32_c_fp16",
 ]
-TRITON_CASES = ["triton_t80_nc_1h_fp16", "triton_t80_c_bh_fp16", "triton_t100_nc_1h_fp16"]
+TRITON_CASES = ["triton_t80_nc_1h_fp16", "triton_t80_c_bh_fp16", "triton_t100_nc_1h_fp16",
+                "triton_d128_nc_1h_fp16", "triton_d32_c_1h_fp16", "triton_mgtn_nc_bh_fp16"]  # (round 3: D = 128, D = 32, M > N per-batch bias)

@@ -22,7 +22,7 @@ def _case(z, name):
     return dtype, kahan, wd, lr, b1, b2, eps, get
 
 
-@pytest.mark.parametrize("name", ["fp32", "fp32_wd", "bf16", "bf16_kahan_wd", "fp16_kahan"])
+@pytest.mark.parametrize("name", ["fp32", "fp32_wd", "bf16", "bf16_kahan_wd", "fp16_kahan", "fp32_sbf16_wd", "bf16_kahan_sfp16", "bf16_plain", "fp32_plain_wd", "fp16_kahan_plain_sbf16"])
 def test_adamw_scale_reference_fixture(name):
     """Against the reference class's CPU results.  torch's CPU kernels round the `alpha` of a 16-bit add_ to 16 bit where its
     device kernels (and this one) keep it in fp32, and a Kahan pair (p, k) may split the same value one ulp of p differently:
@@ -30,8 +30,11 @@ def test_adamw_scale_reference_fixture(name):
     from flasht5_amd import AdamWScale
     z = load("adamw_scale")
     dtype, kahan, wd, lr, b1, b2, eps, get = _case(z, name)
+    cfg = z[f"{name}__cfg"]
+    sdtype = None if int(cfg[7]) < 0 else DT[int(cfg[7])]  # `use_state_dtype` (reference :101-103)
+    correct = bool(cfg[8])                                  # `correct_bias` (:177)
     params = [torch.nn.Parameter(get("p0", i).cuda()) for i in range(4)]
-    opt = AdamWScale(params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, kahan_sum=kahan)
+    opt = AdamWScale(params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, kahan_sum=kahan, correct_bias=correct, use_state_dtype=sdtype)
     for step in range(3):
         for i, p in enumerate(params):
             p.grad = get(f"g{step}", i).cuda()
@@ -40,13 +43,13 @@ def test_adamw_scale_reference_fixture(name):
 
     def ulp_err(got, want):  # max error in units of the last place of the tensor's largest magnitude
         w = want.float()
-        return (got.float().cpu() - w).abs().max().item() / (ULP[dtype] * max(w.abs().max().item(), 1e-30))
+        return (got.float().cpu() - w).abs().max().item() / (ULP[got.dtype] * max(w.abs().max().item(), 1e-30))  # (the tensor's own dtype: states may differ from p)
 
     for i, p in enumerate(params):
         st = opt.state[p]
         assert all(torch.isfinite(t.float()).all() for t in (p, st["exp_avg"], st["exp_avg_sq"]))
         assert ulp_err(st["exp_avg"], get("m", i)) <= 1.0, (name, i, "m", ulp_err(st["exp_avg"], get("m", i)))
-        assert ulp_err(st["exp_avg_sq"], get("v", i)) <= 1.0 or (st["exp_avg_sq"].float().cpu() - get("v", i).float()).abs().max().item() <= 2 * TINY[dtype], (name, i, "v")
+        assert ulp_err(st["exp_avg_sq"], get("v", i)) <= 1.0 or (st["exp_avg_sq"].float().cpu() - get("v", i).float()).abs().max().item() <= 2 * TINY[st["exp_avg_sq"].dtype], (name, i, "v")
         assert ulp_err(p.detach(), get("p", i)) <= 2.0, (name, i, "p", ulp_err(p.detach(), get("p", i)))
         if kahan:
             got = p.detach().float().cpu() + st["kahan_comp"].float().cpu()
@@ -146,3 +149,42 @@ def test_fused_gradient_clipping_matches_clip_then_step(gscale):
             opt.step()
         for p_, q_ in zip(ps, psf):
             assert torch.equal(p_.detach(), q_.detach())
+
+
+@pytest.mark.parametrize("path", ["native", "python"])
+def test_rpe_table_forward_sees_fused_optimizer_updates(path):
+    """`flash_attention_v2_rpe(q, k, v, table)` in a training loop with this package's fused AdamWScale.  The
+    optimizer kernel writes the table through its raw pointer (no autograd version bump), so anything cached per table version
+    would keep running the step-0 bias.  Three steps of the in-kernel-RPE path against the dense path (`compute_bias` of the live
+    table, the reference's formulation: positional_encoding.py:73-110 + flash_attention_v2_bias) with its own copy of the table
+    and optimizer: outputs agree at EVERY step and the tables stay together."""
+    from flasht5_amd import AdamWScale, flash_attention_v2_bias, flash_attention_v2_rpe
+    from flasht5_amd import positional_encoding as pe
+    from flasht5_amd.flash_attention_v2_bias import FlashAttentionRPE
+    B, H, S, D = 2, 4, 192, 64
+    g = torch.Generator().manual_seed(21)
+    q, k, v, do = (torch.randn(B, H, S, D, generator=g).bfloat16().cuda() for _ in range(4))
+    t0 = torch.randn(32, H, generator=g) * 0.5
+    ta, tb = torch.nn.Parameter(t0.clone().cuda()), torch.nn.Parameter(t0.clone().cuda())
+    oa_, ob_ = AdamWScale([ta], lr=0.5), AdamWScale([tb], lr=0.5)  # (large steps: a stale bias would be off by ~0.25 per entry)
+    first = None
+    for step in range(3):
+        if path == "native":
+            o1 = flash_attention_v2_rpe(q, k, v, ta, True, 32, 128, False, 0.125)
+        else:
+            o1 = FlashAttentionRPE.apply(q, k, v, ta, True, 32, 128, False, 0.125)
+        (o1.float() * do.float()).sum().backward()
+        bias = pe.compute_bias(tb, S, S, True, 32, 128).to(torch.bfloat16).contiguous()
+        o2 = flash_attention_v2_bias(q, k, v, bias, False, 0.125)
+        (o2.float() * do.float()).sum().backward()
+        e = (o1.float() - o2.float()).abs().max().item()
+        assert e <= 2 * (1e-3 + 2.0 ** -8) * max(1.0, o2.float().abs().max().item()), (step, e)  # (two bf16 outputs, bf16-rounded bias on one side)
+        if first is None:
+            first = o1.detach().clone()
+        oa_.step()
+        ob_.step()
+        ta.grad = tb.grad = None
+    # the table really moved, the forward really followed it, and both loops ended in the same place
+    assert (ta.detach() - t0.cuda()).abs().max().item() > 0.2
+    assert (o1.detach().float() - first.float()).abs().max().item() > 0.02
+    assert (ta.detach() - tb.detach()).abs().max().item() <= 0.05 * max(1.0, tb.detach().abs().max().item())

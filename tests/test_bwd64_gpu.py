@@ -1,5 +1,5 @@
 """GPU parity tests of the long-sequence backward bodies (csrc/attn_bwd64.h: dK/dV with 64 keys per wave, dQ with 64 query rows
-per wave; software-pipelined step loops, 4-slot LDS rings, AGPR accumulators) -- forced with FAT5_BWD64=1 / FAT5_BWDQ64=1 at sizes
+per wave; software-pipelined step loops, 4-slot LDS rings, AGPR accumulators) -- forced per call with the variant bits FAT5_V_KV64_ON / FAT5_V_Q64_ON (include/fat5.h) at sizes
 the oracle finishes in seconds; at (4,12,8192,64) the default dispatch picks them by itself
 (test_attention_gpu.py::test_cfg3_properties_s8192)."""
 import pytest
@@ -12,10 +12,23 @@ from test_attention_gpu import bound, gbound, _rpe_case
 pytestmark = pytest.mark.gpu
 
 
+def _bits(kv64, q64, fwd64=None):
+    from flasht5_amd import _lib
+    b = 0
+    if kv64 is not None:
+        b |= _lib.V_KV64_ON if kv64 else _lib.V_KV64_OFF
+    if q64 is not None:
+        b |= _lib.V_Q64_ON if q64 else _lib.V_Q64_OFF
+    if fwd64 is not None:
+        b |= _lib.V_FWD64_ON if fwd64 else _lib.V_FWD64_OFF
+    return b
+
+
 @pytest.fixture(autouse=True)
-def force_bwd64(monkeypatch):
-    monkeypatch.setenv("FAT5_BWD64", "1")
-    monkeypatch.setenv("FAT5_BWDQ64", "1")
+def force_bwd64():
+    from flasht5_amd import _lib
+    with _lib.variant(_bits(True, True)):
+        yield
 
 
 def _grads(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
@@ -87,9 +100,9 @@ def test_bwd64_agrees_with_32key_body(monkeypatch):
     q, k, v, _, do = make_inputs(2, 4, 2048, 2048, 64, torch.bfloat16, None, seed=3, strided=True)
     table = (torch.randn(32, 4, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
     outs = []
-    for f in ("0", "1"):
-        monkeypatch.setenv("FAT5_BWD64", f)
-        monkeypatch.setenv("FAT5_BWDQ64", f)
+    from flasht5_amd import _lib
+    for f in (False, True):
+        _lib.set_variant(_bits(f, f))
         plan = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=True, rpe1d=pe.rpe1d_from_table(table, True, 32, 128), radius=128)
         plan.forward()
         plan.backward()
@@ -141,8 +154,8 @@ def test_bwd64_deterministic():
 def test_bwd64_mixed_with_32wide_bodies(monkeypatch, kv64, q64):
     """one 64-wide body next to the other 32-wide one (what the dispatch picks when only M or only N is long): the row statistics
     cross between them in both directions (delta for the 32-key dK/dV body, the pre-scaled pair for the 64-key one)"""
-    monkeypatch.setenv("FAT5_BWD64", kv64)
-    monkeypatch.setenv("FAT5_BWDQ64", q64)
+    from flasht5_amd import _lib
+    _lib.set_variant(_bits(kv64 == "1", q64 == "1"))
     q, k, v, do, table, bias = _rpe_case(2, 2, 600, 456, torch.bfloat16, True, True, 128, seed=77)
     ref = oracle_all(q, k, v, bias, do, 0.125, True)
     got = _grads(q, k, v, do, True, 0.125, table)
@@ -159,8 +172,8 @@ def test_default_dispatch_long_sequence_slice_vs_oracle(monkeypatch, dtype, caus
     fp32 oracle run on the device, table gradient of the whole batch through the zero-sum property of the softmax Jacobian."""
     from flasht5_amd.flash_attention_v2_bias import AttentionPlan
     from flasht5_amd import positional_encoding as pe
-    for name in ("FAT5_BWD64", "FAT5_BWDQ64", "FAT5_FWD64"):
-        monkeypatch.delenv(name, raising=False)
+    from flasht5_amd import _lib
+    _lib.set_variant(0)  # the library's own choice
     B, H, S = 4, 12, 4096
     q, k, v, _, do = make_inputs(B, H, S, S, 64, dtype, None, seed=12, strided=True)
     table = (torch.randn(32, H, generator=torch.Generator().manual_seed(4)) * 0.5).cuda()

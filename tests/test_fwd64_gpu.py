@@ -1,5 +1,5 @@
 """GPU parity tests of the long-sequence forward body (csrc/attn_fwd64.h: 64 query rows per wave, software-pipelined tile
-loop, 4-slot LDS rings) -- forced with FAT5_FWD64=1 at sizes the oracle finishes in seconds; at (4,12,8192,64) the default
+loop, 4-slot LDS rings) -- forced per call with the variant bit FAT5_V_FWD64_ON (include/fat5.h) at sizes the oracle finishes in seconds; at (4,12,8192,64) the default
 dispatch picks it by itself (test_attention_gpu.py::test_cfg3_properties_s8192)."""
 import pytest
 import torch
@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def force_fwd64(monkeypatch):
-    monkeypatch.setenv("FAT5_FWD64", "1")
+def force_fwd64():
+    from flasht5_amd import _lib
+    with _lib.variant(_lib.V_FWD64_ON):
+        yield
 
 
 def _run(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
@@ -111,8 +113,9 @@ def test_fwd64_agrees_with_32row_body(monkeypatch):
     table = (torch.randn(32, 4, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
     plan = AttentionPlan(q, k, v, do, sm_scale=0.125, need_dbias=False, rpe1d=pe.rpe1d_from_table(table, True, 32, 128), radius=128)
     outs = []
-    for f in ("0", "1"):
-        monkeypatch.setenv("FAT5_FWD64", f)
+    from flasht5_amd import _lib
+    for f in (_lib.V_FWD64_OFF, _lib.V_FWD64_ON):
+        plan.set_variant(f)
         plan.forward()
         torch.cuda.synchronize()
         outs.append((plan.o.float().clone(), plan.lse.clone()))

@@ -176,7 +176,10 @@ def test_varlen_bwd_oracle_matches_autograd():
             assert md(a, b) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["fp32", "fp32_wd", "bf16", "bf16_kahan_wd", "fp16_kahan"])
+ADAMW_CASES = ["fp32", "fp32_wd", "bf16", "bf16_kahan_wd", "fp16_kahan", "fp32_sbf16_wd", "bf16_kahan_sfp16", "bf16_plain", "fp32_plain_wd", "fp16_kahan_plain_sbf16"]
+
+
+@pytest.mark.parametrize("name", ADAMW_CASES)
 def test_adamw_scale_golden(name):
     """the optimizer-step oracle reproduces, bit for bit, what the reference class `AdamWScale` produced on the same seeded tensors
     (three steps; fixture written by tests/golden/make_golden.py gen_adamw, which also asserted it against the live class)"""
@@ -185,13 +188,16 @@ def test_adamw_scale_golden(name):
     cfg = z[f"{name}__cfg"]
     dtype = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(cfg[0])]
     kahan, wd, lr, b1, b2, eps = bool(cfg[1]), float(cfg[2]), float(cfg[3]), float(cfg[4]), float(cfg[5]), float(cfg[6])
+    # round 3: `use_state_dtype` (exp_avg / exp_avg_sq in another 16-bit dtype, reference :101-103) and `correct_bias` (:177)
+    sdtype = {-1: dtype, 0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(cfg[7])]
+    correct = bool(cfg[8])
     for i in range(4):
         p = _t(z[f"{name}__p0_{i}"]).clone()
         assert p.dtype == dtype
-        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        m, v = torch.zeros_like(p, dtype=sdtype), torch.zeros_like(p, dtype=sdtype)
         k = torch.zeros_like(p) if (kahan and dtype != torch.float32) else None
         for step in range(3):
-            oracle.adamw_scale_step(p, _t(z[f"{name}__g{step}_{i}"]).clone(), m, v, k, step + 1, lr, b1, b2, wd, eps, True)
+            oracle.adamw_scale_step(p, _t(z[f"{name}__g{step}_{i}"]).clone(), m, v, k, step + 1, lr, b1, b2, wd, eps, correct)
         assert torch.equal(p, _t(z[f"{name}__p_{i}"])) and torch.equal(m, _t(z[f"{name}__m_{i}"])) and torch.equal(v, _t(z[f"{name}__v_{i}"]))
         if k is not None:
             assert torch.equal(k, _t(z[f"{name}__k_{i}"]))
