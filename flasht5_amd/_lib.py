@@ -114,6 +114,7 @@ def load():
 # fat5_attn_params.variant bits (include/fat5.h `enum fat5_variant`): tests and profilers force / forbid a kernel body per call
 V_FWD64_ON, V_FWD64_OFF, V_KV64_ON, V_KV64_OFF, V_Q64_ON, V_Q64_OFF = 1, 2, 4, 8, 16, 32
 V_DBIAS_STAGED, V_DBIAS_INKERNEL, V_NO_FUSE, V_NO_SPLIT = 64, 128, 256, 512
+V_FWD64_KSPLIT_ON, V_FWD64_KSPLIT_OFF = 1024, 2048
 _variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)
 
 

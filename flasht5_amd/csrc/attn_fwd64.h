@@ -9,12 +9,24 @@
 //    (attn_fwd.h) has 4-long same-accumulator chains, so its softmax VALU work cannot be placed under its MFMAs at all
 //    (measured there: time = 32 * #MFMA + sum of VALU issue).  Here VALU / LDS work sits in the gaps between MFMAs.
 //  * Three-stage software pipeline over 32-key blocks i: while the VALU pipe turns the scores of block i into
-//    probabilities (one FMA + v_exp_f32 + row-sum add per element, packed to 16 bit), the matrix pipe runs
-//    O^T += V^T P^T of block i-1 and S^T = K Q^T of block i+1 -- 16 MFMAs that do not depend on this block's VALU work.
-//  * K and V live in separate 3-slot LDS rings filled global -> LDS by DMA two tiles (K) / one tile (V) ahead;
+//    probabilities (one FMA + v_exp_f32 per element, packed to 16 bit), the matrix pipe runs O^T += V^T P^T of block i-1
+//    and S^T = K Q^T of block i+1 -- 16 MFMAs that do not depend on this block's VALU work.
+//  * K and V live in separate 4-slot LDS rings filled global -> LDS by DMA three tiles (K) / two tiles (V) ahead;
 //    one barrier per 64-key tile.
-//  * The pipelined loop covers the all-visible constant-bias tiles with the optimistic softmax of attn_fwd.h (bf16; exact
-//    second pass if a row sum overflows).  Band / masked / baseline tiles run an exact, unpipelined body on both blocks.
+//  * bf16, round 3: ONE pipelined sweep over every tile all of whose keys are visible to all rows of the workgroup -- far
+//    tiles (constant bias) and the tiles of the T5 band alike -- with NO running row maximum.  FlashAttention's reference
+//    point m is free: exp2(x - m) with ANY m is exact as long as nothing overflows or is flushed, and bf16 P + fp32
+//    accumulators share fp32's exponent range.  The sweep uses m = 0 for every row: p = exp2(s * c2 + bias), no row maximum, no
+//    lane exchange, no rescale, no baseline tiles.  At the end a row whose sum left [2^-40, 2^100) (log2-scores above ~ +100 or
+//    all below ~ -40: |s * sm_scale| beyond ~28 .. 69 nats) sends its workgroup through the exact running-maximum pass again
+//    (second pass, unpipelined).  Band tiles read their per-element bias from the padded table copies in LDS (attn_common.h)
+//    inside the pipelined stream: the value is the FMA's addend (no extra VALU op), fetched three MFMA gaps ahead.
+//    Tiles with masked keys (N tail, causal diagonal) run unpipelined with the same reference point.  fp16 P overflows at
+//    2^16: fp16 runs the exact pass only.
+//  * KSPLIT (mid sequence lengths): the waves of a workgroup pair up on 64 query rows, each taking ONE 32-key block of every
+//    staged tile, and merge (m, l, O) through LDS at the end: 128-row workgroups of half-length waves.  With 64 rows x N keys
+//    per wave (4,12,2048,64) is 1536 waves on 1024 SIMDs at two waves per SIMD: half the SIMDs carry two waves for the whole
+//    kernel, the other half one.  3072 half-length waves are 3 per SIMD: two side by side, then one alone at the full issue rate.
 #pragma once
 #include "attn_common.h"
 #include <utility>
@@ -26,23 +38,16 @@ template <int N, typename F>
 FAT5_DEV void static_for(F&& f) {
   [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
-template <int NMF, int DB>
-constexpr bool v0_ok() { return NMF / 2 - 2 >= 0 && NMF / 2 - 2 + 2 * DB <= NMF; }
 
-template <int D>
+template <int D, bool KSPLIT = false>
 struct Fwd64Cfg {
-  static constexpr int NW = 4, BM = 64 * NW, BN = 64, NT = 64 * NW, NS = 4;  // NS ring slots per operand
+  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = 4;  // NS ring slots per operand
   static constexpr int TILE = rm_bytes<D, BN>();
   static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + 16;
+  static constexpr int MERGE = 32 * 64 * 4 + 1024;  // KSPLIT: per wave, one query block's O^T (32 registers x 64 lanes) + (m, l) -- inside the rings
+  static_assert(NW * MERGE <= 2 * NS * TILE, "merge area lives in the K / V rings");
   static size_t smem(int R, int bias_mode) { return TAB + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0); }
 };
-
-#ifndef FAT5_F64_PIN
-#define FAT5_F64_PIN 1  // pin the hand-placed MFMA / VALU / LDS interleave of the pipelined block: a sched_barrier after every MFMA gap
-#endif
-#ifndef FAT5_F64_ORDER
-#define FAT5_F64_ORDER 0  // 0: the 8 P.V MFMAs, then the 8 Q.K MFMAs of a block; 1: alternating
-#endif
 
 // LDS access by integer address (base VGPR + compile-time constant -> the constant lands in the instruction's offset field;
 // pointer arithmetic on the dynamic-LDS symbol costs a v_add per access instead)
@@ -85,9 +90,6 @@ FAT5_DEV uint32_t asm_cvt_pk(float a, float b) {
   else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (gfx950: one instruction, round-to-nearest-even like the cast)
   return r;
 }
-#ifndef FAT5_F64_LMFMA
-#define FAT5_F64_LMFMA 1  // row sums of the pipelined blocks on the matrix pipe (0: two v_add_f32 per element pair)
-#endif
 // acc += A(16x32) . B(32x16), in place (asm: a builtin may pick a fresh destination, and no hazard padding exists between asm ops)
 template <bool BF16>
 FAT5_DEV void mfma16_acc(f32x4& acc, const u32x4 A, const u32x4 B) {
@@ -95,21 +97,22 @@ FAT5_DEV void mfma16_acc(f32x4& acc, const u32x4 A, const u32x4 B) {
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
 }
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#ifndef FAT5_F64_MINW
-#define FAT5_F64_MINW 2  // waves per SIMD the register allocator leaves room for
-#endif
 
-template <int D, bool BF16, int BIAS>
+
+template <int D, bool BF16, int BIAS, bool KSPLIT>
 FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   static_assert(BIAS != FAT5_BIAS_DENSE, "dense bias runs the 32-row body");
-  using Cfg = Fwd64Cfg<D>;
+  using Cfg = Fwd64Cfg<D, KSPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
+  constexpr int NKB = KSPLIT ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + Cfg::FLAG);
   float* sT = reinterpret_cast<float*>(smem + Cfg::TAB) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;
+  const int rg = KSPLIT ? (w >> 1) : w;  // 64-row group of this wave
+  const int kh = KSPLIT ? (w & 1) : 0;   // KSPLIT: the 32-key block of every tile this wave owns (wave-uniform)
   int b, h, mblk;
   decode_unit(a, item, a.n_mblk, b, h, mblk);
   const int M = a.M, N = a.N;
@@ -126,7 +129,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   if (a.causal) n_end = min(N, m0 + BM + P);
   const int nt = n_end > 0 ? (n_end + BN - 1) / BN : 0;
 
-  const int qrow0 = m0 + 64 * w;  // first query row of this wave; block qb covers rows qrow0 + 32*qb ..+31
+  const int qrow0 = m0 + 64 * rg;  // first query row of this wave; block qb covers rows qrow0 + 32*qb ..+31
   // Q fragments (B operand of S^T = K Q^T): Q[q][16kk + 8hi + j]
   u32x4 qf[2][KK];
 #pragma unroll
@@ -148,7 +151,6 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   f32x16 oacc[2][DB];
   float m_run[2];
   float l_run[2][2];
-#if FAT5_F64_LMFMA
   // Row sums of the pipelined blocks: lacc[qb] += SEL . P^T words (the B operands of the P.V products, i.e. the ROUNDED
   // probabilities) with one 16x16x32 MFMA per four packed words instead of 16 v_add_f32. As a 32x16 B operand the words of lanes
   // n, n+16, n+32, n+48 form column n; SEL row 4G has ones for the k-groups of parity G%2, every other row is zero, so register 0 of
@@ -156,13 +158,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   u32x4 sel;
   {
-    const int li = (int)(threadIdx.x & 63), i16 = li & 15;
+    const int i16 = l & 15;
     const uint32_t one2 = pack2<BF16>(1.f, 1.f);
-    const uint32_t wv = ((i16 & 3) == 0 && (((li >> 4) ^ (i16 >> 2)) & 1) == 0) ? one2 : 0u;
+    const uint32_t wv = ((i16 & 3) == 0 && (((l >> 4) ^ (i16 >> 2)) & 1) == 0) ? one2 : 0u;
     sel = u32x4{wv, wv, wv, wv};
     asm volatile("" : "+v"(sel));  // (resident: never re-materialised by VALU moves right in front of an asm consumer)
   }
-#endif
 
   DmaStage<D, BN, NT> kst, vst;
   kst.init(a.ks[2], tid);
@@ -171,7 +172,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb_, a.vs[2], N, D);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)w * 1024u);
   using Dma = DmaStage<D, BN, NT>;
   static_assert(Dma::NV == 1, "one voffset per lane");
   auto dma_tile = [&](const Dma& st, __amdgpu_buffer_rsrc_t rs, uint32_t tile_off, uint32_t lds_tile) {
@@ -210,18 +211,20 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   wait_dma_all();
   __syncthreads();
-  // per-lane LDS addresses of the fragment reads (ring base folded in; slot / block / step offsets are immediates)
+  // per-lane LDS addresses of the fragment reads (ring base folded in; slot / block / step offsets are immediates;
+  // KSPLIT: the wave's own 32-key block of every tile is folded in as well)
+  const uint32_t khoff = (uint32_t)(kh * 32 * 2 * D);
   uint32_t rmA[KK], trA[2][DB];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    rmA[kk] = lds0 + (uint32_t)(Cfg::KOFF + fa.rm[kk]);
+    rmA[kk] = lds0 + (uint32_t)(Cfg::KOFF + fa.rm[kk]) + khoff;
     asm volatile("" : "+v"(rmA[kk]));  // opaque: one register per address, constants go to the offset fields
   }
 #pragma unroll
   for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      trA[j2][db] = lds0 + (uint32_t)(Cfg::VOFF + fa.tr[j2][db]);
+      trA[j2][db] = lds0 + (uint32_t)(Cfg::VOFF + fa.tr[j2][db]) + khoff;
       asm volatile("" : "+v"(trA[j2][db]));
     }
   auto rd_k = [&](uint32_t off, int blk, int kk) { return lds_rd128(rmA[kk] + off + (uint32_t)(blk * 32 * 2 * D)); };
@@ -236,28 +239,45 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   const float c2 = a.scale * kLog2e;
   const bool fold_ok = c2 > 0.f;
   float cst_neg = 0.f, cst_pos = 0.f;
+  // band tiles of the pipelined sweep: LDS byte address of entry 0 of this lane's table copy, and the lane's position term
+  // (index of block-relative key 0 for query block qb; see tile_exact: R + nb + 4 hi - qrow - ((R - qrow) & 3))
+  uint32_t tabA = 0;
+  int posb[2] = {0, 0};
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     cst_neg = sT[0];
     cst_pos = sT[2 * a.R];
+    tabA = (uint32_t)(uintptr_t)sTa;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qrow0 + 32 * qb + lq;
+      posb[qb] = a.R + 4 * hi - qrow - ((a.R - qrow) & 3);
+    }
   }
+  const int clamp_hi = rpe_n1p(a.R) - kRpePad - 28;  // (rpe_clamp_asc)
+  auto tab_addr = [&](int qb, int nb) {  // LDS address of the lane's 28-entry window of block nb (clamped into the padded copy)
+    return tabA + 4u * (uint32_t)min(max(posb[qb] + nb, -kRpePad), clamp_hi);
+  };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // ------------------------------------------------------------------------------------------------------------------
-  // Exact tile (unpipelined): MODE 0 generic (RPE band, N tail, causal diagonal), MODE 1 all-visible constant-bias tile.
+  // Unpipelined tile: MODE 0 generic (RPE band, N tail, causal diagonal), MODE 1 all-visible constant-bias tile.
   // Both query blocks per 32-key block: K / V fragments are read once and used twice.
+  // NOMAX: reference point 0 for every row (the optimistic sweep's masked tiles); otherwise the exact running maximum.
   // ------------------------------------------------------------------------------------------------------------------
-  auto tile_exact = [&]<int MODE>(int t, int slot, float cst) {
+  auto tile_exact = [&]<int MODE, bool NOMAX>(int t, int slot, float cst) {
     const int n0 = t * BN;
     const uint32_t soff = (uint32_t)(slot * TILE);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kbi = 0; kbi < NKB; ++kbi) {
+      const int kb = KSPLIT ? kh : kbi;         // key block inside the tile
+      const int kbo = KSPLIT ? 0 : kbi;         // ... as an address offset (KSPLIT: folded into the lane bases)
       const int nb = n0 + 32 * kb;
       f32x16 s[2];
       {
         u32x4 kf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = rd_k(soff, kb, kk);
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = rd_k(soff, kbo, kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -267,19 +287,18 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) vf[t2][db] = rd_v(soff, kb, t2, db);
+        for (int db = 0; db < DB; ++db) vf[t2][db] = rd_v(soff, kbo, t2, db);
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qr0 = qrow0 + 32 * qb, qrow = qr0 + lq;
         f32x16& sq = s[qb];
-        float mul, add, mcand;
+        float mul, add, mcand = 0.f;
         if constexpr (MODE == 1) {
           mul = c2;
           add = cst;
-          mcand = fmaf(max16(sq), c2, cst);
+          if constexpr (!NOMAX) mcand = fmaf(max16(sq), c2, cst);
         } else {
           bool folded = fold_ok;
-          float cb = 0.f;
           if constexpr (BIAS == FAT5_BIAS_RPE1D) {
             // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
             const int R = a.R;
@@ -307,24 +326,29 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
             for (int r = 0; r < 16; ++r)
               if (nb + crow(r, hi) > lim) sq[r] = -INFINITY;
           }
-          const float m16 = max16(sq);
           mul = folded ? c2 : 1.f;
-          add = folded ? cb : 0.f;
-          mcand = folded ? fmaf(m16, c2, cb) : m16;
+          add = 0.f;
+          if constexpr (!NOMAX) {
+            const float m16 = max16(sq);
+            mcand = folded ? m16 * c2 : m16;
+          }
         }
-        mcand = pair_max(mcand);
-        if (__any(mcand > m_run[qb] + FAT5_DEFER_THR)) {
-          const float m_new = fmaxf(m_run[qb], mcand);
-          const float alpha = fast_exp2(m_run[qb] - ((m_new == -INFINITY) ? 0.f : m_new));
-          l_run[qb][0] *= alpha;
-          l_run[qb][1] *= alpha;
+        float ad = add;
+        if constexpr (!NOMAX) {
+          mcand = pair_max(mcand);
+          if (__any(mcand > m_run[qb] + FAT5_DEFER_THR)) {
+            const float m_new = fmaxf(m_run[qb], mcand);
+            const float alpha = fast_exp2(m_run[qb] - ((m_new == -INFINITY) ? 0.f : m_new));
+            l_run[qb][0] *= alpha;
+            l_run[qb][1] *= alpha;
 #pragma unroll
-          for (int i = 0; i < DB; ++i)
+            for (int i = 0; i < DB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
-          m_run[qb] = m_new;
+              for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+            m_run[qb] = m_new;
+          }
+          ad = add - ((m_run[qb] == -INFINITY) ? 0.f : m_run[qb]);
         }
-        const float ad = add - ((m_run[qb] == -INFINITY) ? 0.f : m_run[qb]);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float x0 = fast_exp2(fmaf(sq[r], mul, ad)), x1 = fast_exp2(fmaf(sq[r + 1], mul, ad));
@@ -349,22 +373,28 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   //   S        raw scores of the block whose softmax is due (both query blocks)
   //   PB, VF   packed probabilities / V^T fragments of the block whose P.V product is due; the last two words of
   //            PB[1][1] are still on their way: xc = exponent arguments of that block's chunk 15, pc = probabilities of
-  //            its chunk 14 (row sums not yet updated with either)
+  //            its chunk 14
+  //   TN, tadr0   band tiles: table entries of the first eight keys (query block 0) of the block whose softmax is due -- fetched
+  //            during the previous block -- and the LDS address of that block's window for query block 0
   // ------------------------------------------------------------------------------------------------------------------
   f32x16 S[2];
   u32x4 PB[2][2], VF[2][DB];
   float xc[2], pc[2];
+  u32x4 TN[2];
+  uint32_t tadr0 = 0;
 
   // One pipelined 32-key block i = 16 MFMA gaps.  Gap g holds, all mutually independent:
   //   MFMA g          g < 8: O^T += VF . PB (block i-1; VF was fetched during the previous block)   g >= 8: S' = K(KS, KB) . Q^T (block i+1)
-  //   VALU            chunk g: x = s*c2 + ad (2 elements) | chunk g-1: p = exp2(x) | chunk g-2: l += p, pack to 16 bit
+  //   VALU            chunk g: x = s*c2 + bias (2 elements) | chunk g-1: p = exp2(x) | chunk g-2: pack to 16 bit
   //   LDS             gaps 0..3: one K fragment of (KS, KB); gaps 8..15: one ds_read_b64_tr_b16 of the V^T fragments of
-  //                   (VS, VB) = block i
+  //                   (VS, VB) = block i; BAND: one 16-byte read of table entries in every odd gap, three gaps ahead of its FMAs
+  //                   (gaps 13, 15: the first two reads of the NEXT block, whose first key is nbS + NSTEP)
   // No instruction waits on another one of its own gap and consecutive MFMAs never share an accumulator.  The VALU ops
   // are volatile asm: hipcc neither reorders nor packs them (v_pk_*_f32 beside MFMAs is an anti-lever, MI355X_MICROARCH.md)
   // and pads no hazards for them -- the youngest MFMA result they read (S'[0], finished by MFMA 14) is two MFMA issue
   // periods old when chunk 0 of the next block reads it.
-  auto pipe_block = [&]<int KS, int KB, int VS, int VB>(const float ad0, const float ad1) {
+  constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
+  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float adc, const int nbS) {
     static_assert(D == 64, "gap schedule written for D = 64 (16 MFMAs, 16 two-element chunks per block)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
     u32x4 kf[KK];
@@ -372,6 +402,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     u32x4 PBn[2][2];
     u32x2 vh[2][DB][2];  // halves of the transposed fragments
     float X[16][2], Pr[16][2];
+    u32x4 T[2][4];       // BAND: table entries of this block, [query block][8-key group]
+    uint32_t tadr1 = 0;
+    if constexpr (BAND) {
+      T[0][0] = TN[0];
+      T[0][1] = TN[1];
+    }
     static_for<16>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       // ---- MFMA ----
@@ -391,7 +427,19 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         typedef s16x4_t __attribute__((address_space(3))) * p_t;
         vh[t2][db][j2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)(trA[j2][db] + voff + (uint32_t)(16 * t2 * 2 * D))));
       }
-      // ---- VALU: add + pack of chunk g-2 ----
+      if constexpr (BAND) {
+        if constexpr (g == 1) T[0][2] = lds_rd128(tadr0 + 64u);
+        else if constexpr (g == 3) T[0][3] = lds_rd128(tadr0 + 96u);
+        else if constexpr (g == 4) tadr1 = tab_addr(1, nbS);
+        else if constexpr (g == 5) T[1][0] = lds_rd128(tadr1);
+        else if constexpr (g == 7) T[1][1] = lds_rd128(tadr1 + 32u);
+        else if constexpr (g == 9) T[1][2] = lds_rd128(tadr1 + 64u);
+        else if constexpr (g == 11) T[1][3] = lds_rd128(tadr1 + 96u);
+        else if constexpr (g == 12) tadr0 = tab_addr(0, nbS + NSTEP);
+        else if constexpr (g == 13) TN[0] = lds_rd128(tadr0);
+        else if constexpr (g == 15) TN[1] = lds_rd128(tadr0 + 32u);
+      }
+      // ---- VALU: pack of chunk g-2 ----
       {
         constexpr int c = g - 2;  // -2, -1: chunks 14, 15 of the previous block (query block 1, words 2, 3 of PB[1][1])
         constexpr int cq = c < 0 ? 1 : (c >> 3), cr = c < 0 ? 2 * (c + 8) : 2 * (c & 7);
@@ -399,10 +447,6 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         if constexpr (c == -2) { p0 = pc[0]; p1 = pc[1]; }
         else if constexpr (c == -1) { p0 = Pr[15][0]; p1 = Pr[15][1]; }  // (slot 15 of this block's array is free until gap 15)
         else { p0 = Pr[c][0]; p1 = Pr[c][1]; }
-#if !FAT5_F64_LMFMA
-        asm_add(l_run[cq][0], p0);
-        asm_add(l_run[cq][1], p1);
-#endif
         const uint32_t wd = asm_cvt_pk<BF16>(p0, p1);
         if constexpr (c < 0) PB[1][1][(cr & 7) >> 1] = wd;
         else PBn[cq][cr >> 3][(cr & 7) >> 1] = wd;
@@ -418,21 +462,21 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       // ---- VALU: exponent arguments of chunk g ----
       {
         constexpr int cq = g >> 3, cr = 2 * (g & 7);
-        const float ad = cq == 0 ? ad0 : ad1;
-        X[g][0] = asm_fma(S[cq][cr], c2, ad);
-        X[g][1] = asm_fma(S[cq][cr + 1], c2, ad);
+        if constexpr (BAND) {
+          X[g][0] = asm_fma(S[cq][cr], c2, __uint_as_float(T[cq][cr >> 2][cr & 3]));
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]));
+        } else {
+          X[g][0] = asm_fma(S[cq][cr], c2, adc);
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, adc);
+        }
       }
-#if FAT5_F64_LMFMA
       // chunk c is packed in gap c + 2: a group of four words is summed two gaps after its last one (the previous block's last group,
-      // whose words 2, 3 were packed in gaps 0, 1, in gap 3); nothing reads lacc before the next block boundary, a full gap away
+      // whose words 2, 3 were packed in gaps 0, 1, in gap 3); nothing reads lacc before the end of the sweep
       if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
       else if constexpr (g == 7) mfma16_acc<BF16>(lacc[0], sel, PBn[0][0]);
       else if constexpr (g == 11) mfma16_acc<BF16>(lacc[0], sel, PBn[0][1]);
       else if constexpr (g == 14) mfma16_acc<BF16>(lacc[1], sel, PBn[1][0]);
-#endif
-#if FAT5_F64_PIN
-      __builtin_amdgcn_sched_barrier(0);
-#endif
+      __builtin_amdgcn_sched_barrier(0);  // pin the hand-placed MFMA / VALU / LDS interleave of this gap
     });
     // hand over: chunk 14's probabilities and chunk 15's arguments finish inside the next block
     pc[0] = Pr[14][0]; pc[1] = Pr[14][1];
@@ -464,16 +508,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // finish the pending block: its last two chunks, then its product (V fragments are in registers already)
   auto pipe_drain = [&]() {
     const float q0 = fast_exp2(xc[0]), q1 = fast_exp2(xc[1]);
-#if !FAT5_F64_LMFMA
-    l_run[1][0] += pc[0] + q0;
-    l_run[1][1] += pc[1] + q1;
-#endif
     PB[1][1][2] = pack2<BF16>(pc[0], pc[1]);
     PB[1][1][3] = pack2<BF16>(q0, q1);
-#if FAT5_F64_LMFMA
     asm volatile("s_nop 1" : "+v"(PB[1][1]));  // (VALU write -> asm MFMA read: two wait states by hand)
     mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
-#endif
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -482,10 +520,6 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         for (int qb = 0; qb < 2; ++qb) oacc[qb][db] = mfma32<BF16>(VF[t2][db], PB[qb][t2], oacc[qb][db]);
     pipe_reset();
   };
-
-  // keep l (and O) below 2^40 by an exact power of two (optimistic tiles never rescale otherwise).  A pending product was
-  // formed against the old reference point: finish it first (T13 hazard: everything at the old scale is scaled exactly once).
-#if FAT5_F64_LMFMA
   // fold the matrix-pipe row sums into l_run (both key halves hold the full sum and pair_sum adds the halves: half each, exact)
   auto merge_lacc = [&]() {
     asm volatile("s_nop 11" : "+v"(lacc[0]), "+v"(lacc[1]));  // (asm MFMA -> VALU read: no padding is generated; tied so no read moves above it)
@@ -495,62 +529,21 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-#endif
-  auto renorm = [&]() {
-#if FAT5_F64_LMFMA
-    const float lchk = fmaxf(l_run[0][0] + l_run[0][1] + lacc[0][0], l_run[1][0] + l_run[1][1] + lacc[1][0]);
-#else
-    const float lchk = fmaxf(l_run[0][0] + l_run[0][1], l_run[1][0] + l_run[1][1]);
-#endif
-    if (__builtin_expect(__any(!(lchk < 0x1p40f)), 0)) {
-      pipe_drain();
-#if FAT5_F64_LMFMA
-      merge_lacc();
-#endif
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float lc = pair_sum(l_run[qb][0] + l_run[qb][1]);
-        const int e = (lc >= 0x1p40f) ? (int)((__float_as_uint(lc) >> 23) & 0xffu) - 127 : 0;
-        const float alpha = __uint_as_float((uint32_t)(127 - min(e, 126)) << 23);
-        l_run[qb][0] *= alpha;
-        l_run[qb][1] *= alpha;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
-        m_run[qb] += (float)e;
-      }
-    }
-  };
 
-  // pipelined range of tiles [t, te), constant bias `cst`; `slot` = t % 3 on entry and te % 3 on exit.
-  // Tile-iteration t runs blocks 2t, 2t+1: it reads K(t) block 1 and K(t+1) block 0 (scores of blocks 2t+1, 2t+2) and both
-  // blocks of V(t) (fragments for the products of blocks 2t, 2t+1) -- inside the ring protocol's window.
-  auto pipe_range = [&](int& t, const int te, int& slot, const float cst) {
-    if (t >= te) return;  // (slot == 0 here: the callers run exact tiles up to a multiple of NS)
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) m_run[qb] = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];  // rows without a visible key so far
-    // fill: scores of the first block, nothing pending
-    {
-      const uint32_t soff = (uint32_t)(slot * TILE);
-      u32x4 kf[KK];
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) kf[kk] = rd_k(soff, 0, kk);
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) S[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], kk == 0 ? zero16 : S[qb]);
-      pipe_reset();
-    }
-    // steady state: NS tiles (ring slots 0 .. NS-1) per trip, straight-line -- a slot switch inside the loop makes the
-    // register allocator reconcile the bodies at every merge (tuple copies, spilled accumulators)
+  // Pipelined tiles [t, te), t a multiple of NS on entry (ring slot 0).  Tile-iteration t runs the wave's blocks of tile t: it
+  // reads K(t) and K(t+1) (scores one block ahead) and V(t) -- inside the ring protocol's window.  Steady state: NS tiles (ring
+  // slots 0 .. NS-1) per trip, straight-line -- a slot switch inside the loop makes the register allocator reconcile the bodies at
+  // every merge (tuple copies, spilled accumulators).
+  auto pipe_run = [&]<bool BAND>(int& t, const int te, int& slot, const float cst) {
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
-      renorm();
-      const float ad0 = cst - m_run[0], ad1 = cst - m_run[1];
       begin_iter(tt, SL);
-      pipe_block.template operator()<SL, 1, SL, 0>(ad0, ad1);
-      pipe_block.template operator()<S1, 0, SL, 1>(ad0, ad1);
+      if constexpr (KSPLIT) {
+        pipe_block.template operator()<S1, 0, SL, 0, BAND>(cst, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
+      } else {
+        pipe_block.template operator()<SL, 1, SL, 0, BAND>(cst, tt * BN);
+        pipe_block.template operator()<S1, 0, SL, 1, BAND>(cst, tt * BN + 32);
+      }
       end_iter(tt);
     };
     for (; t + NS <= te; t += NS) {
@@ -564,77 +557,147 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         slot = sl + 1;
       }
     });
-    pipe_drain();
-#if FAT5_F64_LMFMA
-    merge_lacc();
-#endif
   };
-  auto exact_range = [&]<int MODE>(int& t, const int te, int& slot, const float cst) {
+  auto exact_range = [&]<int MODE, bool NOMAX>(int& t, const int te, int& slot, const float cst) {
     for (; t < te; ++t) {
       begin_iter(t, slot);
-      tile_exact.template operator()<MODE>(t, slot, cst);
+      tile_exact.template operator()<MODE, NOMAX>(t, slot, cst);
       slot = slot == NS - 1 ? 0 : slot + 1;
       end_iter(t);
     }
   };
 
-  // Tile classes (workgroup-uniform):  [0, ta) FAST cst_a | [ta, tb0) generic | [tb0, tb1) FAST cst_b | [tb1, nt) generic
-  int ta = 0, tb0 = 0, tb1 = 0;
+  // Tile classes (workgroup-uniform).  t_full: tiles all of whose keys are visible to every row of the workgroup.
+  //   exact pass:       [0, ta) constant bias cst_a | [ta, tb0) generic | [tb0, tb1) constant cst_b | [tb1, nt) generic
+  //   optimistic sweep: [0, tbA) constant | [tbA, tbB) band (rounded outwards to multiples of NS tiles: a band-mode tile reads
+  //                     the padded table whatever its position) | [tbB, t_full) constant | [t_full, nt) masked, unpipelined
+  int t_full = N / BN;
+  if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));
+  t_full = min(t_full, nt);
+  int ta = 0, tb0 = 0, tb1 = 0, tbA = 0, tbB = 0;
   float cst_a = 0.f, cst_b = 0.f;
-  if (fold_ok) {
-    int t_full = N / BN;
-    if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));
-    t_full = min(t_full, nt);
-    if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-      const int lim_a = m0 - a.R - (BN - 1);
-      ta = lim_a >= 0 ? min(t_full, lim_a / BN + 1) : 0;
-      const int lo = m0 + BM - 1 + a.R;
-      tb0 = min(t_full, max(ta, (lo + BN - 1) / BN));
-      tb1 = t_full;
-      cst_a = cst_neg;
-      cst_b = cst_pos;
-    } else {
-      ta = t_full;
-    }
-    if (tb1 < tb0) tb0 = tb1 = ta;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+    const int lim_a = m0 - a.R - (BN - 1);
+    ta = lim_a >= 0 ? min(t_full, lim_a / BN + 1) : 0;
+    const int lo = m0 + BM - 1 + a.R;
+    tb0 = min(t_full, max(ta, (lo + BN - 1) / BN));
+    tb1 = t_full;
+    cst_a = cst_neg;
+    cst_b = cst_pos;
+    tbA = ta / NS * NS;
+    tbB = min(t_full, (tb0 + NS - 1) / NS * NS);
+  } else {
+    ta = t_full;
+    tbA = tbB = t_full;  // (no band: one constant range, bias 0)
   }
+  if (tb1 < tb0) tb0 = tb1 = ta;
 
   for (int pass = 0;; ++pass) {
-    const bool opt = OPT && pass == 0;
+    const bool nomax = OPT && pass == 0;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
-      m_run[qb] = -INFINITY;
+      m_run[qb] = nomax ? 0.f : -INFINITY;
       l_run[qb][0] = l_run[qb][1] = 0.f;
     }
     if (pass > 0) {
-      __syncthreads();  // every wave is done with the rings
+      __syncthreads();  // every wave is done with the rings (and, KSPLIT, with the merge area inside them)
       stage_first();
       wait_dma_all();
       __syncthreads();
     }
     int t = 0, slot = 0;
-    // range A: exact baseline (two tiles), then pipelined optimistic
-    exact_range.template operator()<1>(t, opt ? min(ta, NS) : ta, slot, cst_a);
     if constexpr (OPT) {
-      if (opt) pipe_range(t, ta, slot, cst_a);
+      if (nomax) {
+        if (t_full > 0) {
+          // fill: scores of the wave's first block, nothing pending
+          {
+            u32x4 kf[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) kf[kk] = rd_k(0u, 0, kk);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+              for (int qb = 0; qb < 2; ++qb) S[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], kk == 0 ? zero16 : S[qb]);
+            pipe_reset();
+          }
+          if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+            pipe_run.template operator()<false>(t, tbA, slot, cst_a);
+            if (t < tbB) {  // entering the band: the first block's table entries for query block 0 (later blocks prefetch their successor's)
+              tadr0 = tab_addr(0, t * BN + 32 * kh);
+              TN[0] = lds_rd128(tadr0);
+              TN[1] = lds_rd128(tadr0 + 32u);
+            }
+            pipe_run.template operator()<true>(t, tbB, slot, 0.f);
+            pipe_run.template operator()<false>(t, t_full, slot, cst_b);
+          } else {
+            pipe_run.template operator()<false>(t, t_full, slot, 0.f);
+          }
+          pipe_drain();
+          merge_lacc();
+        }
+        exact_range.template operator()<0, true>(t, nt, slot, 0.f);
+      }
     }
-    exact_range.template operator()<0>(t, min(max(tb0, ta), nt), slot, 0.f);
-    // range B
-    exact_range.template operator()<1>(t, opt ? min(tb1, max(NS, (t + NS - 1) / NS * NS)) : tb1, slot, cst_b);
-    if constexpr (OPT) {
-      if (opt) pipe_range(t, tb1, slot, cst_b);
+    if (!nomax) {
+      if (fold_ok) {
+        exact_range.template operator()<1, false>(t, ta, slot, cst_a);
+        exact_range.template operator()<0, false>(t, min(max(tb0, ta), nt), slot, 0.f);
+        exact_range.template operator()<1, false>(t, tb1, slot, cst_b);
+      }
+      exact_range.template operator()<0, false>(t, nt, slot, 0.f);
     }
-    exact_range.template operator()<0>(t, nt, slot, 0.f);
+
+    if constexpr (KSPLIT) {
+      // ---- merge the two key halves of every 64-row group through LDS: wave kh keeps query block kh, hands the other one over ----
+      __syncthreads();  // the rings are free
+      char* mine = smem + w * Cfg::MERGE;
+      const char* theirs = smem + (w ^ 1) * Cfg::MERGE;
+      auto put = [&]<int QB>() {
+#pragma unroll
+        for (int i = 0; i < DB * 4; ++i) {
+          const f32x4 v4 = {oacc[QB][i >> 2][4 * (i & 3)], oacc[QB][i >> 2][4 * (i & 3) + 1], oacc[QB][i >> 2][4 * (i & 3) + 2], oacc[QB][i >> 2][4 * (i & 3) + 3]};
+          *reinterpret_cast<f32x4*>(mine + (i * 64 + l) * 16) = v4;
+        }
+        *reinterpret_cast<float2*>(mine + DB * 4 * 64 * 16 + l * 8) = make_float2(m_run[QB], l_run[QB][0] + l_run[QB][1]);
+      };
+      auto get = [&]<int QB>() {
+        const float2 ml = *reinterpret_cast<const float2*>(theirs + DB * 4 * 64 * 16 + l * 8);
+        const float m_new = fmaxf(m_run[QB], ml.x);
+        const float mref = (m_new == -INFINITY) ? 0.f : m_new;
+        const float sa = fast_exp2(m_run[QB] - mref), sb = fast_exp2(ml.x - mref);
+#pragma unroll
+        for (int i = 0; i < DB * 4; ++i) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(theirs + (i * 64 + l) * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) oacc[QB][i >> 2][4 * (i & 3) + j] = oacc[QB][i >> 2][4 * (i & 3) + j] * sa + v4[j] * sb;
+        }
+        l_run[QB][0] = (l_run[QB][0] + l_run[QB][1]) * sa + ml.y * sb;
+        l_run[QB][1] = 0.f;
+        m_run[QB] = m_new;
+      };
+      if (kh == 0) put.template operator()<1>(); else put.template operator()<0>();
+      __syncthreads();
+      if (kh == 0) get.template operator()<0>(); else get.template operator()<1>();
+    }
 
     if constexpr (!OPT) {
       break;
     } else {
-      if (!opt) break;
-      if (!(l_run[0][0] + l_run[0][1] < 0x1p120f) || !(l_run[1][0] + l_run[1][1] < 0x1p120f)) *sFlag = 1;
+      if (!nomax) break;
+      // the sweep's reference point was 0 for every row: a row sum outside [2^-40, 2^100) (overflow / flushed terms) -> exact pass
+      bool bad = false;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if (KSPLIT && qb != kh) continue;
+        const float lt = pair_sum(l_run[qb][0] + l_run[qb][1]);
+        const bool visible = !(a.causal && qrow0 + 32 * qb + lq + P < 0);  // (a row without any visible key has l = 0 exactly)
+        bad = bad || !(lt < 0x1p100f) || (visible && lt < 0x1p-40f);
+      }
+      if (bad) *sFlag = 1;
       __syncthreads();
       if (*sFlag == 0) break;
     }
@@ -643,6 +706,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // ---- epilogue: o = acc / l, L = m + ln(l) ----
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
+    if (KSPLIT && qb != kh) continue;
     const int qrow = qrow0 + 32 * qb + lq;
     const float l_tot = pair_sum(l_run[qb][0] + l_run[qb][1]);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
@@ -662,15 +726,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   }
 }
 
-template <int D, bool BF16, int BIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAT5_F64_MINW)))
-void attn_fwd64_kernel(const AttnArgs a, const int n_items) {
-  // gridDim.x == n_items (one workgroup per item, the default) or a smaller multiple of 8 (persistent workgroups walking the
-  // items with stride gridDim.x; an item keeps the XCD = index % 8 that decode_block() gave its (b, h)).
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    attn_fwd64_body<D, BF16, BIAS>(a, item);
-    __syncthreads();  // this item's last LDS readers (table, flag) are done before the next item overwrites them
-  }
+template <int D, bool BF16, int BIAS, bool KSPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  // (two waves per SIMD: <= 256 registers)
+void attn_fwd64_kernel(const AttnArgs a) {
+  attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, blockIdx.x);
 }
 
 }  // namespace fat5

@@ -11,24 +11,29 @@
 
 namespace fat5 {
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool KSPLIT>
 static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = Fwd64Cfg<D>::smem(a.R, BIAS);
-  auto kern = attn_fwd64_kernel<D, BF16, BIAS>;
+  const size_t smem = Fwd64Cfg<D, KSPLIT>::smem(a.R, BIAS);
+  auto kern = attn_fwd64_kernel<D, BF16, BIAS, KSPLIT>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
   // One workgroup per item (persistent workgroups walking the items were measured no faster at (4,12,8192,64): 1536 equal items
   // over 512 slots balance by themselves).
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 
-hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+template <bool KSPLIT>
+static hipError_t launch64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
   if (bias == FAT5_BIAS_RPE1D)
-    return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
-  return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
+    return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s);
+  return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE, KSPLIT>(a, grid, s);
+}
+// nw == 2: the key-split variant (two waves per 64 query rows, 128-row workgroups); otherwise 256-row workgroups
+hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  return nw == 2 ? launch64_bias<true>(a, bf16, bias, grid, s) : launch64_bias<false>(a, bf16, bias, grid, s);
 }
 
 size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D>::smem(R, bias); }

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -32,6 +33,10 @@ int hip_fail(hipError_t e, const char* what) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the 64-rows-per-wave forward takes over from this many waves of (64 rows x all keys) on (measured, tools/attn_time.py, (4,12,S,64):
+// S = 1024 -- 768 waves -- 19.7 / 23.3 us without / with the T5 bias against 22.4 / 26.1 us of the 32-row body; S = 512 stays there)
+constexpr long kFwd64MinWaves = 768;
 
 // kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
 inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
@@ -157,14 +162,21 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   // long sequences: 64 query rows per wave, software-pipelined tile loop (attn_fwd64.h) once its 256-row workgroups fill
   // the chip (fat5_attn_params.variant: FAT5_V_FWD64_OFF disables, FAT5_V_FWD64_ON forces wherever the body applies)
   const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
-  const long ctas256 = bh * ((p->M + 255) / 256);
+  const long waves64 = bh * ((p->M + 63) / 64);  // waves of 64 query rows x all keys
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
-      (f64_env == 1 || (p->dtype == FAT5_BF16 && ctas256 >= 512 &&
+      (f64_env == 1 || (p->dtype == FAT5_BF16 && waves64 >= kFwd64MinWaves &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     fn = launch_fwd64_d64;
-    nw = 4;
-    a.n_mblk = (p->M + 255) / 256;
+    // Key-split variant (two waves per 64 rows, 128-row workgroups): where the 64-row waves fill between one and two slots of the
+    // chip's 1024 SIMDs -- half the SIMDs then carry two full-length waves and the others one.  Measured at (4,12,2048,64) (tools/
+    // attn_time.py): 60.7 vs 63.8 us with the T5 bias (a 128-row workgroup also crosses fewer band tiles), 58.4 vs 59.1 without;
+    // slower everywhere else (S = 1024: 22.0 vs 19.7 us, 4096: 207 vs 190, 8192: 794 vs 724).  The hardware packs the workgroups of the
+    // last, half-empty round two to a CU, so the finer grain buys less than a per-SIMD issue model predicts.
+    const int ks_env = vsel(p->variant, FAT5_V_FWD64_KSPLIT_ON, FAT5_V_FWD64_KSPLIT_OFF);
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && waves64 > 1024 && waves64 < 2048);
+    nw = ksplit ? 2 : 4;
+    a.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
   }
   const long grid = n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");

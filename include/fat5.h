@@ -48,7 +48,8 @@ enum fat5_variant {
   FAT5_V_Q64_ON = 16, FAT5_V_Q64_OFF = 32,     /* backward dQ: 64-rows-per-wave pipelined body */
   FAT5_V_DBIAS_STAGED = 64, FAT5_V_DBIAS_INKERNEL = 128, /* dense (1,H,M,N) dbias: staged dS + reduction / batch-inner kernel */
   FAT5_V_NO_FUSE = 256,                         /* backward: never the single side-by-side dQ | dK/dV launch */
-  FAT5_V_NO_SPLIT = 512                         /* forward: never the two-waves-per-32-rows short-sequence body */
+  FAT5_V_NO_SPLIT = 512,                        /* forward: never the two-waves-per-32-rows short-sequence body */
+  FAT5_V_FWD64_KSPLIT_ON = 1024, FAT5_V_FWD64_KSPLIT_OFF = 2048 /* 64-row forward: key-split (two waves per 64 rows) variant always / never */
 };
 
 enum fat5_bias_mode {

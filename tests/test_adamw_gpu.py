@@ -50,7 +50,14 @@ def test_adamw_scale_reference_fixture(name):
         assert all(torch.isfinite(t.float()).all() for t in (p, st["exp_avg"], st["exp_avg_sq"]))
         assert ulp_err(st["exp_avg"], get("m", i)) <= 1.0, (name, i, "m", ulp_err(st["exp_avg"], get("m", i)))
         assert ulp_err(st["exp_avg_sq"], get("v", i)) <= 1.0 or (st["exp_avg_sq"].float().cpu() - get("v", i).float()).abs().max().item() <= 2 * TINY[st["exp_avg_sq"].dtype], (name, i, "v")
-        assert ulp_err(p.detach(), get("p", i)) <= 2.0, (name, i, "p", ulp_err(p.detach(), get("p", i)))
+        if st["exp_avg"].dtype == p.dtype:
+            assert ulp_err(p.detach(), get("p", i)) <= 2.0, (name, i, "p", ulp_err(p.detach(), get("p", i)))
+        else:
+            # 16-bit moments beside wider parameters: the one-ulp (of the STATE dtype) freedom of m and v above moves each update
+            # by that relative amount -- far more than an ulp of an fp32 parameter
+            moved = (get("p", i).float() - get("p0", i).float()).abs().max().item()
+            perr = (p.detach().float().cpu() - get("p", i).float()).abs().max().item()
+            assert perr <= 3 * ULP[st["exp_avg"].dtype] * moved + 2 * ULP[dtype] * get("p", i).float().abs().max().item(), (name, i, "p", perr, moved)
         if kahan:
             got = p.detach().float().cpu() + st["kahan_comp"].float().cpu()
             want = get("p", i).float() + get("k", i).float()

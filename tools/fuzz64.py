@@ -4,9 +4,10 @@ usage: [FUZZ_FORCE64=0] python tools/fuzz64.py [n_cases] [seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-if os.environ.get("FUZZ_FORCE64", "1") != "0":  # FUZZ_FORCE64=0: the default dispatch (32-row bodies at these sizes)
-    os.environ["FAT5_FWD64"] = "1"; os.environ["FAT5_BWD64"] = "1"; os.environ["FAT5_BWDQ64"] = "1"
 import torch
+from flasht5_amd import _lib
+if os.environ.get("FUZZ_FORCE64", "1") != "0":  # FUZZ_FORCE64=0: the default dispatch (32-row bodies at these sizes)
+    _lib.set_variant(_lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON)
 import oracle
 from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
 from test_attention_gpu import bound, gbound, _rpe_case

@@ -36,8 +36,8 @@ for S, D, H in ((512, 64, 12), (2048, 64, 12), (777, 128, 3), (1024, 32, 6)):
 for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (8192, 8192, max(3, reps // 30), "-1")):
     for mode in ("none", "rpe"):
         for causal in (False, True):
-            for name in ("FAT5_FWD64", "FAT5_BWD64", "FAT5_BWDQ64"):
-                os.environ[name] = force
+            from flasht5_amd import _lib
+            _lib.set_variant((_lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON) if force == "1" else 0)
             q, k, v, _, do = make_inputs(4, 12, M, S, 64, torch.bfloat16, None, seed=S + 7, strided=True)
             kw = {}
             table = (torch.randn(32, 12, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
