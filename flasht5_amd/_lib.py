@@ -48,7 +48,7 @@ EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
-    "fat5_ce_fwd", "fat5_ce_bwd",
+    "fat5_ce_fwd", "fat5_ce_bwd", "fat5_linear_fused",
     "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
 )
 
@@ -93,6 +93,8 @@ def load():
     lib.fat5_add_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.fat5_ce_fwd.restype = ctypes.c_int
     lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
+    lib.fat5_linear_fused.restype = ctypes.c_int
+    lib.fat5_linear_fused.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp]
     lib.fat5_ce_bwd.restype = ctypes.c_int
     lib.fat5_ce_bwd.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, f32, f32, i64, i32, vp]
     lib.fat5_adamw_scale_step.restype = ctypes.c_int

@@ -1,0 +1,168 @@
+// Linear layers with the T5 pre-norm / residual fused in, for gfx950 ("RMSNorm -> QKV projection prologue,
+// output-projection + residual epilogue", reference src/model/modeling_flash_t5.py:304-318 (layer_norm -> Wq / Wk / Wv),
+// :159-164 (h + wo(act(layer_norm(h)))), :95-98 (FlashT5LayerNorm)).
+//
+//   out[m][n] = rowscale[m] * sum_k a[m][k] * w[n][k]   (+ res[m][n])
+//
+// a: (M, K) activations, w: (N, K) = an nn.Linear weight as stored, out / res: (M, N); 16-bit dtype, fp32 accumulation.
+//  * NORM: rowscale[m] = rsqrt(mean_k a[m][k]^2 + eps), formed INSIDE the kernel from the A tiles on their way through LDS --
+//    with w = W * diag(g) (the norm weight folded into the projection by the caller) this is Linear(RMSNorm(a; g)):
+//    RMSNorm(a)[m][k] = a[m][k] * rstd[m] * g[k], so (RMSNorm(a) W^T)[m][n] = rstd[m] * sum_k a[m][k] (g[k] W[n][k]).
+//    The normalised activation is never written (forward) nor kept for the backward.
+//  * RES: the residual add of the sub-layer as the epilogue: out = res + round(a w^T), rounded twice like the two separate ops.
+//
+// One workgroup = 4 waves = a 128 x 128 output tile, each wave a 64 x 64 quadrant (four 32x32x16 MFMA accumulators); K in steps
+// of 64: A and W tiles travel global -> LDS by DMA (double buffered, counted vmcnt) into the XOR-swizzled row-major images of
+// attn_common.h; both operands are contracted along their rows, so every fragment is a ds_read_b128.  The accumulators hold
+// the TRANSPOSED tile (lane = output row m, registers = 16 output columns): the row scale is one scalar per lane, and the
+// epilogue stages the tile through LDS to leave as whole 256-byte rows.
+#pragma once
+#include "attn_common.h"
+#include "attn_fwd64.h"  // dma16_asm, wait_dma_all
+
+namespace fat5 {
+
+struct LinCfg {
+  static constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+  static constexpr int IMG = rm_bytes<BK, BM>();      // one 128-row x 64-element image: 16 KiB
+  static constexpr int STAGE = 2 * IMG;               // A + W
+  static constexpr int CROW = 2 * BN + 8;             // staged output row: 256 bytes + 8 (bank spread for the per-lane row writes)
+  static constexpr int RSTD = 2 * STAGE;              // 128 floats behind the two stages
+  static constexpr int SMEM = 2 * STAGE + BM * 4;
+  static_assert(BM * CROW <= 2 * STAGE, "output staging reuses the operand stages");
+};
+
+template <bool BF16>
+FAT5_DEV void dot2_acc(float& acc, uint32_t a) {
+  if constexpr (BF16) asm("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(acc) : "v"(a));
+  else asm("v_dot2c_f32_f16 %0, %1, %1" : "+v"(acc) : "v"(a));
+}
+
+struct LinArgs {
+  const uint16_t *a, *w, *res;
+  uint16_t* out;
+  float* rstd_out;
+  int64_t lda, ldw, ldr, ldo;
+  int M, N, K;
+  float eps;
+};
+
+template <bool BF16, bool NORM, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void linear_fused_kernel(const LinArgs p) {
+  using Cfg = LinCfg;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT, IMG = Cfg::IMG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sR = reinterpret_cast<float*>(smem + Cfg::RSTD);
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int mt = blockIdx.x / tiles_n, nt = blockIdx.x - mt * tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk = p.K / BK;
+
+  using Dma = DmaStage<BK, BM, NT>;
+  static_assert(Dma::NV == 1 && Dma::PER == 4, "four 1-KiB pieces per wave and tile");
+  Dma ast, wst;
+  ast.init(p.lda, tid);
+  wst.init(p.ldw, tid);
+  const __amdgpu_buffer_rsrc_t ars = make_rows_rsrc(p.a + (int64_t)m0 * p.lda, p.lda, min(BM, p.M - m0), p.K);
+  const __amdgpu_buffer_rsrc_t wrs = make_rows_rsrc(p.w + (int64_t)n0 * p.ldw, p.ldw, min(BN, p.N - n0), p.K);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)w * 1024u);
+  auto dma_stage = [&](int kt, int buf) {
+    const uint32_t koff = (uint32_t)(kt * BK * 2);
+#pragma unroll
+    for (int i = 0; i < Dma::PER; ++i) dma16_asm(ars, wave_lds + (uint32_t)(buf * Cfg::STAGE + NT * 16 * i), ast.voff[0], koff + ast.piece_step * i);
+#pragma unroll
+    for (int i = 0; i < Dma::PER; ++i) dma16_asm(wrs, wave_lds + (uint32_t)(buf * Cfg::STAGE + IMG + NT * 16 * i), wst.voff[0], koff + wst.piece_step * i);
+  };
+
+  FragAddr<BK> fa;
+  fa.init(l);
+  f32x16 acc[2][2];  // [nb][mb]: rows = 32 output columns n (C layout), lane column = output row m
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+  float ss = 0.f;  // NORM: this thread's share of sum_k a[row][k]^2, row = tid / 2, 32 of every 64 elements
+  const int srow = tid >> 1, shalf = tid & 1;
+
+  dma_stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      dma_stage(kt + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER) : "memory");  // everything but the stage just requested
+    } else {
+      wait_dma_all();
+    }
+    __syncthreads();
+    const char* imgA = smem + buf * Cfg::STAGE;
+    const char* imgW = imgA + IMG;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      u32x4 af[2], wf[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) af[mb] = ld_rm<BK>(imgA, fa, 2 * wm + mb, kk);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) wf[nb] = ld_rm<BK>(imgW, fa, 2 * wn + nb, kk);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mfma32<BF16>(wf[nb], af[mb], acc[nb][mb]);
+    }
+    if constexpr (NORM) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(imgA + rm_off<BK>(srow, 4 * shalf + c));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot2_acc<BF16>(ss, v[j]);
+      }
+    }
+    __syncthreads();  // this stage is free for the request of the next iteration
+  }
+  if constexpr (NORM) {
+    ss += __shfl_xor(ss, 1, 64);
+    const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+    if (shalf == 0) {
+      sR[srow] = rstd;
+      if (nt == 0 && p.rstd_out && m0 + srow < p.M) p.rstd_out[m0 + srow] = rstd;
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: scale, round, stage the 128 x 128 tile in LDS as rows of m, leave as whole rows (+ residual) ----
+  char* sC = smem;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int ml = 64 * wm + 32 * mb + lq;
+    const float sc = NORM ? sR[ml] : 1.f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 wv;
+        wv[0] = pack2<BF16>(acc[nb][mb][4 * g + 0] * sc, acc[nb][mb][4 * g + 1] * sc);
+        wv[1] = pack2<BF16>(acc[nb][mb][4 * g + 2] * sc, acc[nb][mb][4 * g + 3] * sc);
+        *reinterpret_cast<u32x2*>(sC + ml * Cfg::CROW + (64 * wn + 32 * nb + 8 * g + 4 * hi) * 2) = wv;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BM * (BN / 4) / NT; ++i) {
+    const int id = tid + NT * i, row = id >> 5, c4 = id & 31;  // 32 eight-byte pieces per row
+    const int m = m0 + row, n = n0 + 4 * c4;
+    if (m < p.M && n < p.N) {
+      u32x2 v = *reinterpret_cast<const u32x2*>(sC + row * Cfg::CROW + c4 * 8);
+      if constexpr (RES) {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(p.res + (int64_t)m * p.ldr + n);
+        v[0] = pack2<BF16>(cvt_lo<BF16>(v[0]) + cvt_lo<BF16>(r[0]), cvt_hi<BF16>(v[0]) + cvt_hi<BF16>(r[0]));
+        v[1] = pack2<BF16>(cvt_lo<BF16>(v[1]) + cvt_lo<BF16>(r[1]), cvt_hi<BF16>(v[1]) + cvt_hi<BF16>(r[1]));
+      }
+      *reinterpret_cast<u32x2*>(p.out + (int64_t)m * p.ldo + n) = v;
+    }
+  }
+}
+
+}  // namespace fat5

