@@ -218,6 +218,115 @@ def event_time(fn, iters, warmup=3, prewarm_s=0.2):
     return s.elapsed_time(e) / iters
 
 
+def event_stats(fn, iters, reps=5):
+    """min / median / max over `reps` event-timed batches of `iters` calls (ms per call): the spread a single average hides
+    (the clock under these kernels is power-limited and moves by several per cent between batches)"""
+    ts = sorted(event_time(fn, iters, warmup=2, prewarm_s=0.05 if i else 0.2) for i in range(reps))
+    return {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1]}
+
+
+def seq_rooflines(S, mode, plan, iters):
+    """`roofline` block of one sequence length: per stage (fwd, dq, dk/dv) min / median / max launch time, algorithmic flops,
+    fraction of the dense bf16 MFMA peak at the median, HBM traffic per launch from the PMC passes (profiles/pmc_traffic.json);
+    `dominant` = the stage with the longest median launch"""
+    f = fwd_flops(S)
+    plan.forward()
+    plan.backward()
+    stages = {"attn_fwd": (plan.forward, f), "attn_bwd_dq": (lambda: plan.backward(1), 0.5 * f), "attn_bwd_dkdv": (lambda: plan.backward(2), 2.0 * f)}
+    out = {}
+    for name, (fn, fl) in stages.items():
+        st = event_stats(fn, iters, reps=3)
+        out[name] = {"us_min": round(st["min"] * 1e3, 2), "us_median": round(st["median"] * 1e3, 2), "us_max": round(st["max"] * 1e3, 2),
+                     "alg_flops": fl, "achieved": round(fl / st["median"] / 1e9, 1), "frac": round(fl / st["median"] / 1e9 / PEAK_BF16_TFLOPS, 4),
+                     "traffic": load_traffic(name, S, mode)}
+    dom = max(out, key=lambda n: out[n]["us_median"])
+    return {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "dominant": dom, "achieved": out[dom]["achieved"],
+            "frac": out[dom]["frac"], "avg_launch_us": out[dom]["us_median"], "traffic": out[dom]["traffic"], "stages": out}
+
+
+def n3_bench(device):
+    """SURVEY 8(f) n3's fusions, kernel time by graph replay (bf16): pre-norm inside the projection GEMM against norm kernel +
+    library GEMM; residual add as GEMM epilogue; chunked lm_head -> loss against the full-logits form (time and peak memory)"""
+    from flasht5_amd import rmsnorm_linear, linear_residual, fast_rms_layernorm, lm_head_cross_entropy, cross_entropy_loss
+    out = {}
+    M, K = 4096, 768
+    x = torch.randn(M, K, device=device).bfloat16()
+    g = torch.ones(K, device=device).bfloat16()
+    with torch.no_grad():
+        for N, tag in ((2304, "qkv"), (4096, "wi01")):
+            W = (torch.randn(N, K, device=device) / K ** 0.5).bfloat16()
+            tf = graph_time(lambda: rmsnorm_linear(x, g, W, 1e-6))
+            ts = graph_time(lambda: torch.nn.functional.linear(fast_rms_layernorm(x, g, 1e-6), W))
+            out[f"rmsnorm_linear_{tag}_{M}x{N}x{K}"] = {"fused_us": round(tf * 1e6, 2), "separate_us": round(ts * 1e6, 2),
+                                                       "fused_tflops": round(2.0 * M * N * K / tf / 1e12, 1)}
+        W = (torch.randn(K, K, device=device) / K ** 0.5).bfloat16()
+        r = torch.randn(M, K, device=device).bfloat16()
+        tf = graph_time(lambda: linear_residual(x, W, r))
+        ts = graph_time(lambda: r + torch.nn.functional.linear(x, W))
+        out[f"linear_residual_{M}x{K}x{K}"] = {"fused_us": round(tf * 1e6, 2), "separate_us": round(ts * 1e6, 2)}
+    # the config-5 step (FAT5-base, B = 4, 1024 / 512 tokens, one GPU) forward + backward in its three formulations: wall time (the eager
+    # step is host-bound), kernel launches and the stand-alone RMSNorm launches among them, per step
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
+    from torch.profiler import profile, ProfilerActivity
+    steps = {}
+    for flag in (None, "fuse_add_norm", "fuse_norm_linear"):
+        cfg = FAT5Config()
+        if flag:
+            setattr(cfg, flag, True)
+        torch.manual_seed(0)
+        m = FAT5ForConditionalGeneration(cfg).to(device).bfloat16()
+        ids = torch.randint(0, cfg.vocab_size, (4, 1024), device=device)
+        labels = torch.randint(0, cfg.vocab_size, (4, 512), device=device)
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            m(ids, labels).backward()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 8
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        ev = prof.key_averages()
+        steps[flag or "separate_ops"] = {"wall_ms": round(wall * 1e3, 2), "kernel_ms": round(sum(e.device_time_total for e in ev) / 1e3, 2),
+                                         "launches": int(sum(e.count for e in ev)),
+                                         "rmsnorm_launches": int(sum(e.count for e in ev if "rmsnorm" in e.key and "unit_bwd" not in e.key)),
+                                         "tokens_per_s": round(4 * 1536 / wall, 0)}
+        del m
+        torch.cuda.empty_cache()
+    out["cfg5_step_fwd_bwd"] = steps
+    # lm_head -> loss at the reference's CE benchmark size (16384 rows, BASELINE.md 1b), V = 32768
+    rows, V = 16384, 32768
+    hid = torch.randn(rows, K, device=device).bfloat16().requires_grad_()
+    Wl = (torch.randn(V, K, device=device) / K ** 0.5).bfloat16().requires_grad_()
+    lab = torch.randint(0, V, (rows,), device=device)
+
+    def chunked():
+        l, _ = lm_head_cross_entropy(hid, Wl, lab, label_smoothing=0.1, lse_square_scale=1e-4)
+        return torch.autograd.grad(l.mean(), (hid, Wl))
+
+    def full():
+        l, _ = cross_entropy_loss(hid @ Wl.t(), lab, label_smoothing=0.1, lse_square_scale=1e-4, inplace_backward=True)
+        return torch.autograd.grad(l.mean(), (hid, Wl))
+
+    res = {}
+    for name, fn in (("chunked", chunked), ("full_logits", full)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t = event_time(fn, 5, warmup=1, prewarm_s=0.05)
+        res[name] = {"ms": round(t, 3), "peak_extra_MB": round((torch.cuda.max_memory_allocated() - base) / 2 ** 20, 1)}
+    out[f"lm_head_ce_{rows}x{V}"] = res
+    return out
+
+
 def kernel_breakdown(plan, S, iters):
     """per-kernel average duration (us) with HIP events around each C-ABI stage"""
     t_fwd = event_time(plan.forward, iters) * 1e3
@@ -259,10 +368,24 @@ def _cpu_attn_time(b, h, S, reps):
     return best
 
 
+def _cpu_attn_lowp(b, h, S, dtype):
+    """the reference's eager path as its model runs it: low-precision matmuls, fp32 softmax (attn_ref upcast=False)"""
+    import oracle
+    q, k, v = (torch.randn(b, h, S, D).to(dtype).requires_grad_() for _ in range(3))
+    bias = torch.randn(1, h, S, S).to(dtype).requires_grad_()
+    do = torch.randn(b, h, S, D).to(dtype)
+    t0 = time.perf_counter()
+    o = oracle.attn_ref(q, k, v, bias, 0.125, causal=False, upcast=False)
+    t1 = time.perf_counter()
+    torch.autograd.grad(o, (q, k, v, bias), do)
+    return t1 - t0, time.perf_counter() - t1
+
+
 def cpu_baseline(S=512, reps=5):
-    """The reference's eager attention (oracle restatement of src/utils/attn_ref.py) forward+backward on the host cores,
-    fp32: the full cfg2 batch (the benched workload), plus -- SURVEY 8(d) -- a (1,2,8192,64) slice of cfg3 scaled x24
-    (the full cfg3 eager pass needs ~25 GB and minutes).  A bounded sample: a few seconds of CPU work in total."""
+    """The reference's eager attention (oracle restatement of src/utils/attn_ref.py) forward+backward on the host cores:
+    the full cfg2 batch in fp32 (the benched workload; `value`) and -- the other samples SURVEY 8(d) lists -- cfg1
+    (2,8,128,64) fp32 forward, cfg2 in bf16, the full (4,12,2048,64) batch in fp32, and a (1,2,8192,64) slice of cfg3 scaled
+    x24 (the full cfg3 eager pass needs ~25 GB and minutes).  A bounded sample: ~10-30 s of CPU work in total."""
     torch.manual_seed(0)
     best = _cpu_attn_time(B, H, S, reps)
     out = {"value": 3.5 * fwd_flops(S) / best / 1e12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
@@ -270,12 +393,31 @@ def cpu_baseline(S=512, reps=5):
            "sample": f"eager fp32 attention fwd+bwd (oracle.attn_ref + autograd), full (4,12,{S},64) batch with dense "
                      f"(1,12,{S},{S}) bias, min of {reps} runs, {best*1e3:.1f} ms"}
     try:
+        import oracle
+        q1, k1, v1 = (torch.randn(2, 8, 128, D) for _ in range(3))
+        b1 = torch.randn(1, 8, 128, 128)
+        t_c1 = min(_t for _t in (_timeit(lambda: oracle.attn_ref(q1, k1, v1, b1, 0.125, causal=False, upcast=True)) for _ in range(5)))
+        out["cfg1_fwd_fp32"] = {"value": 4.0 * 2 * 8 * 128 * 128 * D / t_c1 / 1e12, "unit": "TFLOP/s", "sample": f"(2,8,128,64) forward, min of 5, {t_c1*1e3:.2f} ms"}
+        tf_b, tb_b = _cpu_attn_lowp(B, H, S, torch.bfloat16)
+        out["cfg2_bf16"] = {"value": 3.5 * fwd_flops(S) / (tf_b + tb_b) / 1e12, "unit": "TFLOP/s",
+                            "sample": f"(4,12,{S},64) bf16 matmuls + fp32 softmax (attn_ref upcast=False), one run, fwd {tf_b*1e3:.0f} ms + bwd {tb_b*1e3:.0f} ms"}
+        t2k = _cpu_attn_time(B, H, 2048, 1)
+        out["s2048_fp32"] = {"value": 3.5 * fwd_flops(2048) / t2k / 1e12, "unit": "TFLOP/s", "sample": f"full (4,12,2048,64) fp32 fwd+bwd, one run, {t2k:.2f} s"}
+    except Exception as e:  # noqa: BLE001  (host memory)
+        out["extra_samples_error"] = str(e)[:100]
+    try:
         t3 = _cpu_attn_time(1, 2, 8192, 1)
         out["cfg3_slice"] = {"value": 3.5 * 4.0 * 1 * 2 * 8192 * 8192 * D / t3 / 1e12, "unit": "TFLOP/s",
                              "sample": f"(1,2,8192,64) slice of cfg3, one run, {t3:.2f} s; full cfg3 = x24 = {24*t3:.0f} s at this rate"}
     except Exception as e:  # noqa: BLE001  (host memory)
         out["cfg3_slice"] = {"error": str(e)[:100]}
     return out
+
+
+def _timeit(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
 
 
 def load_traffic(kernel_key, S, mode):
@@ -474,26 +616,34 @@ def main():
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_BF16_TFLOPS, 4),
                                "avg_launch_us": round(kern[dom]["us"], 3), "traffic": load_traffic(dom, S, mode)}
             by_seq = {}
+            rooflines = {}
             for s2 in (512, 2048, 8192):
                 p2 = plan if (s2 == S and not strong) else make_plan(s2, mode, device, seed=rank)[0]
                 it = 50 if s2 <= 2048 else 20
-                tf = event_time(p2.forward, it)
+                sf = event_stats(p2.forward, it, reps=3)
                 p2.forward()
-                tb = event_time(p2.backward, it)
+                sb = event_stats(p2.backward, it, reps=3)
+                tf, tb = sf["median"], sb["median"]
                 f = fwd_flops(s2)
+                if s2 != 512:  # (S = 512: the top-level `roofline` block)
+                    rooflines[str(s2)] = seq_rooflines(s2, mode, p2, max(5, it // 2))
                 by_seq[str(s2)] = {"fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "fwd_tflops": round(f / tf / 1e9, 1),
                                    "bwd_tflops": round(2.5 * f / tb / 1e9, 1),
                                    "fwd_bwd_tflops": round(3.5 * f / (tf + tb) / 1e9, 1),
                                    "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4),
                                    # backward: counted flops (5 GEMMs) and executed MFMA flops (the two-kernel design runs 7)
                                    "bwd_frac_of_peak": round(2.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4),
-                                   "bwd_mfma_frac_of_peak": round(3.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4)}
+                                   "bwd_mfma_frac_of_peak": round(3.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                   "fwd_ms_min_max": [round(sf["min"], 4), round(sf["max"], 4)],
+                                   "bwd_ms_min_max": [round(sb["min"], 4), round(sb["max"], 4)]}
                 del p2
             out["by_seq"] = by_seq
+            out["roofline_by_seq"] = rooflines
             if world == 1:
                 out["eager_autograd"] = eager_autograd(S, device)
                 out["rowwise"] = rowwise_bench(device)
                 out["reference_shape"] = reference_shape_bench(device)
+                out["n3_fusions"] = n3_bench(device)
                 out["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -48,7 +48,7 @@ EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
-    "fat5_ce_fwd", "fat5_ce_bwd", "fat5_linear_fused",
+    "fat5_ce_fwd", "fat5_ce_bwd", "fat5_linear_fused", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_rmsnorm_unit_bwd",
     "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
 )
 
@@ -95,6 +95,12 @@ def load():
     lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
     lib.fat5_linear_fused.restype = ctypes.c_int
     lib.fat5_linear_fused.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp]
+    lib.fat5_fold_weights_bwd.restype = ctypes.c_int
+    lib.fat5_fold_weights_bwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, i32, vp]
+    lib.fat5_rmsnorm_unit_bwd.restype = ctypes.c_int
+    lib.fat5_rmsnorm_unit_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]
+    lib.fat5_fold_weights.restype = ctypes.c_int
+    lib.fat5_fold_weights.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, i32, vp]
     lib.fat5_ce_bwd.restype = ctypes.c_int
     lib.fat5_ce_bwd.argtypes = [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, f32, f32, i64, i32, vp]
     lib.fat5_adamw_scale_step.restype = ctypes.c_int
@@ -117,6 +123,7 @@ def load():
 V_FWD64_ON, V_FWD64_OFF, V_KV64_ON, V_KV64_OFF, V_Q64_ON, V_Q64_OFF = 1, 2, 4, 8, 16, 32
 V_DBIAS_STAGED, V_DBIAS_INKERNEL, V_NO_FUSE, V_NO_SPLIT = 64, 128, 256, 512
 V_FWD64_KSPLIT_ON, V_FWD64_KSPLIT_OFF = 1024, 2048
+V_KV64_HALF_ON, V_KV64_HALF_OFF, V_Q64_HALF_ON, V_Q64_HALF_OFF = 4096, 8192, 16384, 32768
 _variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)
 
 

@@ -71,7 +71,34 @@ class FlashT5Attention(nn.Module):
         q = self.Wq(hidden_states).view(B, M, self.n_heads, self.key_value_proj_dim).permute(0, 2, 1, 3)
         k = self.Wk(src).view(B, N, self.n_heads, self.key_value_proj_dim).permute(0, 2, 1, 3)
         v = self.Wv(src).view(B, N, self.n_heads, self.key_value_proj_dim).permute(0, 2, 1, 3)
+        out, position_bias = self._attend(q, k, v, hidden_states.dtype, mask, key_value_states is None, position_bias)
+        return self.o(out), position_bias
 
+    def forward_fused(self, hidden_states, norm_weight, eps, mask=None, key_value_states=None, position_bias=None):
+        """One whole T5 attention sub-layer, `h + o(attention(layer_norm(h)))` (reference modeling_flash_t5.py:304-318 / :321-349),
+        with the pre-norm inside the projection GEMM and the residual add as the output projection's epilogue
+        (`fused_linear.rmsnorm_linear` / `linear_residual`): `hidden_states` is the UN-normalised residual stream,
+        `norm_weight` / `eps` the sub-layer's `layer_norm`.  Returns (new residual stream, position_bias)."""
+        from .fused_linear import rmsnorm_linear, linear_residual
+        B, M = hidden_states.shape[:2]
+        H, Dh = self.n_heads, self.key_value_proj_dim
+        if key_value_states is None:  # self-attention: ONE GEMM for q, k, v
+            qkv = rmsnorm_linear(hidden_states, norm_weight, (self.Wq.weight, self.Wk.weight, self.Wv.weight), eps).view(B, M, 3, H, Dh)
+            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        else:                         # cross-attention: the decoder side is normed, the encoder output is not (:330-336)
+            N = key_value_states.shape[1]
+            q = rmsnorm_linear(hidden_states, norm_weight, self.Wq.weight, eps).view(B, M, H, Dh).permute(0, 2, 1, 3)
+            kv = torch.nn.functional.linear(key_value_states, torch.cat((self.Wk.weight, self.Wv.weight), 0)).view(B, N, 2, H, Dh)
+            k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+        out, position_bias = self._attend(q, k, v, hidden_states.dtype, mask, key_value_states is None, position_bias)
+        return linear_residual(out, self.o.weight, hidden_states), position_bias
+
+    def _attend(self, q, k, v, dtype, mask, is_self, position_bias):
+        """attention of projected (B, H, S, D) views -> (B, M, inner_dim), plus the position bias to hand on"""
+        B, _, M, _ = q.shape
+        N = k.shape[2]
+        key_value_states = None if is_self else True
+        hidden_dtype = dtype
         if self.attention_type == "fat5_rpe":
             if position_bias is None and self.pe_encoding is not None:
                 position_bias = self.pe_encoding.forward_1d()
@@ -97,8 +124,7 @@ class FlashT5Attention(nn.Module):
                 m = mask.unsqueeze(1)
                 if m.dim() == 3:
                     m = m.unsqueeze(3)
-                bias = torch.where(m, bias, torch.finfo(hidden_states.dtype).min)
+                bias = torch.where(m, bias, torch.finfo(hidden_dtype).min)
                 position_bias = bias
             out = flash_attention_v2_bias(q, k, v, bias, self.is_causal, self.softmax_scale)
-        out = out.permute(0, 2, 1, 3).reshape(B, M, self.inner_dim)
-        return self.o(out), position_bias
+        return out.permute(0, 2, 1, 3).reshape(B, M, self.inner_dim), position_bias

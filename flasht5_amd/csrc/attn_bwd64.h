@@ -25,17 +25,24 @@
 
 namespace fat5 {
 
-template <int D>
+// HALF (mid sequence lengths): the four waves form two PAIRS; both pairs own the same 128 keys (64 per wave) and each walks one
+// half of the query steps through a ring of its own, then the second pair hands its dK^T / dV^T over through LDS.  With 256-key
+// workgroups at one per CU (one wave per SIMD), (4,12,2048,64) is 384 workgroups on 256 CUs: two rounds, the second half empty.
+// 768 half-length workgroups are three full rounds of half the length.
+template <int D, bool HALF = false>
 struct Bwd64Cfg {
-  static constexpr int NW = 4, BNK = 64 * NW, QT = 32, NT = 64 * NW, NS = 4;
+  static constexpr int NW = 4, BNK = HALF ? 128 : 64 * NW, QT = 32, NT = 64 * NW, NS = 4;
   static constexpr int IMG = rm_bytes<D, QT>();  // one 32-row image (Q or dO)
   static constexpr int STATB = NW * 1024;        // one private 1 KiB DMA piece of row statistics per wave (256 B used)
   static constexpr int SLOT = 2 * IMG + STATB;
   static constexpr int RING = NS * SLOT;
+  static constexpr int RINGS = HALF ? 2 : 1;     // one ring of query steps per wave pair
+  static constexpr int RPE0 = RINGS * RING;      // the RPE state sits behind the ring(s)
   static constexpr int SKEW_ROW = 160, SKEW = 32 * SKEW_ROW;  // (see BwdKVCfg)
+  static_assert(!HALF || 2 * 128 * 64 * 4 <= RPE0, "the hand-over of dK^T / dV^T (128 registers x 64 lanes per wave) reuses the rings");
   // rpe: four aligned table copies + one private diagonal accumulator per (wave, key block) + one skew tile per wave
   static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * 2 * NW + 63) / 64 * 64; }
-  static size_t smem(int R, int bias_mode) { return RING + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0); }
+  static size_t smem(int R, int bias_mode) { return RPE0 + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0); }
 };
 
 FAT5_DEV float asm_mul(float a, float b) {
@@ -97,15 +104,17 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 #define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
 #endif
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool HALF>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
-  using Cfg = Bwd64Cfg<D>;
+  using Cfg = Bwd64Cfg<D, HALF>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
+  const int pr = HALF ? (w >> 1) : 0;  // HALF: wave pair = which half of the query steps
+  const int wp = HALF ? (w & 1) : w;   // wave inside its pair / workgroup = which 64 keys
   int b, h, nblk;
   decode_unit(a, bid, a.n_nblk, b, h, nblk);
   const int bh = b * a.H + h;
@@ -118,7 +127,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   uint16_t* dkb = a.dk + (int64_t)b * a.dks[0] + (int64_t)h * a.dks[1];
   uint16_t* dvb = a.dv + (int64_t)b * a.dvs[0] + (int64_t)h * a.dvs[1];
   const int P = N - M;
-  const int kw0 = n0 + 64 * w;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
+  const int kw0 = n0 + 64 * wp;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
 
   // K and V fragments (B operands) of this lane's two keys
   u32x4 kf[2][KK], vf[2][KK];
@@ -133,10 +142,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   }
 
   // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators, skew tile) ----
-  float* sT = reinterpret_cast<float*>(smem + Cfg::RING) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RPE0) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int n1 = 2 * a.R + 1;
   float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);
-  char* sG = smem + Cfg::RING + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
+  char* sG = smem + Cfg::RPE0 + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
   const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
   int sk_r[2];
   {
@@ -187,16 +196,23 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   // query-step range: causal => only rows with q + P >= n0 see this key block
   int m_lo = 0;
   if (a.causal) m_lo = max(0, n0 - P) / 32 * 32;
-  const int mt0 = m_lo / 32;
   const int nst_all = (M + 31) / 32;
-  const int nsteps = nst_all - mt0;
+  int mt0 = m_lo / 32;
+  int nsteps = nst_all - mt0;
+  if constexpr (HALF) {
+    // each pair takes half of the steps (the second half may end with one step past the last row: its Q / dO rows and its
+    // statistics read as zeros through the buffer descriptors -> dS = 0, dO = 0: it contributes exactly nothing)
+    const int hs = (nsteps + 1) / 2;
+    mt0 += pr * hs;
+    nsteps = hs;
+  }
 
   // ---- ring: step j (query rows 32*(mt0+j) ..+31) lives in slot j % 4: [Q image | dO image | 4 private statistics pieces] ----
-  using Dma = DmaStage<D, Cfg::QT, NT>;
-  static_assert(Dma::PER == 1 && Dma::NV == 1, "one 16-byte piece per thread and image");
+  using Dma = DmaStage<D, Cfg::QT, HALF ? 128 : NT>;  // (HALF: a pair's 128 threads fill the pair's ring)
+  static_assert(Dma::PER == (HALF ? 2 : 1) && Dma::NV == 1, "one (HALF: two) 16-byte piece(s) per thread and image");
   Dma qst, dost;
-  qst.init(a.qs[2], tid);
-  dost.init(a.dos[2], tid);
+  qst.init(a.qs[2], HALF ? (tid & 127) : tid);
+  dost.init(a.dos[2], HALF ? (tid & 127) : tid);
   const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
   const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
   // statistics: 64 floats per step ([32] -L/scale, [32] -delta), whole steps (the dQ kernel pads the last one)
@@ -205,16 +221,20 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
   const uint32_t svoff = (uint32_t)(l & 15) * 16u;  // (lanes 16.. re-read the same 256 bytes: no out-of-range reliance)
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
+  const uint32_t ring0 = (uint32_t)(pr * Cfg::RING);  // this pair's ring
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wp * 1024u);
   auto dma_step = [&](int j, uint32_t slot_off) {
     const uint32_t mt = (uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j);
-    dma16_asm(qrs, wave_lds + slot_off, qst.voff[0], mt * 32u * qstride_b);
-    dma16_asm(dors, wave_lds + slot_off + (uint32_t)IMG, dost.voff[0], mt * 32u * dostride_b);
+#pragma unroll
+    for (int i = 0; i < Dma::PER; ++i) {
+      dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
+      dma16_asm(dors, wave_lds + slot_off + (uint32_t)(IMG + i * 2048), dost.voff[0], mt * 32u * dostride_b + dost.piece_step * i);
+    }
     dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
   };
   // E(j): step j+1 has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
   auto sync_step = [&](int j, uint32_t slot3_off) {
-    if (j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER + 1) : "memory");
     else wait_dma_all();
     __syncthreads();
     if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
@@ -226,7 +246,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       if (i < nsteps) dma_step(i, (uint32_t)(i * SLOT));
   }
   // slot 3 is read (against an all-zero P / dS) before anything lands in it: finite contents
-  for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int rg = 0; rg < Cfg::RINGS; ++rg)
+    for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + rg * Cfg::RING + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
     for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
@@ -245,17 +267,17 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   uint32_t rmA[KK], trA[2][DB], stA;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    rmA[kk] = lds0 + (uint32_t)fa.rm[kk];
+    rmA[kk] = lds0 + ring0 + (uint32_t)fa.rm[kk];
     asm volatile("" : "+v"(rmA[kk]));
   }
 #pragma unroll
   for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      trA[j2][db] = lds0 + (uint32_t)fa.tr[j2][db];
+      trA[j2][db] = lds0 + ring0 + (uint32_t)fa.tr[j2][db];
       asm volatile("" : "+v"(trA[j2][db]));
     }
-  stA = lds0 + (uint32_t)(2 * IMG + w * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +128+32g (-delta)
+  stA = lds0 + ring0 + (uint32_t)(2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +128+32g (-delta)
   asm volatile("" : "+v"(stA));
   auto rd_f4 = [&](uint32_t addr) { return __builtin_bit_cast(f32x4, lds_rd128(addr)); };
   auto put4 = [](f32x16& x, int g, const f32x4 v) { x[4 * g] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3]; };
@@ -713,6 +735,39 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
     }
   }
 
+  if constexpr (HALF) {
+    // ---- the second pair hands its dK^T / dV^T over (lane-major 16-byte pieces: conflict-free), the first adds and stores ----
+    __syncthreads();  // every wave is done with the rings
+    char* mg = smem + wp * (128 * 64 * 4);
+    if (pr == 1) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int i = ((kb * DB + db) * 4 + g) * 2;
+            *reinterpret_cast<f32x4*>(mg + (i * 64 + l) * 16) = f32x4{dk[kb][db][4 * g], dk[kb][db][4 * g + 1], dk[kb][db][4 * g + 2], dk[kb][db][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(mg + ((i + 1) * 64 + l) * 16) = f32x4{dv[kb][db][4 * g], dv[kb][db][4 * g + 1], dv[kb][db][4 * g + 2], dv[kb][db][4 * g + 3]};
+          }
+    }
+    __syncthreads();
+    if (pr == 1) return;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int i = ((kb * DB + db) * 4 + g) * 2;
+          const f32x4 xk = *reinterpret_cast<const f32x4*>(mg + (i * 64 + l) * 16), xv = *reinterpret_cast<const f32x4*>(mg + ((i + 1) * 64 + l) * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dk[kb][db][4 * g + e] += xk[e];
+            dv[kb][db][4 * g + e] += xv[e];
+          }
+        }
+  }
   const float scale = a.scale;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
@@ -1157,10 +1212,10 @@ void attn_bwd_q64_kernel(const AttnArgs a) {
   attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x);
 }
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool HALF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_kv64_kernel(const AttnArgs a) {
-  attn_bwd_kv64_body<D, BF16, BIAS>(a, blockIdx.x);
+  attn_bwd_kv64_body<D, BF16, BIAS, HALF>(a, blockIdx.x);
 }
 
 }  // namespace fat5

@@ -10,10 +10,10 @@
 
 namespace fat5 {
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool HALF>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = Bwd64Cfg<D>::smem(a.R, BIAS);
-  auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS>;
+  const size_t smem = Bwd64Cfg<D, HALF>::smem(a.R, BIAS);
+  auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -39,11 +39,17 @@ hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int b
   return bf16 ? launch_q64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_q64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
 }
 
-hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+template <bool HALF>
+static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
   if (bias == FAT5_BIAS_RPE1D)
-    return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
-  return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
+    return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, HALF>(a, grid, s);
+  return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_NONE, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_NONE, HALF>(a, grid, s);
+}
+// nw == 2: the half-length variant (128-key workgroups, two wave pairs each walking half of the query steps); otherwise 256 keys
+hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  return nw == 2 ? launch_kv64_bias<true>(a, bf16, bias, grid, s) : launch_kv64_bias<false>(a, bf16, bias, grid, s);
 }
 size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }
+size_t CAT(smem_bwd_kv64h_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D, true>::smem(R, bias); }
 
 }  // namespace fat5

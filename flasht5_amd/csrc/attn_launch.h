@@ -24,6 +24,7 @@ size_t smem_fwd64_d64(int R, int bias);  // dynamic LDS of one workgroup (two fi
 // 64 keys per wave, software-pipelined dK/dV body (attn_bwd64.h): bf16, bias none / rpe1d, no packed batches
 hipError_t launch_bwd_kv64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 size_t smem_bwd_kv64_d64(int R, int bias);
+size_t smem_bwd_kv64h_d64(int R, int bias);  // (nw == 2: 128-key workgroups, half the query steps per wave pair)
 // 64 query rows per wave, software-pipelined dQ body (attn_bwd64.h): same conditions
 hipError_t launch_bwd_q64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 }  // namespace fat5

@@ -45,6 +45,7 @@ inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit
 struct BwdLayout {
   size_t delta_off, stat2_off, ds_off, drpe_off, scratch_off, total;
   bool kv64;        // dK/dV by the 64-keys-per-wave pipelined body (attn_bwd64.h); the dQ kernel then also writes its statistics
+  bool kv64_half;   // ... in its half-length variant (128-key workgroups: two wave pairs, each half of the query steps)
   bool q64;         // dQ by the 64-rows-per-wave pipelined body (attn_bwd64.h)
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
@@ -194,12 +195,26 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   // long sequences: 64 keys per wave, software-pipelined (attn_bwd64.h) once its 256-key workgroups (one per CU) cover the
   // chip twice (variant: FAT5_V_KV64_OFF disables, FAT5_V_KV64_ON forces wherever the body applies; FAT5_V_Q64_* likewise)
   const int b64_env = vsel(p->variant, FAT5_V_KV64_ON, FAT5_V_KV64_OFF);
+  // One workgroup per CU (one wave per SIMD): `wg256` 256-key workgroups take ceil(wg256 / 256) rounds.  The half-length variant
+  // (twice the workgroups, half the steps each) where that wastes more than a quarter of the last round, e.g. (4,12,2048,64):
+  // 384 workgroups = 2 rounds against 768 half-length ones = 3 half rounds.  Measured (tools/attn_time.py, dK/dV stage, us):
+  //   S = 2048  no bias: 32-key body 118, 256-key 112, half-length 108.7     T5 bias: 135.9 / 155.4 / 152.4
+  //   S = 3072  no bias: 256-key 247, half-length 235                        T5 bias: 307.6 / 311.0
+  // -- five DMA pieces per wave and step instead of three and a third prologue eat most of the round model's 25 %, and with the
+  // T5 bias the ~12 band steps of a wave (general iteration + skew-tile sums, ~2.9x a pipelined step) decide: below 512 workgroups
+  // the 64-key bodies take over only without bias.
+  const long wg256 = bh * ((p->N + 255) / 256);
+  const int kvh_env = vsel(p->variant, FAT5_V_KV64_HALF_ON, FAT5_V_KV64_HALF_OFF);
+  const double r_full = (double)((wg256 + 255) / 256), r_half = 0.5 * 1.04 * (double)((2 * wg256 + 255) / 256);
+  L.kv64_half = kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full);
+  const size_t kv64_lds = L.kv64_half ? smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode) : smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode);
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || bh * ((p->N + 255) / 256) >= 512) &&
-           smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024;
+           (b64_env == 1 || wg256 >= (L.kv64_half ? 320 : 512)) && kv64_lds <= 160 * 1024;
   if (L.kv64) {
-    L.nw_kv = 4;
-    L.n_nblk = (p->N + 255) / 256;
+    L.nw_kv = L.kv64_half ? 2 : 4;  // (launch_bwd_kv64: 2 selects the half-length variant)
+    L.n_nblk = L.kv64_half ? (p->N + 127) / 128 : (p->N + 255) / 256;
+  } else {
+    L.kv64_half = false;
   }
   const int q64_env = vsel(p->variant, FAT5_V_Q64_ON, FAT5_V_Q64_OFF);
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
@@ -295,7 +310,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   bwd_layout(p, L);
   if (p->bias_mode == FAT5_BIAS_RPE1D) {
     // the dK/dV body keeps the table and one private diagonal accumulator per wave in LDS
-    const size_t lds = L.kv64 ? smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode)
+    const size_t lds = L.kv64 ? (L.kv64_half ? smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode) : smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode))
                      : p->D == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
                                   : (p->D == 64 ? smem_bwd_kv_d64(L.nw_kv, p->rpe_radius, p->bias_mode) : smem_bwd_kv_d128(L.nw_kv, p->rpe_radius, p->bias_mode));
     if (lds > 160 * 1024)
@@ -610,6 +625,74 @@ int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, 
 #undef LIN_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "linear_fused launch");
+  return FAT5_OK;
+}
+
+int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0, int64_t ld1,
+                      int64_t ld2, const void* g, void* out, int64_t K, int dtype, void* stream_) {
+  if (!w0 || !out || n0 <= 0 || n1 < 0 || n2 < 0 || (n1 > 0 && !w1) || (n2 > 0 && !w2)) return fail(FAT5_EINVAL, "fold_weights: bad arguments");
+  if (dtype != FAT5_F16 && dtype != FAT5_BF16) return fail(FAT5_EINVAL, "fold_weights: 16-bit dtypes only");
+  if (K <= 0 || K % 8 != 0 || ld0 % 8 || ld1 % 8 || ld2 % 8 || !aligned16(w0) || !aligned16(out) || (w1 && !aligned16(w1)) ||
+      (w2 && !aligned16(w2)) || (g && !aligned16(g)))
+    return fail(FAT5_EINVAL, "fold_weights: K and the row strides must be multiples of 8 elements, bases 16-byte aligned");
+  const int64_t items = (n0 + n1 + n2) * (K / 8);
+  if (n0 + n1 + n2 > 0x7fffffffLL || items > (int64_t)0x7fffffff * 256) return fail(FAT5_EINVAL, "fold_weights: too large");
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned grid = (unsigned)((items + 255) / 256);
+  if (dtype == FAT5_BF16)
+    hipLaunchKernelGGL(fold_weights_kernel<true>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2,
+                       (int)n0, (int)n1, (int)n2, ld0, ld1, ld2, (const uint16_t*)g, (uint16_t*)out, (int)K);
+  else
+    hipLaunchKernelGGL(fold_weights_kernel<false>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2,
+                       (int)n0, (int)n1, (int)n2, ld0, ld1, ld2, (const uint16_t*)g, (uint16_t*)out, (int)K);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "fold_weights launch");
+  return FAT5_OK;
+}
+
+int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0,
+                          int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
+                          void* stream_) {
+  if (!dwg || !w0 || !g || n0 <= 0 || n1 < 0 || n2 < 0 || (n1 > 0 && !w1) || (n2 > 0 && !w2)) return fail(FAT5_EINVAL, "fold_weights_bwd: bad arguments");
+  if (dtype != FAT5_F16 && dtype != FAT5_BF16) return fail(FAT5_EINVAL, "fold_weights_bwd: 16-bit dtypes only");
+  if (K <= 0 || K % 64 != 0 || ld0 % 8 || ld1 % 8 || ld2 % 8) return fail(FAT5_EINVAL, "fold_weights_bwd: K must be a multiple of 64, row strides of 8");
+  const void* ptrs[] = {dwg, w0, w1, w2, g, dw0, dw1, dw2};
+  for (const void* q : ptrs)
+    if (q && !aligned16(q)) return fail(FAT5_EINVAL, "fold_weights_bwd: 16-byte aligned bases");
+  if (n0 + n1 + n2 > 0x7fffffffLL) return fail(FAT5_EINVAL, "fold_weights_bwd: too large");
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned grid = (unsigned)(K / 64);
+#define FOLDB(BF)                                                                                                               \
+  hipLaunchKernelGGL(fold_weights_bwd_kernel<BF>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)dwg, (const uint16_t*)w0,      \
+                     (const uint16_t*)w1, (const uint16_t*)w2, (int)n0, (int)n1, (int)n2, ld0, ld1, ld2, (const uint16_t*)g,     \
+                     (uint16_t*)dw0, (uint16_t*)dw1, (uint16_t*)dw2, (uint16_t*)dg, (int)K)
+  if (dtype == FAT5_BF16) FOLDB(true); else FOLDB(false);
+#undef FOLDB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "fold_weights_bwd launch");
+  return FAT5_OK;
+}
+
+int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n, int64_t gy_stride,
+                          int64_t x_stride, int64_t dx_stride, int64_t xhat_stride, int dtype, void* stream_) {
+  if (!gy || !x || !rstd || !dx || !xhat) return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: null pointer");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: bad dtype");
+  const int v = vec_of(dtype);
+  if (rows <= 0 || n <= 0 || n % v || n > 4 * 64 * v || gy_stride % v || x_stride % v || dx_stride % v || xhat_stride % v || !aligned16(gy) ||
+      !aligned16(x) || !aligned16(dx) || !aligned16(xhat))
+    return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: n must be a multiple of %d and at most %d; 16-byte aligned rows", v, 4 * 64 * v);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int grid = (int)((rows + 3) / 4);
+  const int nch = (int)((n + 64 * v - 1) / (64 * v));
+  dispatch_dtype(dtype, [&](auto dt_) {
+    constexpr int DT = decltype(dt_)::value;
+    if (nch <= 2)
+      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 2>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride);
+    else
+      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 4>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride);
+  });
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rmsnorm_unit_bwd launch");
   return FAT5_OK;
 }
 

@@ -257,6 +257,55 @@ __global__ __launch_bounds__(256) void add_rmsnorm_fwd_reg_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward through the UNIT-weight norm xhat = x * rstd, for the backward of the pre-norm fused into a projection GEMM
+// (fused_linear.py): gy = dL/dxhat ->  dx = (gy - xhat * mean(xhat * gy)) * rstd, and xhat itself (the A operand of the
+// dout^T xhat weight-gradient GEMM) in the same pass.  Wave per row, everything of the row in registers.
+// ---------------------------------------------------------------------------------------------
+template <int XDT, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_unit_bwd_kernel(const void* __restrict__ gy_, const void* __restrict__ x_,
+                                                               const float* __restrict__ rstd, void* __restrict__ dx_,
+                                                               void* __restrict__ xhat_, int64_t rows, int n, int64_t gys, int64_t xs,
+                                                               int64_t dxs, int64_t xhs) {
+  typedef Elem<XDT> X;
+  constexpr int VEC = X::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(x_) + row * xs;
+  const typename X::T* gy = reinterpret_cast<const typename X::T*>(gy_) + row * gys;
+  typename X::T* dx = reinterpret_cast<typename X::T*>(dx_) + row * dxs;
+  typename X::T* xh_out = reinterpret_cast<typename X::T*>(xhat_) + row * xhs;
+  const float r = rstd[row];
+  float xh[NCH][VEC], gv[NCH][VEC];
+  float c1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+    if (c < n) {
+      X::load(x + c, xh[i]);
+      X::load(gy + c, gv[i]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xh[i][j] *= r;
+        c1 = fmaf(xh[i][j], gv[i][j], c1);
+      }
+    }
+  }
+  c1 = wave_sum(c1) / (float)n;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * VEC;
+    if (c < n) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = (gv[i][j] - xh[i][j] * c1) * r;
+      X::store(dx + c, o);
+      X::store(xh_out + c, xh[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RMSNorm backward: persistent waves over strided rows; dw accumulated per lane in registers,
 // reduced across the workgroup's waves through LDS, one fp32 partial row per workgroup.
 //   NCH = max 16-byte chunks per lane (n <= NCH * 64 * VEC)

@@ -52,6 +52,8 @@ class FAT5Config:
     crossentropy_inplace_backward: bool = True
     fuse_lm_head_ce: bool = False          # lm_head + loss in row chunks: the (B*T, vocab) logits are never materialised
     fuse_add_norm: bool = False            # every residual add runs inside the next pre-norm (fused_add_rms_layernorm): same bits, fewer passes
+    fuse_norm_linear: bool = False         # pre-norm inside the projection GEMM, residual add as the output projection's epilogue
+                                           # (fused_linear.py / fat5_linear_fused): no stand-alone norm or add launch in the blocks
     is_decoder: bool = False
 
 
@@ -90,6 +92,18 @@ class FAT5LayerFF(nn.Module):  # :148-164
     def forward(self, h):
         return h + self.wo(self.act(self.layer_norm(h)))
 
+    def forward_fused(self, h):
+        """the same sub-layer with the norm inside the wi GEMM and the residual add as wo's epilogue"""
+        from .fused_linear import rmsnorm_linear, linear_residual
+        a = self.act
+        if a.glu:
+            g = rmsnorm_linear(h, self.layer_norm.weight, (a.wi_0.weight, a.wi_1.weight), self.layer_norm.variance_epsilon)
+            g0, g1 = g.split(a.wi_0.weight.shape[0], dim=-1)
+            t = a.act(g0) * g1
+        else:
+            t = a.act(rmsnorm_linear(h, self.layer_norm.weight, a.wi.weight, self.layer_norm.variance_epsilon))
+        return linear_residual(t, self.wo.weight, h)
+
     def forward_deferred(self, h, pending):
         """(h, delta): the residual stream after the pending add, and this sub-layer's output whose add is left to the next pre-norm"""
         h, n = _pre_norm(self.layer_norm, h, pending)
@@ -106,6 +120,9 @@ class FAT5LayerSelfAttention(nn.Module):  # :297-318
         a, position_bias = self.self_attention(self.layer_norm(h), position_bias=position_bias)
         return h + a, position_bias
 
+    def forward_fused(self, h, position_bias=None):
+        return self.self_attention.forward_fused(h, self.layer_norm.weight, self.layer_norm.variance_epsilon, position_bias=position_bias)
+
     def forward_deferred(self, h, pending, position_bias=None):
         h, n = _pre_norm(self.layer_norm, h, pending)
         a, position_bias = self.self_attention(n, position_bias=position_bias)
@@ -121,6 +138,9 @@ class FAT5LayerCrossAttention(nn.Module):  # :321-349
     def forward(self, h, key_value_states):
         a, _ = self.cross_attention(self.layer_norm(h), key_value_states=key_value_states)
         return h + a
+
+    def forward_fused(self, h, key_value_states):
+        return self.cross_attention.forward_fused(h, self.layer_norm.weight, self.layer_norm.variance_epsilon, key_value_states=key_value_states)[0]
 
     def forward_deferred(self, h, pending, key_value_states):
         h, n = _pre_norm(self.layer_norm, h, pending)
@@ -143,6 +163,12 @@ class FAT5Block(nn.Module):  # :352-392
             h = self.cross_attention_layer(h, encoder_hidden_states)
         return self.ff_layer(h), position_bias
 
+    def forward_fused(self, h, position_bias=None, encoder_hidden_states=None):
+        h, position_bias = self.self_attention_layer.forward_fused(h, position_bias)
+        if self.is_decoder and encoder_hidden_states is not None:
+            h = self.cross_attention_layer.forward_fused(h, encoder_hidden_states)
+        return self.ff_layer.forward_fused(h), position_bias
+
     def forward_deferred(self, h, pending, position_bias=None, encoder_hidden_states=None):
         h, pending, position_bias = self.self_attention_layer.forward_deferred(h, pending, position_bias)
         if self.is_decoder and encoder_hidden_states is not None:
@@ -158,12 +184,17 @@ class FAT5Stack(nn.Module):  # :394-464
         self.block = nn.ModuleList([FAT5Block(c, has_positional_encoding=(i == 0)) for i in range(n_layers)])
         self.final_layer_norm = FlashT5LayerNorm(c.d_model, eps=c.layer_norm_epsilon)
         self.fuse_add_norm = c.fuse_add_norm
+        self.fuse_norm_linear = c.fuse_norm_linear
 
     def forward(self, input_ids, encoder_hidden_states=None):
         h = self.embed_tokens(input_ids)
         if torch.is_autocast_enabled() and h.is_cuda:  # :424-425
             h = h.to(torch.get_autocast_gpu_dtype())
         position_bias = None  # produced by block 0, shared by the others (:452-455)
+        if self.fuse_norm_linear and h.dtype in (torch.float16, torch.bfloat16):
+            for blk in self.block:
+                h, position_bias = blk.forward_fused(h, position_bias, encoder_hidden_states)
+            return self.final_layer_norm(h)
         if self.fuse_add_norm:
             pending = None  # the last sub-layer's output: its residual add happens inside the next pre-norm
             for blk in self.block:

@@ -1,0 +1,161 @@
+"""Linear layers with the T5 pre-norm / the residual add fused in -- host side of `fat5_linear_fused`
+(csrc/linear_fused.h: a hand-written gfx950 MFMA GEMM whose prologue forms the RMSNorm row statistics from the A tiles on their
+way through LDS and whose epilogue applies them / adds the residual).
+
+    rmsnorm_linear(x, norm_weight, weight, eps)   == F.linear(fast_rms_layernorm(x, norm_weight, eps), weight)
+        reference: `normed = self.layer_norm(hidden_states)` then Wq / Wk / Wv (src/model/modeling_flash_t5.py:304-318, :95-98);
+        likewise layer_norm -> wi_0 / wi_1 (:159-160).  The normalised activation is neither written in the forward nor kept for
+        the backward (autograd would keep it as the Linear's input): the backward rebuilds x * rstd from x and the saved rstd.
+    linear_residual(a, weight, residual)          == residual + F.linear(a, weight)
+        reference: `hidden_states + self.o(...)` / `hidden_states + self.wo(...)` (:316, :162-163), rounded twice like the two ops.
+
+Both differentiable in every tensor argument.  The backward GEMMs are library GEMMs (torch.matmul -> hipBLASLt)."""
+import torch
+
+from . import _lib
+
+__all__ = ["rmsnorm_linear", "linear_residual", "fold_weights", "RMSNormLinear", "LinearResidual", "fused_linear_supported"]
+
+
+def fused_linear_supported(x, weight):
+    """shapes / dtypes the MFMA kernel takes (fat5_linear_fused): 16-bit, K a multiple of 64, N of 8"""
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype and weight.dim() == 2 and
+            x.shape[-1] == weight.shape[1] and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
+
+
+def _rows(t):
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if (t2.stride(-1) == 1 and t2.data_ptr() % 16 == 0 and t2.stride(0) % 8 == 0) else t2.contiguous()
+
+
+def _launch(a, w, res, norm, eps, want_rstd):
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=a.device) if want_rstd else None
+    if M == 0:
+        return out, rstd
+    with _lib.on_device(a.device):
+        _lib.check(_lib.load().fat5_linear_fused(
+            a.data_ptr(), w.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
+            rstd.data_ptr() if rstd is not None else None, M, N, K, a.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
+            out.stride(0), int(bool(norm)), float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device)), "fat5_linear_fused")
+    return out, rstd
+
+
+def fold_weights(weights, norm_weight):
+    """[w0; w1; ...] (up to three (n_i, K) weights stacked along n) times diag(norm_weight), ONE launch (fat5_fold_weights):
+    the projection weight `rmsnorm_linear`'s kernel takes.  norm_weight None: the plain stack."""
+    ws = [w if (w.stride(-1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 8 == 0) else w.contiguous() for w in weights]
+    assert 1 <= len(ws) <= 3
+    K = ws[0].shape[1]
+    out = torch.empty((sum(w.shape[0] for w in ws), K), dtype=ws[0].dtype, device=ws[0].device)
+    g = None if norm_weight is None else norm_weight.to(ws[0].dtype).contiguous()
+    ptr = [w.data_ptr() for w in ws] + [None] * (3 - len(ws))
+    n = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
+    ld = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
+    with _lib.on_device(out.device):
+        _lib.check(_lib.load().fat5_fold_weights(ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2],
+                                                 g.data_ptr() if g is not None else None, out.data_ptr(), K, _lib.dtype_code(out.dtype),
+                                                 _lib.stream_ptr(out.device)), "fat5_fold_weights")
+    return out
+
+
+class RMSNormLinear(torch.autograd.Function):
+    """`weights`: one to three (n_i, K) projection weights applied to the SAME normalised input (Wq, Wk, Wv / wi_0, wi_1): the
+    outputs come back concatenated along the last dim, the gradients per weight.
+
+    forward : fold (one launch: [W_i] diag g) + the MFMA kernel (rstd formed in-kernel)                      -- 2 launches
+    backward: gy = dout Wg (GEMM) | dx and xhat = x rstd in one pass (fat5_rmsnorm_unit_bwd) | dWg = dout^T xhat (GEMM) |
+              dW_i = dWg g, dg = sum_n dWg W in one launch (fat5_fold_weights_bwd)                           -- 4 launches
+    (the separate ops: norm + 3 GEMMs forward; 6 GEMMs + 2 norm-backward kernels + 2 gradient accumulations backward)"""
+
+    @staticmethod
+    def forward(ctx, x, norm_weight, eps, *weights):
+        shape = x.shape
+        x2 = _rows(x)
+        # the norm weight rides in the projection: (x rstd g) W^T = rstd (x (W diag g)^T)
+        wg = fold_weights(weights, norm_weight)
+        out, rstd = _launch(x2, wg, None, True, eps, True)
+        ctx.save_for_backward(x2, norm_weight, rstd, wg, *weights)  # (wg: a few MB per layer -- the normalised activation is what is NOT kept)
+        ctx.shape = shape
+        return out.reshape(*shape[:-1], wg.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, g, rstd, wg, *weights = ctx.saved_tensors
+        d2 = _rows(dout)
+        if d2.dtype != x2.dtype:
+            d2 = d2.to(x2.dtype)
+        lib = _lib.load()
+        M, K = x2.shape
+        gy = d2 @ wg                                                     # dL/dxhat: (M, K)
+        dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+        xhat = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+        with _lib.on_device(x2.device):
+            _lib.check(lib.fat5_rmsnorm_unit_bwd(gy.data_ptr(), x2.data_ptr(), rstd.data_ptr(), dx.data_ptr(), xhat.data_ptr(), M, K,
+                                                 gy.stride(0), x2.stride(0), K, K, _lib.dtype_code(x2.dtype), _lib.stream_ptr(x2.device)),
+                       "fat5_rmsnorm_unit_bwd")
+        dg = None
+        dWs = [None] * len(weights)
+        if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[3:]):
+            dwg = d2.t() @ xhat                                          # gradient of the folded weight [W_i] diag(g): (N, K)
+            ws = [w if (w.stride(-1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0) else w.contiguous() for w in weights]
+            gq = g.to(x2.dtype).contiguous()
+            dWs = [torch.empty((w.shape[0], K), dtype=x2.dtype, device=x2.device) for w in ws]
+            dgq = torch.empty((K,), dtype=x2.dtype, device=x2.device)
+            ptr = [w.data_ptr() for w in ws] + [None] * (3 - len(ws))
+            n = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
+            ld = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
+            dptr = [t.data_ptr() for t in dWs] + [None] * (3 - len(ws))
+            with _lib.on_device(x2.device):
+                _lib.check(lib.fat5_fold_weights_bwd(dwg.data_ptr(), ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2],
+                                                     gq.data_ptr(), dptr[0], dptr[1], dptr[2], dgq.data_ptr(), K, _lib.dtype_code(x2.dtype),
+                                                     _lib.stream_ptr(x2.device)), "fat5_fold_weights_bwd")
+            dg = dgq.to(g.dtype) if ctx.needs_input_grad[1] else None
+            dWs = [(t.to(w.dtype) if ctx.needs_input_grad[3 + i] else None) for i, (t, w) in enumerate(zip(dWs, weights))]
+        return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None, dg, None, *dWs)
+
+
+class LinearResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, weight, residual):
+        shape = residual.shape
+        a2, r2 = _rows(a), _rows(residual)
+        out, _ = _launch(a2, _rows(weight), r2, False, 0.0, False)
+        ctx.save_for_backward(a2, weight)
+        ctx.ashape = a.shape
+        return out.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, W = ctx.saved_tensors
+        d2 = dout.reshape(-1, dout.shape[-1])
+        da = (d2 @ W).reshape(ctx.ashape) if ctx.needs_input_grad[0] else None
+        dW = (d2.t() @ a2).to(W.dtype) if ctx.needs_input_grad[1] else None
+        return da, dW, (dout if ctx.needs_input_grad[2] else None)
+
+
+def rmsnorm_linear(x, norm_weight, weight, eps=1e-6):
+    """F.linear(fast_rms_layernorm(x, norm_weight, eps), weight) in one MFMA kernel; x (..., K), weight (N, K) -> (..., N).
+    `weight` may be a tuple of up to three weights applied to the same normalised input (Wq, Wk, Wv / wi_0, wi_1): their outputs
+    come back concatenated along the last dim (one GEMM).  Shapes the kernel does not take (K % 64, N % 8, fp32) run the two
+    HIP / library ops one after the other."""
+    if not x.is_cuda:
+        raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
+    weights = tuple(weight) if isinstance(weight, (tuple, list)) else (weight,)
+    if (len(weights) > 3 or not all(fused_linear_supported(x, w) for w in weights) or norm_weight.shape != (x.shape[-1],) or
+            x.shape[-1] > 2048):  # (fat5_rmsnorm_unit_bwd keeps a row in registers: up to 2048 16-bit elements)
+        from .rms_norm import fast_rms_layernorm
+        y = fast_rms_layernorm(x, norm_weight, eps)
+        return torch.cat([torch.nn.functional.linear(y, w) for w in weights], -1) if len(weights) > 1 else torch.nn.functional.linear(y, weights[0])
+    return RMSNormLinear.apply(x, norm_weight, float(eps), *weights)
+
+
+def linear_residual(a, weight, residual):
+    """residual + F.linear(a, weight) with the add as the GEMM's epilogue (rounded twice, like the two separate ops)."""
+    if not a.is_cuda:
+        raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
+    if not fused_linear_supported(a, weight) or residual.dtype != a.dtype or residual.shape[-1] != weight.shape[0]:
+        return residual + torch.nn.functional.linear(a, weight)
+    return LinearResidual.apply(a, weight, residual)

@@ -49,7 +49,9 @@ enum fat5_variant {
   FAT5_V_DBIAS_STAGED = 64, FAT5_V_DBIAS_INKERNEL = 128, /* dense (1,H,M,N) dbias: staged dS + reduction / batch-inner kernel */
   FAT5_V_NO_FUSE = 256,                         /* backward: never the single side-by-side dQ | dK/dV launch */
   FAT5_V_NO_SPLIT = 512,                        /* forward: never the two-waves-per-32-rows short-sequence body */
-  FAT5_V_FWD64_KSPLIT_ON = 1024, FAT5_V_FWD64_KSPLIT_OFF = 2048 /* 64-row forward: key-split (two waves per 64 rows) variant always / never */
+  FAT5_V_FWD64_KSPLIT_ON = 1024, FAT5_V_FWD64_KSPLIT_OFF = 2048, /* 64-row forward: key-split (two waves per 64 rows) variant always / never */
+  FAT5_V_KV64_HALF_ON = 4096, FAT5_V_KV64_HALF_OFF = 8192,       /* 64-key dK/dV body: half-length (128-key workgroup) variant always / never */
+  FAT5_V_Q64_HALF_ON = 16384, FAT5_V_Q64_HALF_OFF = 32768        /* 64-row dQ body: half-length (128-row workgroup) variant always / never */
 };
 
 enum fat5_bias_mode {
@@ -199,6 +201,24 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
 int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, float* rstd_out, int64_t M, int64_t N, int64_t K,
                       int64_t a_row_stride, int64_t w_row_stride, int64_t res_row_stride, int64_t out_row_stride, int norm, float eps,
                       int dtype, void* hip_stream);
+/* The folded projection weight for fat5_linear_fused(norm = 1), in one launch: out = [w0; w1; w2] (rows stacked: (n0 + n1 + n2, K),
+ * contiguous) with every row multiplied elementwise by the norm weight g (K,) (g == NULL: the plain stack) -- e.g. Wq, Wk, Wv of a
+ * T5 attention block and its layer_norm weight.  n1 / n2 may be 0.  All tensors share `dtype` (16-bit); products rounded once. */
+int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0, int64_t ld1,
+                      int64_t ld2, const void* g, void* out, int64_t K, int dtype, void* hip_stream);
+/* Backward pieces of fat5_linear_fused(norm = 1) (the two gradient GEMMs are plain GEMMs):
+ *  - fat5_rmsnorm_unit_bwd: gy = dout (W diag g) = dL/dxhat, xhat = x * rstd ->  dx = (gy - xhat * mean_k(xhat * gy)) * rstd (the
+ *    backward of rms_norm.py:113-124 with unit weight), and xhat itself -- the operand of the dout^T xhat GEMM -- in the same pass;
+ *    x_dtype tensors, n <= 2048 (16-bit) / 1024 (fp32).
+ *  - fat5_fold_weights_bwd: dwg (N, K) = dout^T xhat, the gradient of the folded weight [w0; w1; w2] diag(g) ->
+ *    dw_i = dwg rows * g (contiguous (n_i, K), any of them may be NULL), dg[k] = sum_n dwg[n][k] * w[n][k] (fp32, fixed order; may be NULL).
+ *    K a multiple of 64. */
+int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n,
+                          int64_t gy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, int64_t xhat_row_stride, int dtype,
+                          void* hip_stream);
+int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0,
+                          int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
+                          void* hip_stream);
 
 /*
  * Cross-entropy + label smoothing + z-loss.  Replaces flasht5::cross_entropy_triton_fwd / _bwd

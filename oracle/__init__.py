@@ -10,3 +10,4 @@ from .rpe import (relative_position_bucket, compute_bias, bias1d_from_table,
 from .rmsnorm import rmsnorm_fwd_oracle, rmsnorm_bwd_oracle, rmsnorm_eager
 from .cross_entropy import ce_fwd_oracle, ce_bwd_oracle
 from .adamw_scale import adamw_scale_step
+from .fused_linear import rmsnorm_linear_oracle, rmsnorm_linear_reference_rounding, linear_residual_oracle

@@ -12,9 +12,12 @@ from test_attention_gpu import bound, gbound, _rpe_case
 pytestmark = pytest.mark.gpu
 
 
+HALF = {"on": False}  # set per test by the module fixture: the half-length (128-key / 128-row workgroup) variants of the 64-wide bodies
+
+
 def _bits(kv64, q64, fwd64=None):
     from flasht5_amd import _lib
-    b = 0
+    b = (_lib.V_KV64_HALF_ON | _lib.V_Q64_HALF_ON) if HALF["on"] else (_lib.V_KV64_HALF_OFF | _lib.V_Q64_HALF_OFF)
     if kv64 is not None:
         b |= _lib.V_KV64_ON if kv64 else _lib.V_KV64_OFF
     if q64 is not None:
@@ -24,11 +27,15 @@ def _bits(kv64, q64, fwd64=None):
     return b
 
 
-@pytest.fixture(autouse=True)
-def force_bwd64():
+@pytest.fixture(autouse=True, params=["wg256", "half"])
+def force_bwd64(request):
+    """every test of this module runs twice: 256-key / 256-row workgroups, and the half-length variants (128-key workgroups whose
+    two wave pairs each walk half of the query steps and merge dK^T / dV^T through LDS; likewise for dQ)"""
     from flasht5_amd import _lib
+    HALF["on"] = request.param == "half"
     with _lib.variant(_bits(True, True)):
         yield
+    HALF["on"] = False
 
 
 def _grads(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
