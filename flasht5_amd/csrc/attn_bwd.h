@@ -43,18 +43,6 @@ struct BwdQCfg {
   }
 };
 
-#ifndef FAT5_TRACE
-#define FAT5_TRACE 0  // developer: wave 0 of every workgroup stamps s_memtime into the delta scratch (tools/trace_bwd.py)
-#endif
-#if FAT5_TRACE
-#define FAT5_STAMP(slot)                                                                                   \
-  do {                                                                                                     \
-    if (threadIdx.x == 0 && (slot) < 16)                                                                   \
-      reinterpret_cast<unsigned long long*>(a.delta)[(size_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define FAT5_STAMP(slot) do {} while (0)
-#endif
 #ifndef FAT5_BWD_MINW
 #define FAT5_BWD_MINW 2  // the register allocator must leave room for 2 waves per SIMD (<= 256 VGPR+AGPR)
 #endif
@@ -65,8 +53,6 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
-
-  FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int b, h, mblk;
   decode_unit(a, bid, a.n_mblk, b, h, mblk);
@@ -317,7 +303,6 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
       }
     }
     __syncthreads();
-    FAT5_STAMP(2 + t);
   };
 
   // tile classes as in the forward (boundaries rounded to even tile indices: one body per loop)
@@ -343,7 +328,6 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     tb1 &= ~1;
     if (tb1 < tb0) tb0 = tb1 = ta;
   }
-  FAT5_STAMP(1);
   int t = 0;
   for (; t < ta; t += 2) {
     tile.template operator()<true, 0>(t, cst_a);
@@ -377,7 +361,6 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
         *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
       }
   }
-  FAT5_STAMP(15);
 }
 
 // =============================================================================================
@@ -411,8 +394,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   constexpr int BNK = Cfg::BNK, BMQ = Cfg::BMQ, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  FAT5_STAMP(0);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int b, h, nblk;
   decode_unit(a, bid, a.n_nblk, b, h, nblk);
@@ -827,7 +808,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     }
     if (more) store_stats(smem + (BUF ^ 1) * Cfg::STAGE);
     __syncthreads();  // (carries the vmcnt(0) that retires this wave's DMA pieces)
-    FAT5_STAMP(2 + mt - mt0);
   };
 
   // Tile classes over mt in [mt0, mt1) relative index i = mt - mt0 (even boundaries, see attn_fwd.h).
@@ -835,10 +815,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   int ia = 0, ib0 = 0, ib1 = 0;  // FAST for i < ia (cst_a) and ib0 <= i < ib1 (cst_b)
   float cst_a = 0.f, cst_b = 0.f;
   const bool key_tail = n0 + BNK > N;
-#ifndef FAT5_BWD_NOFAST
-#define FAT5_BWD_NOFAST 0
-#endif
-  if (!FAT5_BWD_NOFAST && BIAS != FAT5_BIAS_DENSE && !key_tail) {
+  if (BIAS != FAT5_BIAS_DENSE && !key_tail) {
     int mt_full = M / BMQ;  // tiles without an M tail
     int mt_first = mt0;     // causal: first tile where every key of the workgroup is visible to every row
     if (a.causal) mt_first = max(mt0, (max(0, n0 + BNK - 1 - P) + BMQ - 1) / BMQ);
@@ -865,7 +842,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
     ib1 &= ~1;
     if (ib1 < ib0) ib0 = ib1 = ia;
   }
-  FAT5_STAMP(1);
   int i = 0;
   for (; i < ia; i += 2) {
     tile.template operator()<true, 0, 1>(mt0 + i, cst_a);
@@ -908,8 +884,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
       }
     }
   }
-  FAT5_STAMP(14);
-
   if (krow < N) {
     const float scale = a.scale;
     uint16_t* dkrow = dkb + (int64_t)krow * a.dks[2];
@@ -927,7 +901,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
       }
   }
-  FAT5_STAMP(15);
 }
 
 // ---- launchable kernels -------------------------------------------------------------------------------------

@@ -50,12 +50,6 @@ FAT5_DEV float asm_mul(float a, float b) {
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// acc += w.lo * o.lo + w.hi * o.hi  (the two 16-bit lanes of a packed word)
-template <bool BF16>
-FAT5_DEV void asm_dot2c(float& acc, uint32_t w, uint32_t o) {
-  if constexpr (BF16) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o));
-  else asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(o));
-}
 // acc += A . B with the accumulator tuple in AGPRs.  The dK^T / dV^T accumulators (128 registers) are touched by nothing but
 // MFMAs: hipcc's VGPR-form MFMA selection would keep them in VGPRs and spill everything else through v_accvgpr moves.
 // No hazard padding is generated for asm: same-accumulator MFMAs need none, A / B come from LDS reads (waitcnt is inserted
@@ -65,44 +59,11 @@ FAT5_DEV void mfma_acc_agpr(f32x16& acc, const u32x4 A, const u32x4 B) {
   if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
   else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-FAT5_DEV f32x2 asm_pk_mul(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-FAT5_DEV f32x2 asm_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-  f32x2 r;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
   typedef s16x4_t __attribute__((address_space(3))) * p_t;
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)addr));
 }
 
-#ifndef FAT5_B64_FARMFMA
-#define FAT5_B64_FARMFMA 1  // far-bin sums of dS on the matrix pipe (0: one v_dot2c per packed word)
-#endif
-#ifndef FAT5_B64_PIN
-#define FAT5_B64_PIN 1
-#endif
-#ifndef FAT5_B64_PK
-#define FAT5_B64_PK 0  // 0: one v_fma / v_mul per element; 1: v_pk_mul_f32 per element pair; 2: v_pk_fma_f32 too
-#endif
-#ifndef FAT5_B64_NLC
-// 1: the row statistics are read once (8 LDS reads per step instead of 16) and enter the first k-step as a separate C operand
-// (-2 %).  A C operand that is not also the destination is read by the MFMA for ~19 cycles after issue, and the volatile-asm
-// VALU ops that follow in the same gap get no hazard padding from hipcc: the registers of NL / DL are therefore kept live (an empty
-// asm use two gaps after their last MFMA) so that nothing can be allocated into them inside that window.
-#define FAT5_B64_NLC 1
-#endif
-#ifndef FAT5_Q64_CREG
-#define FAT5_Q64_CREG 1  // dQ body: 1 = -delta as a 16-register broadcast per query block (C operand of the first dP k-step; 24 gaps per step:
-#endif                   //          1077 vs 1108 us at cfg3), 0 = through one extra MFMA per query block (26 gaps, 32 VGPRs fewer)
-#ifndef FAT5_B64_X
-#define FAT5_B64_X 0  // developer experiments (results are WRONG): 1 no softmax VALU, 2 no LDS reads, 4 no barrier / DMA, 8 no tail
-#endif
 
 template <int D, bool BF16, int BIAS, bool HALF>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
@@ -155,11 +116,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   }
   const uint32_t one2s = pack2<BF16>(1.f, 1.f);
   u32x4 ones = {one2s, one2s, one2s, one2s};
-#if FAT5_B64_FARMFMA
   // (opaque: a constant tuple is re-materialised by v_mov right in front of the asm MFMA that reads it — and no wait states are
   // generated between a VALU write and an asm consumer)
   asm volatile("" : "+v"(ones));
-#endif
   float carry[2] = {0.f, 0.f};
   int carry_d0[2] = {0, 0};
   bool carry_valid[2] = {false, false};
@@ -302,9 +261,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   // ------------------------------------------------------------------------------------------------------------------
   f32x16 S[2], DP[2];
   u32x4 PB[2][2], DS[2][2], TRD, TRQ;
-  float facc = 0.f;  // sum of the dS of a pipelined range (one far bin)
-  // ... or, FAT5_B64_FARMFMA: ones(16x32) . dS words as a 32x16 B operand; every row of the 16x16 result = the column sums, so
-  // the sum over lanes and registers is 16x the sum of all the words' elements, whatever their layout
+  // sum of the dS of a pipelined range (one far bin) on the matrix pipe: ones(16x32) . dS words as a 32x16 B operand; every row of
+  // the 16x16 result = the column sums, so the sum over lanes and registers is 16x the sum of all the words' elements, whatever
+  // their layout (one v_dot2c_f32_bf16 per word instead measured 9 % of this kernel)
   [[maybe_unused]] f32x4 facc4 = {0.f, 0.f, 0.f, 0.f};
 
   // scores of the step in the slot at byte offset `so`
@@ -460,7 +419,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   //   MFMA   g < 16: products of step i-1 -- per (t2, db): dV^T[kb0], dV^T[kb1] (fragment dO^T), dK^T[kb0], dK^T[kb1] (Q^T);
   //          16..23: S'[kb] of step i+1 (k-steps outer, C = -L/scale on the first); 24..31: dP'[kb] (C = -delta)
   //   VALU   element g of step i (key block g >> 4, register g & 15): x = s*c2 + cst | element g-1: p = exp2(x) |
-  //          element g-2: ds = p*dp' | even g: elements g-4, g-3 packed to bf16 (P and dS words), dS summed into `facc`
+  //          element g-2: ds = p*dp' | even g: elements g-4, g-3 packed to bf16 (P and dS words), dS summed on the matrix pipe (`facc4`)
   //   LDS    gaps 0..11 the transposed fragments of the remaining three (t2, db) pairs of step i-1; gap 12 the barrier
   //          E(i) + the DMA of step i+3; gaps 12..22 statistics (straight into the accumulators of S', dP': the MFMA C operand)
   //          and row-major fragments of step i+1; gaps 28..31 the first
@@ -479,7 +438,6 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       PBn[kb][t2][wd] = asm_cvt_pk<BF16>(Pv[E0], Pv[E0 + 1]);
       const uint32_t dsw = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
       DSn[kb][t2][wd] = dsw;
-      if constexpr (BIAS == FAT5_BIAS_RPE1D && !FAT5_B64_FARMFMA) asm_dot2c<BF16>(facc, dsw, one2s);
     };
     static_for<32>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
@@ -493,38 +451,22 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         else mfma_acc_agpr<BF16>(dk[kb][db], fr, DS[kb][t2]);
       } else if constexpr (g < 24) {
         constexpr int kk = (g - 16) >> 1, kb = g & 1;
-        if constexpr (FAT5_B64_NLC && kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], NL);
+        if constexpr (kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], NL);
         else Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sn[kb]);  // (accumulator preloaded with -L/scale)
       } else {
         constexpr int kk = (g - 24) >> 1, kb = g & 1;
-        if constexpr (FAT5_B64_NLC && kk == 0) DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DL);
+        if constexpr (kk == 0) DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DL);
         else DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DPn[kb]);  // (preloaded with -delta)
       }
-#if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap)
-#endif
-#if FAT5_B64_NLC
       if constexpr (g == 19) asm volatile("" ::"v"(NL));  // (keeps NL's registers out of reach of the VALU ops of gaps 16..18)
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
-#endif
       // ---- barrier + DMA ----
-      if constexpr (g == 12 && !(FAT5_B64_X & 4)) sync_step(j, o_prev);
+      if constexpr (g == 12) sync_step(j, o_prev);
       // ---- LDS ----
-      if constexpr ((FAT5_B64_X & 2) != 0) {
-        if constexpr (g == 0) {
-#pragma unroll
-          for (int pp = 1; pp < 4; ++pp)
-#pragma unroll
-            for (int wh = 0; wh < 2; ++wh) { trh[pp][wh][0] = u32x2{TRD[0], TRD[1]}; trh[pp][wh][1] = u32x2{TRQ[2], TRQ[3]}; }
-#pragma unroll
-          for (int kk = 0; kk < KK; ++kk) { qa[kk] = TRD; da[kk] = TRQ; }
-          Sn[0] = S[0]; Sn[1] = S[1]; DPn[0] = DP[0]; DPn[1] = DP[1];
-          tnd[0] = u32x2{TRD[0], TRD[1]}; tnd[1] = u32x2{TRD[2], TRD[3]}; tnq[0] = u32x2{TRQ[0], TRQ[1]}; tnq[1] = u32x2{TRQ[2], TRQ[3]};
-        }
-      } else if constexpr (g < 12) {
+      if constexpr (g < 12) {
         constexpr int pp = (g >> 2) + 1, t2 = pp >> 1, db = pp & 1, wh = (g >> 1) & 1, half = g & 1;
         trh[pp][wh][half] = lds_rd_tr_half(trA[half][db] + o_prev + (uint32_t)((wh == 0 ? IMG : 0) + 16 * t2 * 2 * D));
-#if FAT5_B64_NLC
       } else if constexpr (g == 12) {
         put4(NL, 0, rd_f4(stA + o_next));
         put4(NL, 1, rd_f4(stA + o_next + 32u));
@@ -537,29 +479,6 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         put4(DL, 1, rd_f4(stA + o_next + 160u));
         put4(DL, 2, rd_f4(stA + o_next + 192u));
         put4(DL, 3, rd_f4(stA + o_next + 224u));
-#else
-      } else if constexpr (g == 12) {
-        put4(Sn[0], 0, rd_f4(stA + o_next));
-        put4(Sn[0], 1, rd_f4(stA + o_next + 32u));
-        put4(Sn[0], 2, rd_f4(stA + o_next + 64u));
-        put4(Sn[0], 3, rd_f4(stA + o_next + 96u));
-      } else if constexpr (g == 13) {
-        put4(Sn[1], 0, rd_f4(stA + o_next));
-        put4(Sn[1], 1, rd_f4(stA + o_next + 32u));
-        qa[0] = lds_rd128(rmA[0] + o_next);
-      } else if constexpr (g == 14) {
-        put4(Sn[1], 2, rd_f4(stA + o_next + 64u));
-        put4(Sn[1], 3, rd_f4(stA + o_next + 96u));
-        qa[1] = lds_rd128(rmA[1] + o_next);
-      } else if constexpr (g == 15 || g == 16) {
-        qa[g - 13] = lds_rd128(rmA[g - 13] + o_next);
-      } else if constexpr (g == 17 || g == 18) {
-        constexpr int kb = g - 17;
-        put4(DPn[kb], 0, rd_f4(stA + o_next + 128u));
-        put4(DPn[kb], 1, rd_f4(stA + o_next + 160u));
-        put4(DPn[kb], 2, rd_f4(stA + o_next + 192u));
-        put4(DPn[kb], 3, rd_f4(stA + o_next + 224u));
-#endif
       } else if constexpr (g >= 19 && g <= 22) {
         da[g - 19] = lds_rd128(rmA[g - 19] + o_next + (uint32_t)IMG);
       } else if constexpr (g >= 28) {
@@ -568,63 +487,19 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         else tnq[half] = lds_rd_tr_half(trA[half][0] + o_cur);
       }
       // ---- VALU ----
-      if constexpr ((FAT5_B64_X & 1) != 0) {
-        if constexpr (g == 0) {
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) { PBn[kb][t2] = PB[kb][t2]; DSn[kb][t2] = DS[kb][t2]; }
-        }
-      } else {
-#if FAT5_B64_PK == 0
+      {
       if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
       if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
       if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
       X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
-      if constexpr (g == 31 && !(FAT5_B64_X & 8)) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
+      if constexpr (g == 31) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
         Pv[31] = asm_exp2(X[31]);
         Dv[30] = asm_mul(Pv[30], DP[1][14]);
         pack_pair.template operator()<28>();
         Dv[31] = asm_mul(Pv[31], DP[1][15]);
         pack_pair.template operator()<30>();
       }
-#else
-      // pair form: odd gaps pack the pair multiplied in the gap before; even gaps multiply pair (g-4, g-3) and (PK 2) form the
-      // exponent arguments of pair (g, g+1) with one packed op each
-      if constexpr (g >= 5 && (g & 1) == 1) pack_pair.template operator()<g - 5>();
-      if constexpr (g >= 4 && (g & 1) == 0) {
-        constexpr int e0 = g - 4, kb = e0 >> 4, r = e0 & 15;
-        const f32x2 d2 = asm_pk_mul(f32x2{Pv[e0], Pv[e0 + 1]}, f32x2{DP[kb][r], DP[kb][r + 1]});
-        Dv[e0] = d2[0];
-        Dv[e0 + 1] = d2[1];
       }
-      if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
-#if FAT5_B64_PK == 2
-      if constexpr ((g & 1) == 0) {
-        const f32x2 x2 = asm_pk_fma(f32x2{S[g >> 4][g & 15], S[g >> 4][(g & 15) + 1]}, f32x2{c2, c2}, f32x2{cst, cst});
-        X[g] = x2[0];
-        X[g + 1] = x2[1];
-      }
-#else
-      X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
-#endif
-      if constexpr (g == 31) {
-        Pv[31] = asm_exp2(X[31]);
-        {
-          const f32x2 d2 = asm_pk_mul(f32x2{Pv[28], Pv[29]}, f32x2{DP[1][12], DP[1][13]});
-          Dv[28] = d2[0]; Dv[29] = d2[1];
-        }
-        {
-          const f32x2 d2 = asm_pk_mul(f32x2{Pv[30], Pv[31]}, f32x2{DP[1][14], DP[1][15]});
-          Dv[30] = d2[0]; Dv[31] = d2[1];
-        }
-        pack_pair.template operator()<28>();
-        pack_pair.template operator()<30>();
-      }
-#endif
-      if constexpr (g == 31 && (FAT5_B64_X & 8) != 0) { Pv[31] = Pv[30]; Dv[30] = Dv[29]; Dv[31] = Dv[29]; pack_pair.template operator()<28>(); pack_pair.template operator()<30>(); }
-      }
-#if FAT5_B64_FARMFMA
       // far-bin sum of the step's dS: one 16x16x32 MFMA (16 cycles of the pipe, inside the gap's slack) per four packed words once they
       // are complete — 16 v_dot2c_f32_bf16 per step measured 9 % of this kernel. The last group's words come from the asm ops just
       // above (no hazard padding for asm producers: two wait states by hand)
@@ -636,10 +511,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(facc4) : "v"(ones), "v"(DSn[grp >> 1][grp & 1]));
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(facc4) : "v"(ones), "v"(DSn[grp >> 1][grp & 1]));
       }
-#endif
-#if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);
-#endif
     });
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -692,14 +564,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
         j += 4;
         if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-#if FAT5_B64_FARMFMA
           asm volatile("s_nop 15" : "+v"(facc4));  // (asm MFMA -> VALU read of its result: no padding is generated; tied to the tuple so that no read moves above it)
           const float fsum = ((facc4[0] + facc4[1]) + (facc4[2] + facc4[3])) * 0.0625f;
           facc4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-          const float fsum = facc;
-          facc = 0.f;
-#endif
           if (side > 0) far_pos += fsum; else far_neg += fsum;
         }
       }
@@ -843,7 +710,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   u32x4 qf[2][KK], dof[2][KK];
   float nL2[2];
   // dP'^T = V dO^T - delta.  The pipelined loop takes -delta as a C operand (nd16: 16 registers per query block, live for the whole
-  // loop); the general iteration (and FAT5_Q64_CREG = 0) forms it with one extra MFMA per query block, ones(32 x 16) x D3 with
+  // loop; 1077 vs 1108 us at cfg3 for the alternative); the general iteration forms it with one extra MFMA per query block, ones(32 x 16) x D3 with
   // D3[j][q] = the j-th 16-bit piece of -delta_q (hi + mid + lo: 24+ bits, exact to fp32) -- a 16-register broadcast of -delta per
   // block as the C operand would hold 32 VGPRs for the whole loop (C and D of an MFMA share one register file)
   u32x4 d3[2];
@@ -1059,7 +926,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   //          gaps 12..15 the V row-major fragments of step i+1; gaps 22..25 the K^T fragments (t2 = 0) of step i
   // SL = the step's ring slot, a compile-time constant: the steady state runs four steps (slots 0..3) per trip, straight-line --
   // slot offsets are instruction immediates and S / Sn (...) trade registers from one step to the next instead of being copied.
-  constexpr int NG = FAT5_Q64_CREG ? 24 : 26, G_DP = FAT5_Q64_CREG ? 16 : 18;  // (G_DP: first gap of the dP k-steps)
+  constexpr int NG = 24, G_DP = 16;  // (G_DP: first gap of the dP k-steps)
   auto fast_iter = [&]<int SL>(const int t, const float ad0, const float ad1) {
     constexpr uint32_t o_prev = (uint32_t)(((SL + 3) & 3) * SLOT), o_cur = (uint32_t)(SL * SLOT), o_next = (uint32_t)(((SL + 1) & 3) * SLOT);
     f32x16 Sn[2], DPn[2];
@@ -1090,12 +957,10 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         DPn[g - 16] = mfma32<BF16>(ones4, d3[g - 16], zero16);
       } else {
         constexpr int kk = (g - G_DP) >> 1, qb = g & 1;
-        if constexpr (FAT5_Q64_CREG && kk == 0) DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], nd16[qb]);  // (nd16 lives for the whole loop: no WAR window)
+        if constexpr (kk == 0) DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], nd16[qb]);  // (nd16 lives for the whole loop: no WAR window)
         else DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPn[qb]);
       }
-#if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap: without this it may sink below the gap's VALU work and pair up with the next one)
-#endif
       // ---- barrier + DMA ----
       if constexpr (g == 4) sync_step(t, o_prev);
       // ---- LDS ----
@@ -1131,9 +996,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
           });
         }
       }
-#if FAT5_B64_PIN
       __builtin_amdgcn_sched_barrier(0);
-#endif
     });
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {

@@ -72,40 +72,15 @@ FAT5_DEV void load_bias_block(const uint16_t* brow, int nb, int hi, int N, bool 
   }
 }
 
-#ifndef FAT5_ASM_MAX3
-#define FAT5_ASM_MAX3 0  // 1 is UNSAFE: hipcc pads no MFMA->VALU wait states in front of inline asm
-#endif
 FAT5_DEV float max3f(float a, float b, float c) {
-#if FAT5_ASM_MAX3
-  // single instruction, no canonicalising v_max inserted by the compiler in front of it
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-#else
   return fmaxf(fmaxf(a, b), c);
-#endif
 }
 FAT5_DEV float max16(const f32x16& s) {
   const float a = max3f(s[0], s[1], s[2]), b = max3f(s[3], s[4], s[5]), c = max3f(s[6], s[7], s[8]);
   const float d = max3f(s[9], s[10], s[11]), e = max3f(s[12], s[13], s[14]);
   return max3f(max3f(a, b, c), max3f(d, e, s[15]), s[15]);
 }
-#ifndef FAT5_PSUM_MFMA
-#define FAT5_PSUM_MFMA 0  // 1: row sums of P on the matrix pipe (A = ones).  0 (default): 8 v_pk_add_f32 per block -- the chip is power
-                          // limited under this kernel (~1.95 GHz), two extra MFMAs per block cost more than the packed adds
-#endif
 
-#ifndef FAT5_ABLATE
-#define FAT5_ABLATE 0  // developer ablations (bitmask): 1 no exp, 2 no max, 4 no staging/barrier, 8 no PV, 16 no QK
-#endif
-#ifndef FAT5_FWD_ONEBLK
-#define FAT5_FWD_ONEBLK 1  // form the scores of ONE 32-key block at a time and fetch V fragments right before their MFMAs:
-                          // ~166 live registers at D <= 64 -> three waves per SIMD (S=2048: 3072 waves = exactly one
-                          // round instead of 1.5; +11 % there, +3-4 % at S=8192).  0: both blocks' scores up front.
-#endif
-#ifndef FAT5_FWD_DMA
-#define FAT5_FWD_DMA 1  // K/V tiles global -> LDS directly (buffer_load ... lds) instead of through registers + ds_write
-#endif
 #ifndef FAT5_FWD_MINW
 #define FAT5_FWD_MINW 3  // waves per SIMD the register allocator must leave room for at D <= 64 (D = 128: always 2)
 #endif
@@ -113,7 +88,7 @@ FAT5_DEV float max16(const f32x16& s) {
 // the two bias sources, which keeps hipcc from scheduling across it (dense forward -3..5 %)
 template <int D, bool BF16, int BIAS, int NW, bool SPLIT = false, bool BDMA = false>
 FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
-  static_assert(!SPLIT || (FAT5_FWD_ONEBLK && FAT5_FWD_DMA && NW % 2 == 0), "SPLIT needs the one-block-at-a-time DMA body");
+  static_assert(!SPLIT || NW % 2 == 0, "SPLIT pairs the waves of a workgroup");
   using Cfg = FwdCfg<D, NW, SPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -200,19 +175,9 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 
   f32x16 oacc[DB];
   float m_run;  // reference point of the exponentials (running row max, possibly stale), log2 units
-#if FAT5_PSUM_MFMA
-  f32x16 lacc;  // every register = running row sum of (rounded) P for this lane's query
-  const uint32_t one2 = pack2<BF16>(1.f, 1.f);
-  const u32x4 ones = {one2, one2, one2, one2};
-#else
   f32x2 l_run;  // per-lane partial row sum (two interleaved chains: v_pk_add_f32)
-#endif
 
-#if FAT5_FWD_DMA
   DmaStage<D, BN, NT> kst, vst;
-#else
-  RowStage<D, BN, NT> kst, vst;
-#endif
   kst.init(a.ks[2], tid);
   vst.init(a.vs[2], tid);
   const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
@@ -222,17 +187,10 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // first K/V tile (+ dense bias tile) in flight BEFORE the RPE table is fetched: one memory round trip for the prologue
   auto stage_first = [&]() {
     if (nt > 0) {
-#if FAT5_FWD_DMA
       kst.issue(krs, 0, smem, tid);
       vst.issue(vrs, 0, smem + Cfg::KBYTES, tid);
       if constexpr (BIAS == FAT5_BIAS_DENSE)
         if (bias_dma) bdm.issue(brs, 0, sB, tid);
-#else
-      kst.load_buf(krs, 0, tid);
-      vst.load_buf(vrs, 0, tid);
-      kst.store_rm(smem, tid);
-      vst.store_rm(smem + Cfg::KBYTES, tid);
-#endif
     }
   };
   stage_first();
@@ -261,38 +219,13 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     const char* sV = sK + Cfg::KBYTES;
     const bool more = (t + 1 < nt);
     // prefetch of the next tile through the buffer descriptors (zero-filled past row N-1 by the hardware)
-    if (!(FAT5_ABLATE & 4) && more) {
-#if FAT5_FWD_DMA
+    if (more) {
       char* nK = smem + (BUF ^ 1) * Cfg::STAGE;  // (its last readers passed the previous tile's barrier)
       kst.issue(krs, (uint32_t)(n0 + BN) * kstride_b, nK, tid);
       vst.issue(vrs, (uint32_t)(n0 + BN) * vstride_b, nK + Cfg::KBYTES, tid);
       if constexpr (BIAS == FAT5_BIAS_DENSE)
         if (bias_dma) bdm.issue(brs, (uint32_t)(n0 + BN) * 2u, sB + (BUF ^ 1) * Cfg::BIASB, tid);
-#else
-      kst.load_buf(krs, (uint32_t)(n0 + BN) * kstride_b, tid);
-      vst.load_buf(vrs, (uint32_t)(n0 + BN) * vstride_b, tid);
-#endif
     }
-#if !FAT5_FWD_ONEBLK
-    // ---- S^T = K Q^T for both 32-key blocks first: all K fragments in flight, two independent MFMA chains
-    //      (the second block's MFMAs run under the first block's softmax VALU work) ----
-    f32x16 sblk[2];
-    {
-      u32x4 kf[2][KK];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kb][kk] = ld_rm<D>(sK, fa, kb, kk);
-      __builtin_amdgcn_sched_barrier(0);  // all K-fragment reads in flight before the first MFMA
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          if (FAT5_ABLATE & 16) { sblk[kb] = zero16; sblk[kb][0] = __uint_as_float(qf[kk][0] & 0x3f800000u); continue; }
-          sblk[kb] = mfma32<BF16>(kf[kb][kk], qf[kk], kk == 0 ? zero16 : sblk[kb]);
-        }
-    }
-#endif
     // ---- per block: online softmax -> O^T += V^T P^T ----
     const char* sKb = sK + (SPLIT ? half * 64 * D : 0);  // (32 rows of 2*D bytes)
     const char* sVb = sV + (SPLIT ? half * 64 * D : 0);
@@ -300,7 +233,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     for (int kb = 0; kb < (SPLIT ? 1 : 2); ++kb) {
       const int kbr = SPLIT ? half : kb;  // block index inside the tile
       const int nb = n0 + 32 * kbr;
-#if FAT5_FWD_ONEBLK
       // one block at a time: 32 fewer live registers (fits three waves per SIMD); overlap comes from the other waves
       f32x16 s;
       {
@@ -310,17 +242,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
       }
-#else
-      f32x16& s = sblk[kb];
-#endif
-#if !FAT5_FWD_ONEBLK
-      u32x4 vfr[2][DB];  // V^T fragments of this block: issued now, consumed after the softmax
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) vfr[t2][db] = ld_tr<D>(sV, fa, kb, t2, db);
-      __builtin_amdgcn_sched_barrier(0);
-#endif
 
       float mul, add, mcand;
       if constexpr (MODE == 2) {
@@ -329,7 +250,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       } else if constexpr (FAST) {
         mul = c2;
         add = cst;
-        mcand = (FAT5_ABLATE & 2) ? fmaf(s[0], c2, cst) : fmaf(max16(s), c2, cst);
+        mcand = fmaf(max16(s), c2, cst);
       } else {
         bool folded = fold_ok;
         float cb = 0.f;
@@ -396,12 +317,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       if (MODE != 2 && __any(mcand > m_run + FAT5_DEFER_THR)) {
         const float m_new = fmaxf(m_run, mcand);
         const float alpha = fast_exp2(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
-#if FAT5_PSUM_MFMA
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-#else
         l_run *= alpha;
-#endif
 #pragma unroll
         for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -414,43 +330,22 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         // packed FMA (v_pk_fma_f32): two exponents per instruction
         f32x2 x = {s[r], s[r + 1]};
         x = x * mul + ad;
-        if (!(FAT5_ABLATE & 1)) { x[0] = fast_exp2(x[0]); x[1] = fast_exp2(x[1]); }
+        x[0] = fast_exp2(x[0]);
+        x[1] = fast_exp2(x[1]);
         s[r] = x[0];
         s[r + 1] = x[1];
-#if !FAT5_PSUM_MFMA
         l_run += x;
-#endif
       }
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const u32x4 pb = pack8<BF16>(s, t2);
-        if (FAT5_ABLATE & 8) { asm volatile("" ::"v"(pb)); continue; }
-#if FAT5_FWD_ONEBLK
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(ld_tr<D>(sVb, fa, kb, t2, db), pb, oacc[db]);
-#else
-#pragma unroll
-        for (int db = 0; db < DB; ++db) oacc[db] = mfma32<BF16>(vfr[t2][db], pb, oacc[db]);
-#endif
-#if FAT5_PSUM_MFMA
-        lacc = mfma32<BF16>(ones, pb, lacc);
-#endif
       }
-#if FAT5_FWD_ONEBLK
       __builtin_amdgcn_sched_barrier(0);  // keep the next block's fragment loads from being hoisted over this block
-#endif
     }
 
-    if (!(FAT5_ABLATE & 4)) {
-#if !FAT5_FWD_DMA
-      if (more) {
-        char* nK = smem + (BUF ^ 1) * Cfg::STAGE;
-        kst.store_rm(nK, tid);
-        vst.store_rm(nK + Cfg::KBYTES, tid);
-      }
-#endif
-      __syncthreads();  // (with DMA staging: carries the vmcnt(0) that retires this wave's pieces)
-    }
+    __syncthreads();  // (with DMA staging: carries the vmcnt(0) that retires this wave's pieces)
   };
 
   // Tile classes (workgroup-uniform), all boundaries rounded to EVEN tile indices so that every loop below runs
@@ -483,25 +378,12 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   }
   // once per optimistic tile pair: keep l (and O) below 2^40 by an exact power of two
   auto renorm = [&]() {
-#if FAT5_PSUM_MFMA
-    const float lchk = lacc[0];
-#else
     const float lchk = l_run[0] + l_run[1];  // lane partial <= row sum: conservative trigger
-#endif
     if (__builtin_expect(__any(!(lchk < 0x1p40f)), 0)) {
-#if FAT5_PSUM_MFMA
-      const float lc = lchk;
-#else
       const float lc = pair_sum(lchk);  // both lanes of a row must pick the same exponent
-#endif
       const int e = (lc >= 0x1p40f) ? (int)((__float_as_uint(lc) >> 23) & 0xffu) - 127 : 0;
       const float alpha = __uint_as_float((uint32_t)(127 - min(e, 126)) << 23);  // 2^-e
-#if FAT5_PSUM_MFMA
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-#else
       l_run *= alpha;
-#endif
 #pragma unroll
       for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -517,12 +399,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     m_run = -INFINITY;
-#if FAT5_PSUM_MFMA
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-#else
     l_run = f32x2{0.f, 0.f};
-#endif
     if (pass > 0) {  // (pass 0: staged before the loop)
       stage_first();
       __syncthreads();
@@ -574,17 +451,12 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       break;
     } else {
       if (!opt) break;
-#if FAT5_PSUM_MFMA
-      if (!(lacc[0] < 0x1p120f)) *sFlag = 1;  // inf / NaN / about to overflow
-#else
       if (!(l_run[0] + l_run[1] < 0x1p120f)) *sFlag = 1;
-#endif
       __syncthreads();
       if (*sFlag == 0) break;
     }
   }
 
-#if !FAT5_PSUM_MFMA
   if constexpr (SPLIT) {
     // merge the two key halves of every query group: wave (half 1) parks its state in LDS (the tile buffers are dead:
     // every wave is past the last tile's barrier), wave (half 0) folds it in with the usual two-reference-point rule
@@ -610,13 +482,8 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       for (int r = 0; r < 16; ++r) oacc[db][r] = oacc[db][r] * sa + sx[(2 + 16 * db + r) * 64] * sb;
     m_run = m_n;
   }
-#endif
   // ---- epilogue: o = acc / l, L = m + ln(l) --------------------------------------------------
-#if FAT5_PSUM_MFMA
-  const float l_tot = lacc[0];
-#else
   const float l_tot = pair_sum(l_run[0] + l_run[1]);
-#endif
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   if (qrow < M) {
     uint16_t* orow = ob + (int64_t)qrow * a.os[2];

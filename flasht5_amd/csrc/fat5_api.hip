@@ -36,8 +36,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // the 64-rows-per-wave forward takes over from this many waves of (64 rows x all keys) on (measured, tools/attn_time.py, (4,12,S,64):
-// S = 1024 -- 768 waves -- 19.7 / 23.3 us without / with the T5 bias against 22.4 / 26.1 us of the 32-row body; S = 512 stays there)
-constexpr long kFwd64MinWaves = 768;
+// S = 768 -- 576 waves -- 16.2 / 19.4 us without / with the T5 bias against 18.6 / 21.7 us of the 32-row body, S = 1024: 19.7 / 23.3 against
+// 22.4 / 26.1; at S = 512 -- 384 waves -- the two-waves-per-32-rows split body stays: 10.4 / 12.5 against 12.6 / 15.7)
+constexpr long kFwd64MinWaves = 512;
 
 // kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
 inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
