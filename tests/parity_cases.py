@@ -25,6 +25,11 @@ def gbound(ref_t, dtype):
     return bound(ref_t, dtype, ulps=3.0)
 
 
+def lse_bound(L_ref):
+    fin = torch.isfinite(L_ref)
+    return 1e-4 * max(1.0, L_ref[fin].abs().max().item() if fin.any() else 0.0)
+
+
 def rec(case, tensor, err, bnd):
     return {"case": case, "tensor": tensor, "err": float(err), "bound": float(bnd)}
 
@@ -38,7 +43,11 @@ def fixture_case(name):
     c = _dev(load_attn(name))
     dt = c["dtype"]
     got = run_dense(c["q"], c["k"], c["v"], c["bias"], c["do"], c["sm_scale"], c["causal"])
-    out = [rec(name, "o", maxdiff(got["o"], c["o"]), bound(c["o"], dt))]
+    out = [rec(name, "o", maxdiff(got["o"], c["o"]), bound(c["o"], dt)),
+           rec(name, "lse", maxdiff(got["L"], c["L"]), lse_bound(c["L"]))]  # (part of the operator contract: reference :59, :476)
+    lp = c["eager_lp_err"].tolist()
+    for i, key in enumerate(("o", "dq", "dk", "dv")):  # the reference's own rule (tests/fa2_triton/test_fa2_bias.py:26-28), unmodified
+        out.append(rec(name, key + " [reference rule: 2 x eager low-precision error + 1e-5]", maxdiff(got[key], c[key]), 2 * lp[i] + 1e-5))
     if "o_ref" in c:
         out.append(rec(name, "o_vs_reference_eager_fp32", maxdiff(got["o"], c["o_ref"]), bound(c["o_ref"], dt) + 2e-5))
     for key in ("dq", "dk", "dv"):
@@ -58,6 +67,7 @@ def triton_case(name):
         scale = max(1.0, c[tk].float().abs().max().item())
         nsum = c["B"] if (key == "db" and c["bias"].shape[0] == 1) else 1
         out.append(rec(name, key + "_vs_triton", maxdiff(got[key], c[tk]), 2 * (1e-3 + HALF_ULP[torch.float16]) * scale * nsum))
+    out.append(rec(name, "lse_vs_triton", maxdiff(got["L"], c["L_triton"]), lse_bound(c["L_triton"])))
     return out
 
 
@@ -135,6 +145,18 @@ def cfg3_case():
            rec(name, "dq[0,:2]", maxdiff(dq[sl], rdq), gbound(rdq, dt)),
            rec(name, "dk[0,:2]", maxdiff(dk[sl], rdk), gbound(rdk, dt)),
            rec(name, "dv[0,:2]", maxdiff(dv[sl], rdv), gbound(rdv, dt))]
+    # a second slice at the other end of the grid: last batch element, last two heads (another XCD, the last workgroups)
+    sl2 = (slice(B - 1, B), slice(H - 2, H))
+    bias2 = pe.compute_bias(table[:, H - 2:], S, S).contiguous()
+    q2, k2, v2, do2 = (t[sl2] for t in (q, k, v, do))
+    ref_o2, ref_L2 = oracle.attn_fwd_oracle(q2, k2, v2, bias2, scale, False)
+    rdq2, rdk2, rdv2, _, _ = oracle.attn_bwd_oracle(q2, k2, v2, bias2, ref_o2, ref_L2, do2, scale, False)
+    out += [rec(name, "o[3,10:]", maxdiff(o[sl2], ref_o2), bound(ref_o2, dt)),
+            rec(name, "lse[3,10:]", maxdiff(plan.lse[sl2], ref_L2), 1e-3),
+            rec(name, "dq[3,10:]", maxdiff(dq[sl2], rdq2), gbound(rdq2, dt)),
+            rec(name, "dk[3,10:]", maxdiff(dk[sl2], rdk2), gbound(rdk2, dt)),
+            rec(name, "dv[3,10:]", maxdiff(dv[sl2], rdv2), gbound(rdv2, dt))]
+    del ref_o2, ref_L2, rdq2, rdk2, rdv2, bias2
     # bias gradient of the slice: diagonal sums of the oracle's dS (delta from the kernel's stored o, as FA2 defines it)
     p2 = AttentionPlan(qs, ks, vs, dos, rpe1d=rpe1d[:2].contiguous(), radius=128, sm_scale=scale)
     o2 = p2.forward().clone()
