@@ -182,8 +182,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ring0 = (uint32_t)(pr * Cfg::RING);  // this pair's ring
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wp * 1024u);
-  auto dma_step = [&](int j, uint32_t slot_off) {
+  auto dma_step = [&](int j, uint32_t slot_off_) {
     const uint32_t mt = (uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j);
+    const uint32_t slot_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_off_);  // (provably wave-uniform: it feeds M0)
 #pragma unroll
     for (int i = 0; i < Dma::PER; ++i) {
       dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
@@ -261,6 +262,23 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   // ------------------------------------------------------------------------------------------------------------------
   f32x16 S[2], DP[2];
   u32x4 PB[2][2], DS[2][2], TRD, TRQ;
+  // band steps of the pipelined loop: the first table entries (key block 0, rows 0..3) of the step whose softmax is due and the
+  // address of that window (both formed one iteration ahead), and this lane's addressing of its padded table copy: entry of row mb + crow(r, hi), r = 4 gg + i, is component
+  // 3 - i of the 16 bytes at tab_addr(kb, mb) - 32 gg (the window runs DOWN with the row; see softmax_generic)
+  u32x4 TN0;
+  uint32_t tadr0 = 0u;
+  uint32_t tabB[2] = {0u, 0u};
+  int tpos[2] = {0, 0};
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int krow = kw0 + 32 * kb + lq, al = (a.R + krow - 3) & 3;
+      tabB[kb] = (uint32_t)(uintptr_t)(sT + al * rpe_n1p(a.R));
+      tpos[kb] = a.R + krow - 4 * hi - 3 - al;
+    }
+  }
+  const int tclamp_lo = -kRpePad + 24, tclamp_hi = rpe_n1p(a.R) - kRpePad - 4;  // (rpe_clamp_desc)
+  auto tab_addr = [&](int kb, int mb) { return tabB[kb] + 4u * (uint32_t)min(max(tpos[kb] - mb, tclamp_lo), tclamp_hi); };
   // sum of the dS of a pipelined range (one far bin) on the matrix pipe: ones(16x32) . dS words as a 32x16 B operand; every row of
   // the 16x16 result = the column sums, so the sum over lanes and registers is 16x the sum of all the words' elements, whatever
   // their layout (one v_dot2c_f32_bf16 per word instead measured 9 % of this kernel)
@@ -302,6 +320,50 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) mfma_acc_agpr<BF16>(dk[kb][db], qt, DS[kb][t2]);
       }
+  };
+
+  // Per-diagonal sums of the rounded dS (DS[kb], the words the dK GEMM consumes) of key block kb at query step mb -- the bias-table
+  // gradient's share of one 32 x 32 block.  `far_sum`: the block's sum for the case that it lies entirely beyond the band.
+  auto diag_sums = [&](const int kb, const int mb, const float far_sum) {
+    const int R = a.R;
+    const int k0 = kw0 + 32 * kb;
+    const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
+    if (dmax <= -R || dmin >= R) {
+      flush_carry(kb);
+      if (dmax <= -R) far_neg += far_sum; else far_pos += far_sum;
+    } else {
+      // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31), column sums on the matrix pipe
+      char* gw = sG + sk_w;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+          const int r = 8 * t2 + 2 * wd;
+          const uint32_t word = DS[kb][t2][wd];
+          *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
+          *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
+        }
+      typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+      const f32x4 zf4 = {0.f, 0.f, 0.f, 0.f};
+      float cs[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const char* p0 = sG + sk_r[0] + 32 * cb;
+        const char* p1 = sG + sk_r[1] + 32 * cb;
+        const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
+        const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
+        const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
+        cs[cb] = mfma16<BF16>(ones, fr, zf4)[0];
+      }
+      const bool up = (lq & 16) != 0;
+      const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
+      const int d_hi0 = k0 - mb + 1;  // diagonal of column 32
+      if (carry_valid[kb] && carry_d0[kb] != d_hi0) flush_carry(kb);
+      emit_diag(kb, c_hi + (carry_valid[kb] ? carry[kb] : 0.f), d_hi0 + lq);
+      carry[kb] = c_lo;
+      carry_d0[kb] = k0 - mb - 31;
+      carry_valid[kb] = true;
+    }
   };
 
   // general softmax stage of the step at query row mb: S, DP -> PB, DS (+ per-diagonal sums of dS)
@@ -353,47 +415,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         DS[kb][t2] = pack8<BF16>(s, t2);
       }
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        if (want_drpe) {
-          const int R = a.R;
-          const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
-          if (dmax <= -R || dmin >= R) {
-            flush_carry(kb);
-            const float acc = tree16(s);
-            if (dmax <= -R) far_neg += acc; else far_pos += acc;
-          } else {
-            // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31), column sums on the matrix pipe
-            char* gw = sG + sk_w;
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-              for (int wd = 0; wd < 4; ++wd) {
-                const int r = 8 * t2 + 2 * wd;
-                const uint32_t word = DS[kb][t2][wd];
-                *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
-                *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
-              }
-            typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-            const f32x4 zf4 = {0.f, 0.f, 0.f, 0.f};
-            float cs[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-              const char* p0 = sG + sk_r[0] + 32 * cb;
-              const char* p1 = sG + sk_r[1] + 32 * cb;
-              const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
-              const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
-              const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
-              cs[cb] = mfma16<BF16>(ones, fr, zf4)[0];
-            }
-            const bool up = (lq & 16) != 0;
-            const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
-            const int d_hi0 = k0 - mb + 1;  // diagonal of column 32
-            if (carry_valid[kb] && carry_d0[kb] != d_hi0) flush_carry(kb);
-            emit_diag(kb, c_hi + (carry_valid[kb] ? carry[kb] : 0.f), d_hi0 + lq);
-            carry[kb] = c_lo;
-            carry_d0[kb] = k0 - mb - 31;
-            carry_valid[kb] = true;
-          }
-        }
+        if (want_drpe) diag_sums(kb, mb, tree16(s));
       }
     }
   };
@@ -426,8 +448,15 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   //          transposed fragments of step i (consumed by the next iteration's gaps 0..3)
   // The VALU ops are volatile asm (see attn_fwd64.h); the youngest MFMA results they read are dP'[0] (finished by MFMA 30 of
   // the previous iteration, first read in gap 2) and dP'[1] (MFMA 31, first read in gap 18).
-  auto fast_iter = [&]<int SL>(const int j, const float cst) {
+  // BAND (round 3): the same iteration for steps that cross the T5 band (all keys visible): the bias of element (q, k) is the FMA's
+  // addend, read from this lane's padded table copy (attn_common.h) -- four 16-byte reads per key block, each issued three gaps ahead of
+  // its FMAs (the first one during the previous iteration: TN0) -- and the per-diagonal sums of the step's rounded dS follow the
+  // iteration as a block (diag_sums on DS).  A band step was the general, unpipelined iteration before: ~2.9x a pipelined step.
+  auto fast_iter = [&]<int SL, bool BAND>(const int j, const float cst) {
     constexpr uint32_t o_prev = ((SL + 3) & 3) * SLOT, o_cur = SL * SLOT, o_next = ((SL + 1) & 3) * SLOT;
+    u32x4 T[2][4];
+    uint32_t tadr1 = 0u;
+    if constexpr (BAND) T[0][0] = TN0;
     f32x16 Sn[2], DPn[2];
     [[maybe_unused]] f32x16 NL, DL;
     u32x4 PBn[2][2], DSn[2][2], qa[KK], da[KK];
@@ -491,7 +520,20 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
       if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
       if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
-      X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
+      if constexpr (BAND) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
+      else X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
+      if constexpr (BAND) {  // table entries: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
+        if constexpr (g == 1) T[0][1] = lds_rd128(tadr0 - 32u);
+        else if constexpr (g == 5) T[0][2] = lds_rd128(tadr0 - 64u);
+        else if constexpr (g == 9) T[0][3] = lds_rd128(tadr0 - 96u);
+        else if constexpr (g == 10) tadr1 = tab_addr(1, (mt0 + j) * 32);
+        else if constexpr (g == 13) T[1][0] = lds_rd128(tadr1);
+        else if constexpr (g == 18) T[1][1] = lds_rd128(tadr1 - 32u);
+        else if constexpr (g == 21) T[1][2] = lds_rd128(tadr1 - 64u);
+        else if constexpr (g == 25) T[1][3] = lds_rd128(tadr1 - 96u);
+        else if constexpr (g == 28) tadr0 = tab_addr(0, (mt0 + j + 1) * 32);  // the next step: rows 32 further down, window 32 entries lower
+        else if constexpr (g == 29) TN0 = lds_rd128(tadr0);
+      }
       if constexpr (g == 31) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
         Pv[31] = asm_exp2(X[31]);
         Dv[30] = asm_mul(Pv[30], DP[1][14]);
@@ -503,7 +545,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       // far-bin sum of the step's dS: one 16x16x32 MFMA (16 cycles of the pipe, inside the gap's slack) per four packed words once they
       // are complete — 16 v_dot2c_f32_bf16 per step measured 9 % of this kernel. The last group's words come from the asm ops just
       // above (no hazard padding for asm producers: two wait states by hand)
-      if constexpr (BIAS == FAT5_BIAS_RPE1D && (g == 12 || g == 20 || g == 28 || g == 31)) {
+      if constexpr (BIAS == FAT5_BIAS_RPE1D && !BAND && (g == 12 || g == 20 || g == 28 || g == 31)) {
         constexpr int grp = g == 31 ? 3 : (g - 12) >> 3;
         if constexpr (g == 31) asm volatile("s_nop 1" ::: "memory");
         // (asm, accumulating in place: a builtin may pick a fresh destination, and a C operand that is not the destination is still
@@ -525,6 +567,19 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
     }
     TRD = u32x4{tnd[0][0], tnd[0][1], tnd[1][0], tnd[1][1]};
     TRQ = u32x4{tnq[0][0], tnq[0][1], tnq[1][0], tnq[1][1]};
+    if constexpr (BAND && BIAS == FAT5_BIAS_RPE1D) {
+      if (want_drpe) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          float fs = 0.f;  // (a block of the step entirely beyond the band: the sum of its rounded words)
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) fs += cvt_lo<BF16>(DS[kb][t2][wd]) + cvt_hi<BF16>(DS[kb][t2][wd]);
+          diag_sums(kb, (mt0 + j) * 32, fs);
+        }
+      }
+    }
   };
 
   if (nsteps > 0) {
@@ -550,18 +605,22 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
       }
       return fast;
     };
+    // all of the wave's 64 keys visible to all 32 rows of the step (no key tail, no causal mask)?  Monotone in j: later steps see more
+    auto all_visible = [&](const int j) { return kw0 + 64 <= N && (!a.causal || kw0 + 63 <= (mt0 + j) * 32 + P); };
+    // (single-body inner loops, not one loop over `class ? A : B`: the register allocator keeps one assignment per loop and pays its
+    //  copies only at the few transitions)
     int j = 0;
     while (j < nsteps) {
       int side, side3;
       // steady state: four steps (ring slots 0..3) per trip, straight-line; the fast steps of one side are contiguous, so the
-      // first and the last step of a trip decide for all four.  Fast steps that do not fill an aligned trip run the general iteration.
+      // first and the last step of a trip decide for all four.  Steps that do not fill an aligned trip run the general iteration.
       while (j + 4 <= nsteps && (j & 3) == 0 && classify(j, side) && classify(j + 3, side3) && side3 == side) {
         const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
         if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           flush_carry(0);
           flush_carry(1);
         }
-        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(j + decltype(si)::value, cst); });
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(j + decltype(si)::value, cst); });
         j += 4;
         if constexpr (BIAS == FAT5_BIAS_RPE1D) {
           asm volatile("s_nop 15" : "+v"(facc4));  // (asm MFMA -> VALU read of its result: no padding is generated; tied to the tuple so that no read moves above it)
@@ -570,9 +629,28 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
           if (side > 0) far_pos += fsum; else far_neg += fsum;
         }
       }
-      if (j < nsteps) {
-        generic_iter(j);
-        ++j;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        // trips that touch the band but see every key (band-mode iterations)
+        while (j + 4 <= nsteps && (j & 3) == 0 && all_visible(j) && !(classify(j, side) && classify(j + 3, side3) && side3 == side)) {
+          // a trip that touches the band: the first table entries of its first step, then four band-mode iterations (the carry chain of
+          // the diagonal sums simply continues: no flush)
+          tadr0 = tab_addr(0, (mt0 + j) * 32);
+          TN0 = lds_rd128(tadr0);
+          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, true>(j + decltype(si)::value, 0.f); });
+          j += 4;
+        }
+      }
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        // (after a band trip the far side may follow at once: no general iteration in between, it would break the trips' alignment)
+        if (j < nsteps && !(j + 4 <= nsteps && (j & 3) == 0 && classify(j, side) && classify(j + 3, side3) && side3 == side)) {
+          generic_iter(j);
+          ++j;
+        }
+      } else {
+        if (j < nsteps) {
+          generic_iter(j);
+          ++j;
+        }
       }
     }
     // drain: the products of the last step
