@@ -37,8 +37,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // the 64-rows-per-wave forward takes over from this many waves of (64 rows x all keys) on (measured, tools/attn_time.py, (4,12,S,64):
 // S = 768 -- 576 waves -- 16.2 / 19.4 us without / with the T5 bias against 18.6 / 21.7 us of the 32-row body, S = 1024: 19.7 / 23.3 against
-// 22.4 / 26.1; at S = 512 -- 384 waves -- the two-waves-per-32-rows split body stays: 10.4 / 12.5 against 12.6 / 15.7)
-constexpr long kFwd64MinWaves = 512;
+// 22.4 / 26.1; at S = 512 -- 384 waves -- only its key-split variant (128-row workgroups: 192 of them) keeps up with the
+// two-waves-per-32-rows split body of attn_fwd.h: 10.4 / 11.6 against 10.4 / 12.5 us)
+constexpr long kFwd64MinWaves = 384;
 
 // kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
 inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
@@ -167,7 +168,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
   const long waves64 = bh * ((p->M + 63) / 64);  // waves of 64 query rows x all keys
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
-      (f64_env == 1 || (p->dtype == FAT5_BF16 && waves64 >= kFwd64MinWaves &&
+      // (fp16: P would overflow at 2^16 without the running maximum, so its 64-row body is the exact, unpipelined pass -- still
+      //  ahead of the 32-row body once the chip is full: 953 vs 987 us at (4,12,8192,64))
+      (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 2048) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     fn = launch_fwd64_d64;
@@ -177,7 +180,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     // slower everywhere else (S = 1024: 22.0 vs 19.7 us, 4096: 207 vs 190, 8192: 794 vs 724).  The hardware packs the workgroups of the
     // last, half-empty round two to a CU, so the finer grain buys less than a per-SIMD issue model predicts.
     const int ks_env = vsel(p->variant, FAT5_V_FWD64_KSPLIT_ON, FAT5_V_FWD64_KSPLIT_OFF);
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && waves64 > 1024 && waves64 < 2048);
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512));
     nw = ksplit ? 2 : 4;
     a.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
   }

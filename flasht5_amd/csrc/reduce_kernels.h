@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
   }
 }
 
-// One 1024-thread workgroup per head: drpe1d[h][i] = sum over the (b, key-block) partials (fixed order: four
+// One 1024-thread workgroup per head: drpe1d[h][i] = sum over the (b, key-block) partials (fixed order: up to four
 // interleaved partial chains per entry, then a fixed tree); optionally the T5 table gradient
-// dtable[bucket][h] = sum_{i: bucket[i] == bucket} drpe1d[h][i] in the same launch (8 lanes per bucket, fixed order).
+// dtable[bucket][h] = sum_{i: bucket[i] == bucket} drpe1d[h][i] in the same launch (32 lanes per bucket, fixed order).
 __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restrict__ part, float* __restrict__ out1d,
                                                            const int32_t* __restrict__ bucket, float* __restrict__ dtable,
                                                            int B, int H, int nblk, int n1, int nbuckets, int unit_begin,
@@ -88,16 +88,19 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   int bkr[5];  // (n1 <= 2 * 2048 + 1)
 #pragma unroll
   for (int u = 0; u < 5; ++u) bkr[u] = (bucket && tid + 1024 * u < n1) ? bucket[tid + 1024 * u] : 0;
-  for (int wv = tid; wv < 4 * n1; wv += 1024) {
+  // NG interleaved partial chains per entry, as many as fit ONE pass of the 1024 threads (n1 = 257: three -- a fourth would send four
+  // threads around the loop again, and every trip is a cross-XCD memory round trip the whole workgroup waits for)
+  const int NG = n1 <= 256 ? 4 : (n1 <= 341 ? 3 : (n1 <= 512 ? 2 : 1));
+  for (int wv = tid; wv < NG * n1; wv += 1024) {
     const int i = wv % n1, g = wv / n1;
     float acc = 0.f;
     // 16 partial rows per round, all loads in flight before the first add (each is a cross-XCD round trip: walking
     // them one by one cost 39 us for the 256 partial rows per head of S = 8192); adds stay in the chain's fixed order
-    for (int p0 = g; p0 < nparts; p0 += 64) {
+    for (int p0 = g; p0 < nparts; p0 += 16 * NG) {
       float vv[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int pidx = p0 + 4 * u;
+        const int pidx = p0 + NG * u;
         vv[u] = 0.f;
         if (pidx < nparts) {
           const int b = pidx / nblk, blk = pidx - b * nblk;
@@ -108,10 +111,11 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (p0 + 4 * u < nparts) acc += vv[u];
+        if (p0 + NG * u < nparts) acc += vv[u];
     }
     sv4[g * n1 + i] = acc;
   }
+  for (int wv = NG * n1 + tid; wv < 4 * n1; wv += 1024) sv4[wv] = 0.f;  // (unused chains)
 #pragma unroll
   for (int u = 0; u < 5; ++u)
     if (tid + 1024 * u < n1) sb[tid + 1024 * u] = bkr[u];
@@ -123,14 +127,17 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   }
   if (!dtable) return;
   __syncthreads();
-  // 8 lanes per bucket, each scans every 8th entry, then an in-group butterfly
-  const int sub = tid & 7;
-  for (int bk = tid >> 3; bk < nbuckets; bk += 128) {
+  // 32 lanes per bucket, each scans every 32nd entry (n1 = 257: 9 LDS round trips instead of the 33 of an 8-lane scan), then an
+  // in-group butterfly: fixed order
+  const int sub = tid & 31;
+  for (int bk = tid >> 5; bk < nbuckets; bk += 32) {
     float acc = 0.f;
-    for (int i = sub; i < n1; i += 8) acc += (sb[i] == bk) ? sv[i] : 0.f;
+    for (int i = sub; i < n1; i += 32) acc += (sb[i] == bk) ? sv[i] : 0.f;
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
     if (sub == 0) dtable[(int64_t)bk * H + h] = acc;
   }
 }
