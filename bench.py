@@ -647,6 +647,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # (rank 0 may still have been busy with its extras: everyone leaves together)
         dist.destroy_process_group()
 
 
