@@ -12,12 +12,12 @@ from test_attention_gpu import bound, gbound, _rpe_case
 pytestmark = pytest.mark.gpu
 
 
-HALF = {"on": False}  # set per test by the module fixture: the half-length (128-key / 128-row workgroup) variants of the 64-wide bodies
+HALF = {"on": False}  # set per test by the module fixture: the half-length (128-key workgroup) variant of the 64-key dK/dV body
 
 
 def _bits(kv64, q64, fwd64=None):
     from flasht5_amd import _lib
-    b = (_lib.V_KV64_HALF_ON | _lib.V_Q64_HALF_ON) if HALF["on"] else (_lib.V_KV64_HALF_OFF | _lib.V_Q64_HALF_OFF)
+    b = _lib.V_KV64_HALF_ON if HALF["on"] else _lib.V_KV64_HALF_OFF
     if kv64 is not None:
         b |= _lib.V_KV64_ON if kv64 else _lib.V_KV64_OFF
     if q64 is not None:

@@ -33,11 +33,15 @@ for S, D, H in ((512, 64, 12), (2048, 64, 12), (777, 128, 3), (1024, 32, 6)):
             bad += n_bad
 # the 64-wide pipelined bodies (attn_fwd64.h, attn_bwd64.h): forced at a mid size (many workgroups per CU in flight, ragged
 # ends), then at the size where the dispatch picks them by itself
-for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (8192, 8192, max(3, reps // 30), "-1")):
+for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (1536, 1536, reps, "split"), (900, 1300, reps, "split"),
+                           (8192, 8192, max(3, reps // 30), "-1")):
     for mode in ("none", "rpe"):
         for causal in (False, True):
             from flasht5_amd import _lib
-            _lib.set_variant((_lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON) if force == "1" else 0)
+            on = _lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON
+            # "split": two waves per 64-row block (forward) / per 64-key block (dK/dV), halves merged through LDS
+            _lib.set_variant({"1": on | _lib.V_FWD64_KSPLIT_OFF | _lib.V_KV64_HALF_OFF,
+                              "split": on | _lib.V_FWD64_KSPLIT_ON | _lib.V_KV64_HALF_ON, "-1": 0}[force])
             q, k, v, _, do = make_inputs(4, 12, M, S, 64, torch.bfloat16, None, seed=S + 7, strided=True)
             kw = {}
             table = (torch.randn(32, 12, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
@@ -53,6 +57,6 @@ for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (81
                     torch.cuda.synchronize()
                     cur = [plan.o, plan.lse, plan.dq, plan.dk, plan.dv] + ([plan.dbias] if plan.dbias is not None else [])
                     n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, cur))
-            print(f"64-wide M={M} N={S} {mode:5s} causal={int(causal)} x{reps2}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
+            print(f"64-wide[{force}] M={M} N={S} {mode:5s} causal={int(causal)} x{reps2}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
             bad += n_bad
 print("TOTAL MISMATCHES", bad)
