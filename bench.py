@@ -78,9 +78,34 @@ def eager_autograd(S, device, iters=200):
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
-    return {"ms_per_step": round(t / iters * 1e3, 5), "host_enqueue_ms_per_step": round(t_host / iters * 1e3, 5),
-            "tflops": round(3.5 * fwd_flops(S) / (t / iters) / 1e12, 2),
-            "what": "flash_attention_v2_rpe + torch.autograd.grad (q, k, v, table), eager, no plan, no graph"}
+    out = {"ms_per_step": round(t / iters * 1e3, 5), "host_enqueue_ms_per_step": round(t_host / iters * 1e3, 5),
+           "tflops": round(3.5 * fwd_flops(S) / (t / iters) / 1e12, 2),
+           "what": "flash_attention_v2_rpe + torch.autograd.grad (q, k, v, table), eager, no plan, no graph"}
+    # where the host time goes: the forward call, the backward node's own work (allocations + C-ABI call), and the rest =
+    # torch.autograd.grad itself (graph task, hand-over to the device thread and back: paid once per backward pass of a model,
+    # not once per attention layer)
+    from flasht5_amd import _lib, positional_encoding as pe
+    nat = _lib.native()
+    if nat is not None:
+        def host_us(fn, n=500):
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            dt = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return round(dt / n * 1e6, 1)
+        idx = pe.bucket_index32(pe.rpe_radius(MAX_DISTANCE), True, NUM_BUCKETS, MAX_DISTANCE, q.device)
+        R = pe.rpe_radius(MAX_DISTANCE)
+        qd, kd, vd, td = q.detach(), k.detach(), v.detach(), table.detach()
+        r1 = nat.rpe1d_of(td, idx, R, NUM_BUCKETS)
+        o, L = nat.attn_fwd(qd, kd, vd, None, r1, R, False, 0.125)
+        out["host_us"] = {"forward_call": host_us(lambda: flash_attention_v2_rpe(q, k, v, table, True, NUM_BUCKETS, MAX_DISTANCE, False, 0.125)),
+                          "backward_node": host_us(lambda: nat.attn_bwd(o, do, qd, kd, vd, None, r1, R, L, False, 0.125, True, idx, NUM_BUCKETS))}
+        out["host_us"]["autograd_engine"] = round(out["host_enqueue_ms_per_step"] * 1e3 - out["host_us"]["forward_call"] - out["host_us"]["backward_node"], 1)
+    return out
 
 
 def graph_time(fn, it=20):

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <algorithm>
 
 #include "../../include/fat5.h"
 #include "attn_common.h"
@@ -654,23 +655,38 @@ int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0
   return FAT5_OK;
 }
 
+// rows of one slab of fold_weights_bwd_kernel: at most 64 slabs, at least 64 rows each (a multiple of the 32 row phases)
+static int fold_bwd_rows_per(int64_t ntot) { return (int)std::max<int64_t>(64, ((ntot + 63) / 64 + 31) / 32 * 32); }
+size_t fat5_fold_weights_bwd_scratch_bytes(int64_t n_total, int64_t K) {
+  if (n_total <= 0 || K <= 0) return 0;
+  const int rp = fold_bwd_rows_per(n_total);
+  return (size_t)((n_total + rp - 1) / rp) * (size_t)K * sizeof(float);
+}
+
 int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0,
                           int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
-                          void* stream_) {
+                          void* scratch, size_t scratch_bytes, void* stream_) {
   if (!dwg || !w0 || !g || n0 <= 0 || n1 < 0 || n2 < 0 || (n1 > 0 && !w1) || (n2 > 0 && !w2)) return fail(FAT5_EINVAL, "fold_weights_bwd: bad arguments");
   if (dtype != FAT5_F16 && dtype != FAT5_BF16) return fail(FAT5_EINVAL, "fold_weights_bwd: 16-bit dtypes only");
   if (K <= 0 || K % 64 != 0 || ld0 % 8 || ld1 % 8 || ld2 % 8) return fail(FAT5_EINVAL, "fold_weights_bwd: K must be a multiple of 64, row strides of 8");
   const void* ptrs[] = {dwg, w0, w1, w2, g, dw0, dw1, dw2};
   for (const void* q : ptrs)
     if (q && !aligned16(q)) return fail(FAT5_EINVAL, "fold_weights_bwd: 16-byte aligned bases");
-  if (n0 + n1 + n2 > 0x7fffffffLL) return fail(FAT5_EINVAL, "fold_weights_bwd: too large");
+  const int64_t ntot = n0 + n1 + n2;
+  if (ntot > 0x7fffffffLL) return fail(FAT5_EINVAL, "fold_weights_bwd: too large");
+  if (dg && (!scratch || scratch_bytes < fat5_fold_weights_bwd_scratch_bytes(ntot, K)))
+    return fail(FAT5_EWORKSPACE, "fold_weights_bwd: dg needs %zu bytes of scratch (fat5_fold_weights_bwd_scratch_bytes)",
+                fat5_fold_weights_bwd_scratch_bytes(ntot, K));
   hipStream_t stream = (hipStream_t)stream_;
-  const unsigned grid = (unsigned)(K / 64);
-#define FOLDB(BF)                                                                                                               \
-  hipLaunchKernelGGL(fold_weights_bwd_kernel<BF>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)dwg, (const uint16_t*)w0,      \
-                     (const uint16_t*)w1, (const uint16_t*)w2, (int)n0, (int)n1, (int)n2, ld0, ld1, ld2, (const uint16_t*)g,     \
-                     (uint16_t*)dw0, (uint16_t*)dw1, (uint16_t*)dw2, (uint16_t*)dg, (int)K)
-  if (dtype == FAT5_BF16) FOLDB(true); else FOLDB(false);
+  const int rp = fold_bwd_rows_per(ntot);
+  const unsigned nslab = (unsigned)((ntot + rp - 1) / rp);
+  float* part = dg ? (float*)scratch : nullptr;
+#define FOLDB(BF)                                                                                                                          \
+  hipLaunchKernelGGL(fold_weights_bwd_kernel<BF>, dim3((unsigned)(K / 64), nslab), dim3(256), 0, stream, (const uint16_t*)dwg,                 \
+                     (const uint16_t*)w0, (const uint16_t*)w1, (const uint16_t*)w2, (int)n0, (int)n1, (int)n2, ld0, ld1, ld2,              \
+                     (const uint16_t*)g, (uint16_t*)dw0, (uint16_t*)dw1, (uint16_t*)dw2, part, (int)K, rp);                                \
+  if (dg) hipLaunchKernelGGL(fold_weights_dg_kernel<BF>, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, stream, part, (uint16_t*)dg, (int)K, (int)nslab)
+  if (dtype == FAT5_BF16) { FOLDB(true); } else { FOLDB(false); }
 #undef FOLDB
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "fold_weights_bwd launch");

@@ -61,14 +61,16 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const uint16_t* __res
 
 // Backward of the folded weight: dwg = d(W_stack diag g) (N, K) as it comes out of the dout^T xhat GEMM ->
 //   dW_i[n][k] = dwg[n][k] * g[k]   (written per source weight),   dg[k] = sum_n dwg[n][k] * W_stack[n][k]  (fp32 sum, fixed order).
-// One workgroup = 64 columns x all rows: 8 column chunks x 32 row phases; the 32 partial sums of a column meet in LDS.
+// One workgroup = 64 columns x one slab of `rows_per` rows (8 column chunks x 32 row phases; the 32 partial sums of a column meet in
+// LDS) and writes the slab's column sums to part[slab][k]; fold_weights_dg_kernel adds the slabs in order.  (Round 3, first version:
+// one workgroup per 64 columns walking ALL rows -- 12 workgroups for K = 768: 58 us per call, 3.5 ms of the 21 ms config-5 step.)
 template <bool BF16>
 __global__ __launch_bounds__(256) void fold_weights_bwd_kernel(const uint16_t* __restrict__ dwg, const uint16_t* __restrict__ w0,
                                                                const uint16_t* __restrict__ w1, const uint16_t* __restrict__ w2, int n0,
                                                                int n1, int n2, int64_t ld0, int64_t ld1, int64_t ld2,
                                                                const uint16_t* __restrict__ g, uint16_t* __restrict__ dw0,
                                                                uint16_t* __restrict__ dw1, uint16_t* __restrict__ dw2,
-                                                               uint16_t* __restrict__ dg, int K) {
+                                                               float* __restrict__ part, int K, int rows_per) {
   __shared__ float red[32][65];
   const int c8 = threadIdx.x & 7, ph = threadIdx.x >> 3;
   const int col = blockIdx.x * 64 + 8 * c8;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void fold_weights_bwd_kernel(const uint16_t* _
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const int ntot = n0 + n1 + n2;
-  for (int n = ph; n < ntot; n += 32) {
+  const int r0 = blockIdx.y * rows_per, r1 = min(ntot, r0 + rows_per);
+  for (int n = r0 + ph; n < r1; n += 32) {
     const uint16_t* src;
     uint16_t* dst;
     if (n < n0) { src = w0 + (int64_t)n * ld0; dst = dw0 ? dw0 + (int64_t)n * K : nullptr; }
@@ -97,15 +100,32 @@ __global__ __launch_bounds__(256) void fold_weights_bwd_kernel(const uint16_t* _
     }
     if (dst) *reinterpret_cast<u32x4*>(dst + col) = ov;
   }
+  if (!part) return;
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[ph][8 * c8 + j] = acc[j];
   __syncthreads();
-  if (dg && threadIdx.x < 64) {
+  if (threadIdx.x < 64) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
-    dg[blockIdx.x * 64 + threadIdx.x] = to16<BF16>(s);
+    part[(int64_t)blockIdx.y * K + blockIdx.x * 64 + threadIdx.x] = s;
   }
+}
+
+// dg[k] = sum over the slabs (in order) of part[slab][k]
+template <bool BF16>
+__global__ __launch_bounds__(256) void fold_weights_dg_kernel(const float* __restrict__ part, uint16_t* __restrict__ dg, int K, int nslab) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int s0 = 0; s0 < nslab; s0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (s0 + u < nslab) ? part[(int64_t)(s0 + u) * K + k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  dg[k] = to16<BF16>(s);
 }
 
 struct LinArgs {

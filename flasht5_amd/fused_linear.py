@@ -108,10 +108,11 @@ class RMSNormLinear(torch.autograd.Function):
             n = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
             ld = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
             dptr = [t.data_ptr() for t in dWs] + [None] * (3 - len(ws))
+            scratch = torch.empty((max(int(lib.fat5_fold_weights_bwd_scratch_bytes(sum(n), K)), 4) // 4,), dtype=torch.float32, device=x2.device)
             with _lib.on_device(x2.device):
                 _lib.check(lib.fat5_fold_weights_bwd(dwg.data_ptr(), ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2],
                                                      gq.data_ptr(), dptr[0], dptr[1], dptr[2], dgq.data_ptr(), K, _lib.dtype_code(x2.dtype),
-                                                     _lib.stream_ptr(x2.device)), "fat5_fold_weights_bwd")
+                                                     scratch.data_ptr(), scratch.numel() * 4, _lib.stream_ptr(x2.device)), "fat5_fold_weights_bwd")
             dg = dgq.to(g.dtype) if ctx.needs_input_grad[1] else None
             dWs = [(t.to(w.dtype) if ctx.needs_input_grad[3 + i] else None) for i, (t, w) in enumerate(zip(dWs, weights))]
         return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None, dg, None, *dWs)

@@ -29,8 +29,8 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 110 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
-                            AdamWScale state dtype / flags */
+#define FAT5_VERSION 111 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+                            AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch */
 
 enum fat5_status {
   FAT5_OK = 0,
@@ -211,13 +211,15 @@ int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0
  *    x_dtype tensors, n <= 2048 (16-bit) / 1024 (fp32).
  *  - fat5_fold_weights_bwd: dwg (N, K) = dout^T xhat, the gradient of the folded weight [w0; w1; w2] diag(g) ->
  *    dw_i = dwg rows * g (contiguous (n_i, K), any of them may be NULL), dg[k] = sum_n dwg[n][k] * w[n][k] (fp32, fixed order; may be NULL).
- *    K a multiple of 64. */
+ *    K a multiple of 64.  dg needs `scratch` of fat5_fold_weights_bwd_scratch_bytes(n0 + n1 + n2, K) bytes (row slabs are summed by
+ *    separate workgroups, the slab sums added in order by a second launch); contents need no initialisation. */
 int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n,
                           int64_t gy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, int64_t xhat_row_stride, int dtype,
                           void* hip_stream);
 int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0,
                           int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
-                          void* hip_stream);
+                          void* scratch, size_t scratch_bytes, void* hip_stream);
+size_t fat5_fold_weights_bwd_scratch_bytes(int64_t n_total, int64_t K);
 
 /*
  * Cross-entropy + label smoothing + z-loss.  Replaces flasht5::cross_entropy_triton_fwd / _bwd

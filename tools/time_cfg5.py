@@ -29,6 +29,10 @@ def measure(flag, iters=10):
         for _ in range(3): step()
         torch.cuda.synchronize()
     ev = prof.key_averages()
+    if "--top" in sys.argv:  # where the kernel time of one step goes: the 30 largest kernels by total time
+        tot = sum(e.device_time_total for e in ev)
+        for e in sorted(ev, key=lambda e: -e.device_time_total)[:30]:
+            print(f"  {e.device_time_total / 3 / 1e3:8.3f} ms {100 * e.device_time_total / tot:5.1f}%  x{e.count // 3:4d}  {e.key[:110]}")
     ktime = sum(e.device_time_total for e in ev) / 3 / 1e3
     launches = sum(e.count for e in ev) / 3
     norm_launches = sum(e.count for e in ev if "rmsnorm" in e.key) / 3
