@@ -19,6 +19,7 @@ from .rms_norm import fast_rms_layernorm, Fast_RMS_Layernorm, fused_add_rms_laye
 from .cross_entropy_loss import cross_entropy_loss, CrossEntropyLoss  # noqa: E402
 from .lm_head_cross_entropy import lm_head_cross_entropy, LMHeadCrossEntropy  # noqa: E402
 from .fused_linear import rmsnorm_linear, linear_residual, RMSNormLinear, LinearResidual  # noqa: E402
+from .gated_act import gated_act, gated_act_packed  # noqa: E402
 from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_from_table,  # noqa: E402
                                   RelativePositionalEncoding)
 

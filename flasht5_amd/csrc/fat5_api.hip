@@ -693,6 +693,68 @@ int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const
   return FAT5_OK;
 }
 
+// ---- gated activation (rowwise_kernels.h) ----
+static int gated_act_check(const char* what, int64_t rows, int64_t F, int act, int dtype, std::initializer_list<const void*> ptrs,
+                           std::initializer_list<int64_t> strides) {
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "%s: bad dtype", what);
+  if (act != FAT5_ACT_GELU_TANH && act != FAT5_ACT_RELU) return fail(FAT5_EINVAL, "%s: act %d", what, act);
+  const int v = vec_of(dtype);
+  if (rows < 0 || F <= 0 || F % v || F > 0x7fffffffLL) return fail(FAT5_EINVAL, "%s: F must be a positive multiple of %d", what, v);
+  for (const void* q : ptrs)
+    if (!q || !aligned16(q)) return fail(FAT5_EINVAL, "%s: null or unaligned pointer (16-byte aligned bases)", what);
+  for (int64_t st : strides)
+    if (st % v) return fail(FAT5_EINVAL, "%s: row strides must be multiples of %d elements", what, v);
+  return FAT5_OK;
+}
+int fat5_gated_act_fwd(const void* h0, const void* h1, void* out, int64_t rows, int64_t F, int64_t s0, int64_t s1, int64_t so, int act,
+                       int dtype, void* stream_) {
+  int rc = gated_act_check("gated_act_fwd", rows, F, act, dtype, {h0, h1, out}, {s0, s1, so});
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int v = vec_of(dtype);
+  const unsigned gx = (unsigned)((F / v + 255) / 256);
+  const size_t esz = dtype == FAT5_F32 ? 4 : 2;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {  // (grid.y limit)
+    const unsigned gy = (unsigned)std::min<int64_t>(65535, rows - r0);
+    const char *a = (const char*)h0 + r0 * s0 * esz, *b = (const char*)h1 + r0 * s1 * esz;
+    char* o = (char*)out + r0 * so * esz;
+    dispatch_dtype(dtype, [&](auto dt_) {
+      constexpr int DT = decltype(dt_)::value;
+      if (act == FAT5_ACT_RELU)
+        hipLaunchKernelGGL((gated_act_fwd_kernel<DT, FAT5_ACT_RELU>), dim3(gx, gy), dim3(256), 0, stream, a, b, o, (int)F, s0, s1, so);
+      else
+        hipLaunchKernelGGL((gated_act_fwd_kernel<DT, FAT5_ACT_GELU_TANH>), dim3(gx, gy), dim3(256), 0, stream, a, b, o, (int)F, s0, s1, so);
+    });
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gated_act_fwd launch");
+  return FAT5_OK;
+}
+int fat5_gated_act_bwd(const void* dout, const void* h0, const void* h1, void* dh0, void* dh1, int64_t rows, int64_t F, int64_t sd, int64_t s0,
+                       int64_t s1, int64_t sg0, int64_t sg1, int act, int dtype, void* stream_) {
+  int rc = gated_act_check("gated_act_bwd", rows, F, act, dtype, {dout, h0, h1, dh0, dh1}, {sd, s0, s1, sg0, sg1});
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int v = vec_of(dtype);
+  const unsigned gx = (unsigned)((F / v + 255) / 256);
+  const size_t esz = dtype == FAT5_F32 ? 4 : 2;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const unsigned gy = (unsigned)std::min<int64_t>(65535, rows - r0);
+    const char *g = (const char*)dout + r0 * sd * esz, *a = (const char*)h0 + r0 * s0 * esz, *b = (const char*)h1 + r0 * s1 * esz;
+    char *o0 = (char*)dh0 + r0 * sg0 * esz, *o1 = (char*)dh1 + r0 * sg1 * esz;
+    dispatch_dtype(dtype, [&](auto dt_) {
+      constexpr int DT = decltype(dt_)::value;
+      if (act == FAT5_ACT_RELU)
+        hipLaunchKernelGGL((gated_act_bwd_kernel<DT, FAT5_ACT_RELU>), dim3(gx, gy), dim3(256), 0, stream, g, a, b, o0, o1, (int)F, sd, s0, s1, sg0, sg1);
+      else
+        hipLaunchKernelGGL((gated_act_bwd_kernel<DT, FAT5_ACT_GELU_TANH>), dim3(gx, gy), dim3(256), 0, stream, g, a, b, o0, o1, (int)F, sd, s0, s1, sg0, sg1);
+    });
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "gated_act_bwd launch");
+  return FAT5_OK;
+}
+
 int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n, int64_t gy_stride,
                           int64_t x_stride, int64_t dx_stride, int64_t xhat_stride, int dtype, void* stream_) {
   if (!gy || !x || !rstd || !dx || !xhat) return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: null pointer");

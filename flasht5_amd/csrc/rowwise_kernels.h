@@ -306,6 +306,75 @@ __global__ __launch_bounds__(256) void rmsnorm_unit_bwd_kernel(const void* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Gated activation of the T5 v1.1 feed-forward (reference FlashT5DenseGatedAct.forward, modeling_flash_t5.py:139-142:
+// act(wi_0(x)) * wi_1(x) with act = GELU(approximate='tanh') or ReLU, :134): one pass over the two projections instead of an
+// activation kernel + a multiply (forward) and an activation-backward kernel + two multiplies + a concatenation (backward).
+// h0 / h1 may be the two halves of ONE (rows, 2F) projection output (fused_linear.py stacks wi_0 and wi_1), and dh0 / dh1 the two
+// halves of its gradient: everything is addressed by row strides.  fp32 arithmetic, one rounding per output element.
+//   gelu_tanh(x) = 0.5 x (1 + tanh(k (x + c x^3))),  k = sqrt(2 / pi),  c = 0.044715   (torch.nn.GELU(approximate='tanh'))
+// ---------------------------------------------------------------------------------------------
+// 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + e^(-2u)) =: s, and 1 - s = e^(-2u) s: no cancellation in either tail
+// (1 - 2 / (1 + e^(2u)) loses the small e^(2u) against the 1 for u << 0: 1e-3 relative at u = -5).
+template <int ACT>
+FAT5_DEV void act_and_grad(float x, float& a, float& da) {
+  if constexpr (ACT == FAT5_ACT_RELU) {
+    a = fmaxf(x, 0.f);
+    da = x > 0.f ? 1.f : 0.f;
+  } else {
+    constexpr float k = 0.7978845608028654f, c = 0.044715f;
+    const float x2 = x * x;
+    const float u = fmaxf(k * x * fmaf(c, x2, 1.f), -40.f);  // (e^80 is finite in fp32: below, s is 0 to every output precision anyway)
+    const float e = __builtin_amdgcn_exp2f(u * -2.885390081777927f);  // e^(-2u)
+    const float sg = __builtin_amdgcn_rcpf(1.f + e);
+    a = x * sg;
+    da = fmaf(x * sg * (e * sg), 2.f * k * fmaf(3.f * c, x2, 1.f), sg);
+  }
+}
+// one thread = one 16-byte chunk; blockIdx.y = row
+template <int DT, int ACT>
+__global__ __launch_bounds__(256) void gated_act_fwd_kernel(const void* __restrict__ h0_, const void* __restrict__ h1_, void* __restrict__ out_,
+                                                            int F, int64_t s0, int64_t s1, int64_t so) {
+  typedef Elem<DT> X;
+  constexpr int VEC = X::VEC;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c >= F) return;
+  const int64_t row = blockIdx.y;
+  float a[VEC], b[VEC], o[VEC];
+  X::load(reinterpret_cast<const typename X::T*>(h0_) + row * s0 + c, a);
+  X::load(reinterpret_cast<const typename X::T*>(h1_) + row * s1 + c, b);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float act, dact;
+    act_and_grad<ACT>(a[j], act, dact);
+    o[j] = act * b[j];
+  }
+  X::store(reinterpret_cast<typename X::T*>(out_) + row * so + c, o);
+}
+template <int DT, int ACT>
+__global__ __launch_bounds__(256) void gated_act_bwd_kernel(const void* __restrict__ do_, const void* __restrict__ h0_, const void* __restrict__ h1_,
+                                                            void* __restrict__ dh0_, void* __restrict__ dh1_, int F, int64_t sd, int64_t s0,
+                                                            int64_t s1, int64_t sg0, int64_t sg1) {
+  typedef Elem<DT> X;
+  constexpr int VEC = X::VEC;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c >= F) return;
+  const int64_t row = blockIdx.y;
+  float g[VEC], a[VEC], b[VEC], d0[VEC], d1[VEC];
+  X::load(reinterpret_cast<const typename X::T*>(do_) + row * sd + c, g);
+  X::load(reinterpret_cast<const typename X::T*>(h0_) + row * s0 + c, a);
+  X::load(reinterpret_cast<const typename X::T*>(h1_) + row * s1 + c, b);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float act, dact;
+    act_and_grad<ACT>(a[j], act, dact);
+    d0[j] = g[j] * b[j] * dact;
+    d1[j] = g[j] * act;
+  }
+  X::store(reinterpret_cast<typename X::T*>(dh0_) + row * sg0 + c, d0);
+  X::store(reinterpret_cast<typename X::T*>(dh1_) + row * sg1 + c, d1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // RMSNorm backward: persistent waves over strided rows; dw accumulated per lane in registers,
 // reduced across the workgroup's waves through LDS, one fp32 partial row per workgroup.
 //   NCH = max 16-byte chunks per lane (n <= NCH * 64 * VEC)

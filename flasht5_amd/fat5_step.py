@@ -54,6 +54,7 @@ class FAT5Config:
     fuse_add_norm: bool = False            # every residual add runs inside the next pre-norm (fused_add_rms_layernorm): same bits, fewer passes
     fuse_norm_linear: bool = False         # pre-norm inside the projection GEMM, residual add as the output projection's epilogue
                                            # (fused_linear.py / fat5_linear_fused): no stand-alone norm or add launch in the blocks
+    fuse_gated_act: bool = True            # act(wi_0 x) * wi_1 x in one kernel forward, one backward (gated_act.py / fat5_gated_act_*)
     is_decoder: bool = False
 
 
@@ -67,9 +68,17 @@ class FAT5GatedAct(nn.Module):  # reference FlashT5DenseGatedAct / FlashT5DenseA
         else:
             self.wi = nn.Linear(c.d_model, c.d_ff, bias=False)
         self.act = nn.GELU(approximate="tanh") if c.use_gelu_act else nn.ReLU()
+        self.act_name = "gelu_tanh" if c.use_gelu_act else "relu"
+        self.fuse = bool(getattr(c, "fuse_gated_act", True))
+
+    def fused_ok(self, x):
+        return self.fuse and x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
 
     def forward(self, x):
         if self.glu:
+            if self.fused_ok(x) and self.wi_0.weight.shape[0] % 8 == 0:
+                from .gated_act import gated_act
+                return gated_act(self.wi_0(x), self.wi_1(x), self.act_name)
             return self.act(self.wi_0(x)) * self.wi_1(x)
         return self.act(self.wi(x))
 
@@ -98,8 +107,12 @@ class FAT5LayerFF(nn.Module):  # :148-164
         a = self.act
         if a.glu:
             g = rmsnorm_linear(h, self.layer_norm.weight, (a.wi_0.weight, a.wi_1.weight), self.layer_norm.variance_epsilon)
-            g0, g1 = g.split(a.wi_0.weight.shape[0], dim=-1)
-            t = a.act(g0) * g1
+            if a.fused_ok(g) and a.wi_0.weight.shape[0] % 8 == 0:
+                from .gated_act import gated_act_packed
+                t = gated_act_packed(g, a.act_name)  # (its gradient is ONE (…, 2 d_ff) tensor: no concatenation in front of the backward GEMMs)
+            else:
+                g0, g1 = g.split(a.wi_0.weight.shape[0], dim=-1)
+                t = a.act(g0) * g1
         else:
             t = a.act(rmsnorm_linear(h, self.layer_norm.weight, a.wi.weight, self.layer_norm.variance_epsilon))
         return linear_residual(t, self.wo.weight, h)

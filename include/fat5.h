@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define FAT5_VERSION 111 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
-                            AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch */
+                            AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_* */
 
 enum fat5_status {
   FAT5_OK = 0,
@@ -220,6 +220,21 @@ int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const
                           int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
                           void* scratch, size_t scratch_bytes, void* hip_stream);
 size_t fat5_fold_weights_bwd_scratch_bytes(int64_t n_total, int64_t K);
+
+/*
+ * Gated activation of the T5 v1.1 feed-forward: out = act(h0) * h1 (reference FlashT5DenseGatedAct.forward,
+ * src/model/modeling_flash_t5.py:139-142; act = GELU(approximate='tanh') when config.use_gelu_act, else ReLU, :134) and its backward
+ *   dh0 = dout * h1 * act'(h0),  dh1 = dout * act(h0)
+ * in one pass each.  All tensors (rows, F) in `dtype`, addressed by row strides (elements): h0 / h1 may be the halves of one
+ * (rows, 2F) projection output and dh0 / dh1 the halves of its gradient.  F and the strides multiples of the 16-byte vector
+ * (8 elements; 4 for fp32), bases 16-byte aligned.
+ */
+enum fat5_act { FAT5_ACT_GELU_TANH = 0, FAT5_ACT_RELU = 1 };
+int fat5_gated_act_fwd(const void* h0, const void* h1, void* out, int64_t rows, int64_t F, int64_t h0_row_stride, int64_t h1_row_stride,
+                       int64_t out_row_stride, int act, int dtype, void* hip_stream);
+int fat5_gated_act_bwd(const void* dout, const void* h0, const void* h1, void* dh0, void* dh1, int64_t rows, int64_t F,
+                       int64_t dout_row_stride, int64_t h0_row_stride, int64_t h1_row_stride, int64_t dh0_row_stride,
+                       int64_t dh1_row_stride, int act, int dtype, void* hip_stream);
 
 /*
  * Cross-entropy + label smoothing + z-loss.  Replaces flasht5::cross_entropy_triton_fwd / _bwd

@@ -11,3 +11,4 @@ from .rmsnorm import rmsnorm_fwd_oracle, rmsnorm_bwd_oracle, rmsnorm_eager
 from .cross_entropy import ce_fwd_oracle, ce_bwd_oracle
 from .adamw_scale import adamw_scale_step
 from .fused_linear import rmsnorm_linear_oracle, rmsnorm_linear_reference_rounding, linear_residual_oracle
+from .gated_act import gated_act_oracle, gated_act_bwd_oracle

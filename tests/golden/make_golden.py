@@ -422,10 +422,44 @@ def gen_triton_round3():
     gen_triton_case("triton_mgtn_nc_bh_fp16", 26, 2, 2, 96, 48, 64, "bh", False, 1.0)
 
 
+def gen_gated_act():
+    """the reference's FlashT5DenseGatedAct (modeling_flash_t5.py:128-146) itself, GELU(tanh) and ReLU, fp32 and bf16: the two
+    projection outputs (captured by forward hooks), the module output and autograd's gradients of the projections"""
+    from src.model.configuration_flash_t5 import FlashT5Config
+    from src.model.modeling_flash_t5 import FlashT5DenseGatedAct
+    out = {}
+    for act in ("gelu_tanh", "relu"):
+        for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+            torch.manual_seed(40 + len(out))
+            cfg = FlashT5Config(d_model=64, d_ff=128, dropout_rate=0.0, use_gelu_act=(act == "gelu_tanh"), use_glu_mlp=True)
+            m = FlashT5DenseGatedAct(cfg).to(dt).eval()
+            with torch.no_grad():  # projections of a few units spread: both GELU tails and the region around 0
+                m.wi_0.weight.mul_(6.0)
+            x = torch.randn(24, 64).to(dt)
+            cap = {}
+            def grab(key):
+                def hook(mod, inp, o):
+                    o.retain_grad()
+                    cap[key] = o
+                return hook
+            hooks = [m.wi_0.register_forward_hook(grab("h0")), m.wi_1.register_forward_hook(grab("h1"))]
+            y = m(x)
+            dy = torch.randn(y.shape).to(dt)
+            y.backward(dy)
+            for h in hooks:
+                h.remove()
+            k = f"{act}_{tag}_"
+            for name, t in (("h0", cap["h0"]), ("h1", cap["h1"]), ("out", y), ("dout", dy), ("dh0", cap["h0"].grad), ("dh1", cap["h1"].grad)):
+                out[k + name] = t.detach().float().numpy()  # (bf16 values are exact in fp32)
+            e = (oracle.gated_act_oracle(cap["h0"].detach(), cap["h1"].detach(), act) - y.detach().double()).abs().max().item()
+            print(f"gated_act {act} {tag}: |oracle - reference| = {e:.3e}")
+    save("gated_act", **out)
+
+
 def main():
     torch.set_num_threads(8)
     only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
-    if only is not None:  # regenerate a subset: `--only adamw,triton3,mgtn` (every generator is seeded: the others are unchanged)
+    if only is not None:  # regenerate a subset: `--only adamw,triton3,mgtn,gated` (every generator is seeded: the others are unchanged)
         f16 = torch.float16
         if "adamw" in only:
             gen_adamw()
@@ -433,6 +467,8 @@ def main():
             gen_attn_case("attn_mgtn_c_1h_fp16", 5, 2, 2, 96, 64, 64, f16, "1h", True, 1.0)
         if "triton3" in only:
             gen_triton_round3()
+        if "gated" in only:
+            gen_gated_act()
         return
     gen_rpe()
     f32, f16, bf16 = torch.float32, torch.float16, torch.bfloat16
@@ -457,6 +493,7 @@ def main():
     gen_rmsnorm()
     gen_ce()
     gen_adamw()
+    gen_gated_act()
 
 
 if __name__ == "__main__":

@@ -201,3 +201,24 @@ def test_adamw_scale_golden(name):
         assert torch.equal(p, _t(z[f"{name}__p_{i}"])) and torch.equal(m, _t(z[f"{name}__m_{i}"])) and torch.equal(v, _t(z[f"{name}__v_{i}"]))
         if k is not None:
             assert torch.equal(k, _t(z[f"{name}__k_{i}"]))
+
+
+@pytest.mark.parametrize("act", ["gelu_tanh", "relu"])
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_gated_act_golden(act, tag):
+    """oracle/gated_act.py against the reference's own FlashT5DenseGatedAct (fixture: tests/golden/make_golden.py::gen_gated_act,
+    projections captured by hooks, gradients by autograd) and against torch's tanh GELU"""
+    z = load("gated_act")
+    g = {k: torch.from_numpy(z[f"{act}_{tag}_{k}"]) for k in ("h0", "h1", "out", "dout", "dh0", "dh1")}
+    ulp = 2.0 ** -8 if tag == "bf16" else 2.0 ** -23
+    out = oracle.gated_act_oracle(g["h0"], g["h1"], act)
+    dh0, dh1 = oracle.gated_act_bwd_oracle(g["dout"], g["h0"], g["h1"], act)
+    # the reference rounds act(h0) and the product (and, backward, autograd's intermediate products) to the tensor dtype: a few ulps
+    for got, ref, n in ((out, g["out"], 2), (dh0, g["dh0"], 4), (dh1, g["dh1"], 2)):
+        err = (got - ref.double()).abs()
+        tol = n * ulp * ref.double().abs().clamp_min(1e-3) + (3e-6 if tag == "fp32" else 1e-3)  # (fp32: tanhf's own error where 1 + tanh cancels)
+        assert bool((err <= tol).all()), float((err / tol).max())
+    if act == "gelu_tanh":
+        x = torch.linspace(-12, 12, 4001, dtype=torch.float64)
+        a = oracle.gated_act_oracle(x, torch.ones_like(x), act)
+        assert float((a - torch.nn.functional.gelu(x, approximate="tanh")).abs().max()) < 1e-12
