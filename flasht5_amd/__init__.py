@@ -26,6 +26,6 @@ from .positional_encoding import (relative_position_bucket, compute_bias, rpe1d_
 from .attention_module import FlashT5Attention  # noqa: E402
 from .modules import FlashT5LayerNorm, FlashT5CrossEntropyLoss  # noqa: E402
 from .adamw_scaled import AdamWScale  # noqa: E402
-from .fat5_step import FAT5Config, FAT5ForConditionalGeneration, allreduce_gradients, train_step  # noqa: E402
+from .fat5_step import FAT5Config, FAT5ForConditionalGeneration, allreduce_gradients, train_step, GraphedTrainStep  # noqa: E402
 
 __version__ = "0.1.0"

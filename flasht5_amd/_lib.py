@@ -49,7 +49,7 @@ EXPORTS = (
     "fat5_attn_bwd_stages", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
     "fat5_ce_fwd", "fat5_ce_bwd", "fat5_linear_fused", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_fold_weights_bwd_scratch_bytes", "fat5_rmsnorm_unit_bwd", "fat5_gated_act_fwd", "fat5_gated_act_bwd",
-    "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
+    "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_scale_step_dev", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
 )
 
 _lib = None
@@ -113,6 +113,8 @@ def load():
     f64 = ctypes.c_double
     lib.fat5_adamw_scale_step.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, i32, vp]
     lib.fat5_adamw_scale_step_clipped.restype = ctypes.c_int
+    lib.fat5_adamw_scale_step_dev.restype = ctypes.c_int
+    lib.fat5_adamw_scale_step_dev.argtypes = [vp, i32, i32, vp, vp, f64, f64, f64, i32, i32, i32, vp, vp]
     lib.fat5_adamw_scale_step_clipped.argtypes = [vp, i32, i32, vp, f64, f64, f64, f64, f64, i32, i32, i32, vp, vp]
     lib.fat5_adamw_grad_sumsq.restype = ctypes.c_int
     lib.fat5_adamw_grad_sumsq.argtypes = [vp, i32, i32, vp, i32, vp]

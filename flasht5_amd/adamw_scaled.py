@@ -74,6 +74,11 @@ class AdamWScale(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing:  # (a step recorded into a HIP graph: see graph_advance)
+            self._graph_jobs, self._graph_keep = [], []
+            for a in getattr(self, "_graph_arena", {}).values():
+                a[1] = 0
         jobs = []  # one per (group, device, dtype, kahan) bucket: descriptor table on the device, launched below
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -88,6 +93,9 @@ class AdamWScale(Optimizer):
                 if not p.is_cuda:
                     raise RuntimeError("flasht5_amd.AdamWScale needs parameters on the HIP device (no CPU fallback)")
                 state = self.state[p]
+                if capturing and "kahan_comp" not in state:
+                    raise RuntimeError("AdamWScale: the optimizer state must exist before a step is captured in a graph "
+                                       "(run one eager step first, or call init_state())")
                 if "kahan_comp" not in state:  # reference :96-113
                     # (the reference keeps `step` on p.device; it is only ever read on the host -- beta ** step -- so it lives there)
                     state["step"] = torch.tensor(0, dtype=torch.int32)
@@ -108,7 +116,14 @@ class AdamWScale(Optimizer):
                     raise RuntimeError("AdamWScale: parameters and gradients must be contiguous")
                 g = p.grad if p.grad.dtype == p.dtype else p.grad.to(p.dtype)
                 buckets.setdefault((p.device, p.dtype, state["exp_avg"].dtype, state["kahan_comp"] is not None), []).append((p, g, state))
-            if steps:
+            if capturing:
+                # one step count per group (the captured launch reads ONE prefactor per bucket from device memory), advanced by
+                # graph_advance() before every replay -- capture itself runs nothing
+                if len({int(t) for t in steps}) > 1:
+                    raise RuntimeError("AdamWScale: a captured step needs one step count per parameter group")
+                if group["weight_decay"] < 0:
+                    raise RuntimeError("AdamWScale: negative weight_decay")
+            elif steps:
                 torch._foreach_add_(steps, 1)  # reference :120
             for (device, dtype, sdtype, kahan), items in buckets.items():
                 table = (_Desc * (len(items) + 1))()
@@ -128,10 +143,21 @@ class AdamWScale(Optimizer):
                 table[len(items)].chunk_begin = chunk
                 if chunk == 0:
                     continue
-                raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
+                if capturing:
+                    # capture runs nothing, so the table (pointers into the graph's own pool: they never change) is uploaded by an
+                    # ordinary copy AFTER the capture, in front of the first replay (graph_advance).  Table and step scalars live in
+                    # an arena allocated BEFORE the capture (init_state): memory taken from the graph's pool during capture may
+                    # alias activations that were freed earlier in the capture -- every replay's forward would overwrite it.
+                    host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+                    raw = self._arena_take(device, host.numel())
+                    scalars = self._arena_take(device, 12).view(torch.float32)
+                    self._graph_jobs.append((group, [st for _, _, st in items], scalars, raw, host))
+                else:
+                    raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
+                    scalars = None
                 partials = torch.empty(chunk, dtype=torch.float32, device=device)
                 flags = (1 if kahan else 0) | (0 if group["correct_bias"] else 2)  # FAT5_ADAMW_KAHAN | FAT5_ADAMW_PLAIN_STEP
-                jobs.append((device, dtype, (sdtype, flags), raw, len(items), chunk, partials, group, keep))
+                jobs.append((device, dtype, (sdtype, flags, scalars), raw, len(items), chunk, partials, group, keep))
         if not jobs:
             return loss
         coef = None
@@ -150,7 +176,15 @@ class AdamWScale(Optimizer):
             coef = (self.max_grad_norm / (norm + 1e-6)).clamp(max=1.0).float().contiguous()  # clip_grad_norm_'s clip_coef_clamped
         for device, dtype, kahan, raw, n, chunk, partials, group, keep in jobs:
             beta1, beta2 = group["betas"]
-            sdtype, flags = kahan
+            sdtype, flags, scalars = kahan
+            if scalars is not None:
+                with _lib.on_device(device):
+                    _lib.check(lib.fat5_adamw_scale_step_dev(raw.data_ptr(), n, chunk, partials.data_ptr(), scalars.data_ptr(), float(beta1),
+                                                             float(beta2), float(group["eps"]), _lib.dtype_code(dtype), _lib.dtype_code(sdtype),
+                                                             int(flags), coef.data_ptr() if coef is not None else None,
+                                                             _lib.stream_ptr(device)), "fat5_adamw_scale_step_dev")
+                self._graph_keep += [partials, coef, keep]
+                continue
             args = (raw.data_ptr(), n, chunk, partials.data_ptr(), float(group["lr"]), float(beta1), float(beta2),
                     float(group["weight_decay"]), float(group["eps"]), _lib.dtype_code(dtype), _lib.dtype_code(sdtype), int(flags))
             with _lib.on_device(device):
@@ -159,3 +193,60 @@ class AdamWScale(Optimizer):
                 else:
                     _lib.check(lib.fat5_adamw_scale_step_clipped(*args, coef.data_ptr(), _lib.stream_ptr(device)), "fat5_adamw_scale_step_clipped")
         return loss
+
+    @torch.no_grad()
+    def init_state(self):
+        """allocate exp_avg / exp_avg_sq / kahan_comp / step of every parameter now (what the first step() does lazily, reference
+        :96-113): a step can only be captured in a graph once its state exists"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                state = self.state[p]
+                if "kahan_comp" in state or not p.requires_grad:
+                    continue
+                state["step"] = torch.tensor(0, dtype=torch.int32)
+                sd = group["use_state_dtype"] if group["use_state_dtype"] in (torch.float16, torch.bfloat16) else p.dtype
+                state["exp_avg"] = torch.zeros_like(p, dtype=sd, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, dtype=sd, memory_format=torch.preserve_format)
+                kah = group["kahan_sum"] and p.dtype in (torch.float16, torch.bfloat16)
+                state["kahan_comp"] = torch.zeros_like(p, memory_format=torch.preserve_format) if kah else None
+        # descriptor tables + step scalars of a captured step (see step()): one arena per device, [tensor, bytes handed out]
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            count = {}
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.is_cuda:
+                        count[p.device] = count.get(p.device, 0) + 1
+            self._graph_arena = {dev: [torch.empty((2 * n + 8 * len(self.param_groups) + 8) * 128, dtype=torch.uint8, device=dev), 0]
+                                 for dev, n in count.items()}
+
+    def _arena_take(self, device, nbytes):
+        """`nbytes` of the pre-capture arena of `device` (64-byte aligned pieces, handed out in order)"""
+        a = getattr(self, "_graph_arena", {}).get(device)
+        if a is None:
+            raise RuntimeError("AdamWScale: call init_state() before capturing a step (it allocates the buffers a captured step "
+                               "keeps outside the graph's memory pool)")
+        off = a[1]
+        a[1] = off + (nbytes + 63) // 64 * 64
+        if a[1] > a[0].numel():
+            raise RuntimeError("AdamWScale: capture arena too small (parameters added after init_state()?)")
+        return a[0][off:off + nbytes]
+
+    @torch.no_grad()
+    def graph_advance(self):
+        """Before every replay of a graph that holds a captured step(): count the step (reference :120) and write the three
+        step-dependent scalars of each bucket -- prefactor from the current `lr` and step count, -lr * weight_decay, lr * 1e-3 -- into
+        its device tensor (stream-ordered in front of the replay; the values the eager step passes as launch arguments)."""
+        if not getattr(self, "_graph_jobs", None):
+            raise RuntimeError("AdamWScale.graph_advance: no captured step")
+        for i, (group, states, scalars, raw, host) in enumerate(self._graph_jobs):
+            if host is not None:  # first replay: the descriptor table of the bucket
+                raw.copy_(host)
+                self._graph_jobs[i] = (group, states, scalars, raw, None)
+            torch._foreach_add_([st["step"] for st in states], 1)
+            beta1, beta2 = group["betas"]
+            lr, wd = float(group["lr"]), float(group["weight_decay"])
+            pre = self._prefactor(lr, beta1, beta2, int(states[0]["step"]), group["correct_bias"])
+            # (three fill launches -- the values travel as launch arguments; a copy from a host tensor would wait for the stream,
+            #  i.e. for the previous replay, and the host could never run ahead of the device)
+            for j, val in enumerate((pre, -lr * wd if wd > 0.0 else 0.0, lr * 1e-3)):
+                scalars[j:j + 1].fill_(val)

@@ -90,8 +90,8 @@ struct __attribute__((aligned(sizeof(T) * N))) avec { T x[N]; };
 template <int DT, int SDT, bool KAHAN>
 __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tensor* __restrict__ tab, int n,
                                                            const float* __restrict__ partial, float beta1, float beta2, float a1,
-                                                           float a2, float wdf, float eps, const float* __restrict__ grad_coef,
-                                                           int plain_step, float lr_small) {
+                                                           float a2, float wdf_, float eps, const float* __restrict__ grad_coef,
+                                                           int plain_step, float lr_small_, const float* __restrict__ dev_scalars) {
   typedef typename adt<DT>::type T;
   typedef typename adt<SDT>::type S;
   __shared__ float red[4];
@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tens
   const bool clip = grad_coef != nullptr;
   const float gcoef = clip ? *grad_coef : 1.f;
   const fat5_adamw_tensor t = tab[ti];
+  // dev_scalars: the three values that change from step to step -- {step prefactor, -lr * weight_decay, lr * 1e-3} -- read from
+  // device memory instead of the launch arguments / the table, so that a captured launch (HIP graph replay) follows the schedule
+  const float prefactor = dev_scalars ? dev_scalars[0] : t.step_prefactor;
+  const float wdf = dev_scalars ? dev_scalars[1] : wdf_;
+  const float lr_small = dev_scalars ? dev_scalars[2] : lr_small_;
   // ---- rms(p) of the whole tensor from its chunk partials, fixed order; reference :69-70, :184 ----
   const int nc = (int)((t.numel + kAdamChunk - 1) / kAdamChunk);
   float acc = 0.f;
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(const fat5_adamw_tens
   // p.norm(2): fp32 accumulation, result in p's dtype; "/ numel ** 0.5": one more op in p's dtype
   const float norm = rnd<DT>(sqrtf(sumsq));
   const float rms = rnd<DT>(norm / (float)sqrt((double)t.numel));
-  float neg_step = -(t.step_prefactor * fmaxf(1e-3f, rms));  // float32 x p-dtype scalars promote to float32 (:184)
-  if (plain_step) neg_step = rms > 1e-3f ? -rnd<DT>(t.step_prefactor * rms) : -lr_small;  // (max(1e-3, rms): the tensor only when it is larger)
+  float neg_step = -(prefactor * fmaxf(1e-3f, rms));  // float32 x p-dtype scalars promote to float32 (:184)
+  if (plain_step) neg_step = rms > 1e-3f ? -rnd<DT>(prefactor * rms) : -lr_small;  // (max(1e-3, rms): the tensor only when it is larger)
   // (a1 = 1 - beta1, a2 = 1 - beta2, wdf = -lr * weight_decay: formed in double by the host like the reference's Python, cast once)
 
   const int64_t e0 = (int64_t)(c - t.chunk_begin) * kAdamChunk;

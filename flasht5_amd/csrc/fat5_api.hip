@@ -841,7 +841,7 @@ size_t fat5_sizeof_adamw_tensor(void) { return sizeof(fat5_adamw_tensor); }
 
 static int adamw_step_impl(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr_, double beta1_,
                            double beta2_, double weight_decay_, double eps_, int dtype, int state_dtype, int flags, const float* grad_coef,
-                           void* stream_) {
+                           const float* dev_scalars, void* stream_) {
   // scalars reach the kernels as the fp32 "opmath" values the reference's ops see: each Python double is cast once
   const float beta1 = (float)beta1_, beta2 = (float)beta2_, eps = (float)eps_;
   const float a1 = (float)(1.0 - beta1_), a2 = (float)(1.0 - beta2_);
@@ -864,12 +864,12 @@ static int adamw_step_impl(const fat5_adamw_tensor* table, int32_t n_tensors, in
         if constexpr (DT != FAT5_F32) {
           if (kahan) {
             hipLaunchKernelGGL((adamw_update_kernel<DT, SDT, true>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1,
-                               beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small);
+                               beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small, dev_scalars);
             return;
           }
         }
         hipLaunchKernelGGL((adamw_update_kernel<DT, SDT, false>), dim3(n_chunks), dim3(256), 0, stream, table, n_tensors, partials, beta1,
-                           beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small);
+                           beta2, a1, a2, wdf, eps, grad_coef, plain, lr_small, dev_scalars);
       }
     });
   });
@@ -879,13 +879,19 @@ static int adamw_step_impl(const fat5_adamw_tensor* table, int32_t n_tensors, in
 }
 int fat5_adamw_scale_step(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr, double beta1,
                           double beta2, double weight_decay, double eps, int dtype, int state_dtype, int flags, void* stream) {
-  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, nullptr, stream);
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, nullptr, nullptr, stream);
 }
 int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
                                   double beta1, double beta2, double weight_decay, double eps, int dtype, int state_dtype, int flags,
                                   const float* grad_coef, void* stream) {
   if (!grad_coef) return fail(FAT5_EINVAL, "adamw: grad_coef is NULL");
-  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, grad_coef, stream);
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, lr, beta1, beta2, weight_decay, eps, dtype, state_dtype, flags, grad_coef, nullptr, stream);
+}
+int fat5_adamw_scale_step_dev(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, const float* dev_scalars,
+                              double beta1, double beta2, double eps, int dtype, int state_dtype, int flags, const float* grad_coef,
+                              void* stream) {
+  if (!dev_scalars) return fail(FAT5_EINVAL, "adamw: dev_scalars is NULL");
+  return adamw_step_impl(table, n_tensors, n_chunks, partials, 0.0, beta1, beta2, 0.0, eps, dtype, state_dtype, flags, grad_coef, dev_scalars, stream);
 }
 int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, int dtype, void* stream_) {
   if (!table || !partials) return fail(FAT5_EINVAL, "adamw: null table / partials");

@@ -317,3 +317,75 @@ def train_step(model, input_ids, labels, optimizer=None, group=None, max_grad_no
         optimizer.zero_grad(set_to_none=True)
     return loss.detach()
 
+
+
+class GraphedTrainStep:
+    """`train_step` captured ONCE in HIP graphs and replayed per batch: forward, backward, global-norm clipping and the fused
+    AdamWScale step of a fixed-shape batch are ~3,400 kernel launches whose enqueue time (24-29 ms of Python, dispatcher and
+    hipLaunchKernel for FAT5-base at B = 4) exceeds their 17 ms of kernel time; a replay enqueues them in well under a millisecond.
+
+        step = GraphedTrainStep(model, AdamWScale(model.parameters(), ..., max_grad_norm=1.0))
+        for input_ids, labels in loader:       # every batch of ONE shape
+            loss = step(input_ids, labels)     # (a static tensor, overwritten by the next call: .item() / .clone() to keep it)
+
+    The first `warmup` calls run the eager `train_step` (they also create the optimizer state), the next call captures and replays, every later call only replays.  What changes from step to step reaches the graph
+    through device memory: the batch (copied into static buffers), and the optimizer's step-dependent scalars (learning rate,
+    bias correction: `AdamWScale.graph_advance`, so LR schedulers keep working -- they set `param_group["lr"]` as always).
+    Gradients stay allocated between steps (the graph owns them): `p.grad` holds the last step's unclipped gradients.
+
+    Data parallel (`group` with more than one rank; `split=True` forces this form): two graphs -- forward + backward, then the
+    optimizer step -- with the flat gradient all-reduce (RCCL, `allreduce_gradients`) between them, outside any graph."""
+
+    def __init__(self, model, optimizer, group=None, warmup=2, split=None):
+        from .adamw_scaled import AdamWScale
+        if not isinstance(optimizer, AdamWScale):
+            raise TypeError("GraphedTrainStep needs flasht5_amd.AdamWScale (its captured step reads lr / bias correction from device memory)")
+        self.model, self.optimizer, self.group = model, optimizer, group
+        self.warmup = int(warmup)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.split = multi if split is None else (bool(split) or multi)
+        self.calls = 0
+        self.graphs = None
+        self.ids = self.labels = self.loss = None
+
+    def _eager(self, input_ids, labels):
+        # (on the CURRENT stream.  Warming up on a side stream, as the PyTorch recipe has it, made the first replay after a
+        #  device-wide synchronize fault on this ROCm stack -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, full-size model only;
+        #  tools/graph_step_debug.py -- and buys nothing here: no DDP hooks, one autograd stream)
+        return train_step(self.model, input_ids, labels, self.optimizer, self.group, max_grad_norm=None)
+
+    def _capture(self, input_ids, labels):
+        self.ids, self.labels = input_ids.clone(), labels.clone()
+        self.optimizer.init_state()
+        self.optimizer.zero_grad(set_to_none=True)  # the gradients are (re)allocated inside the graph's pool
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self.loss = self.model(self.ids, self.labels)
+            self.loss.backward()
+            if not self.split:
+                self.optimizer.step()
+            self.loss = self.loss.detach()
+        self.graphs = [g1]
+        if self.split:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.optimizer.step()
+            self.graphs.append(g2)
+
+    def __call__(self, input_ids, labels):
+        self.calls += 1
+        if self.graphs is None:
+            if self.calls <= self.warmup:
+                return self._eager(input_ids, labels)
+            self._capture(input_ids, labels)
+        else:
+            if input_ids.shape != self.ids.shape or labels.shape != self.labels.shape:
+                raise ValueError(f"GraphedTrainStep was captured for batches {tuple(self.ids.shape)} / {tuple(self.labels.shape)}")
+            self.ids.copy_(input_ids, non_blocking=True)
+            self.labels.copy_(labels, non_blocking=True)
+        self.optimizer.graph_advance()
+        self.graphs[0].replay()
+        if self.split:
+            allreduce_gradients(self.model, self.group)
+            self.graphs[1].replay()
+        return self.loss

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define FAT5_VERSION 111 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
-                            AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_* */
+                            AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_*, fat5_adamw_scale_step_dev */
 
 enum fat5_status {
   FAT5_OK = 0,
@@ -294,6 +294,14 @@ int fat5_adamw_grad_sumsq(const fat5_adamw_tensor* table, int32_t n_tensors, int
 int fat5_adamw_scale_step_clipped(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, double lr,
                                   double beta1, double beta2, double weight_decay, double eps, int dtype, int state_dtype,
                                   int flags, const float* grad_coef, void* hip_stream);
+/* The same step with its step-dependent scalars in DEVICE memory -- dev_scalars[0] = the step prefactor lr * sqrt(1 - beta2^t) /
+ * (1 - beta1^t) (or lr with FAT5_ADAMW_PLAIN_STEP; overrides every table entry's step_prefactor: one step count for the group),
+ * [1] = -lr * weight_decay (0 when weight_decay is 0), [2] = lr * 1e-3 -- so that a launch captured in a HIP graph follows the
+ * learning-rate schedule and the bias correction: the host writes three floats before each replay (stream-ordered), nothing in the
+ * graph changes.  grad_coef may be NULL (no clipping). */
+int fat5_adamw_scale_step_dev(const fat5_adamw_tensor* table, int32_t n_tensors, int32_t n_chunks, float* partials, const float* dev_scalars,
+                              double beta1, double beta2, double eps, int dtype, int state_dtype, int flags, const float* grad_coef,
+                              void* hip_stream);
 size_t fat5_sizeof_adamw_tensor(void);
 
 #ifdef __cplusplus

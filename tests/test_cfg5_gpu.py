@@ -165,3 +165,54 @@ def test_cfg5_fused_add_norm_is_bit_identical():
         rel = 2.0 ** -4 if "relative_attention_bias" in n else 2.0 ** -7
         assert maxdiff(p1.grad, p0.grad) <= rel * max(p0.grad.float().abs().max().item(), 1e-6), n
 
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_graphed_train_step_follows_the_eager_step(split, fuse):
+    """GraphedTrainStep: forward + backward + clip + AdamWScale captured in HIP graph(s) (split: two graphs with the gradient
+    all-reduce between them, the data-parallel form) against the eager train_step on the same batches with a learning-rate
+    schedule: warm-up calls are the eager step itself (bit-identical first loss), replays see every new batch and every new
+    learning rate / bias correction (losses and parameters agree to the run-to-run noise of the eager step: torch's embedding
+    backward accumulates with atomics)"""
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration, AdamWScale, train_step, GraphedTrainStep
+    cfg = FAT5Config(num_layers=2, num_decoder_layers=2, vocab_size=4096)
+    cfg.fuse_norm_linear = fuse
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.randint(0, cfg.vocab_size, (2, 512), generator=g).cuda(), torch.randint(0, cfg.vocab_size, (2, 128), generator=g).cuda())
+               for _ in range(6)]
+    lrs = [1e-3, 2e-3, 3e-3, 2e-3, 1e-3, 5e-4]
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(7)
+        model = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+        opt = AdamWScale(model.parameters(), lr=lrs[0], kahan_sum=True, max_grad_norm=1.0)
+        step = GraphedTrainStep(model, opt, warmup=2, split=split) if graphed else (lambda i, l: train_step(model, i, l, opt, max_grad_norm=None))
+        losses = []
+        for (ids, labels), lr in zip(batches, lrs):
+            for grp in opt.param_groups:
+                grp["lr"] = lr
+            losses.append(float(step(ids, labels)))
+        runs.append((losses, [p.detach().float().clone() for p in model.parameters()], int(next(iter(opt.state.values()))["step"])))
+    (l0, p0, s0), (l1, p1, s1) = runs
+    assert s0 == s1 == 6
+    assert l0[0] == l1[0]
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    for a, b in zip(p0, p1):
+        assert float((a - b).abs().max()) <= 2.0 ** -6 * max(float(a.abs().max()), 1e-3)
+
+
+def test_graphed_train_step_argument_checks():
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration, AdamWScale, GraphedTrainStep
+    cfg = FAT5Config(num_layers=1, num_decoder_layers=1, vocab_size=512)
+    model = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+    with pytest.raises(TypeError):
+        GraphedTrainStep(model, torch.optim.AdamW(model.parameters()))
+    opt = AdamWScale(model.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError):
+        opt.graph_advance()
+    step = GraphedTrainStep(model, opt, warmup=0)
+    ids, labels = torch.randint(0, 512, (1, 128)).cuda(), torch.randint(0, 512, (1, 64)).cuda()
+    step(ids, labels)
+    with pytest.raises(ValueError):
+        step(ids[:, :64], labels)
