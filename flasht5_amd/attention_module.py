@@ -27,6 +27,42 @@ def _cfg(config, name, default):
     return getattr(config, name, default)
 
 
+class _UnpackHeads(torch.autograd.Function):
+    """(B, S, n * H * D) projection output -> n views (B, H, S, D) (slice i = heads of projection i).  Same values as
+    `x.view(B, S, n, H, D)[:, :, i].permute(0, 2, 1, 3)`; the difference is the backward: autograd's select would allocate a
+    zero-filled (B, S, n, H, D) tensor per slice, copy the slice's gradient in and add the n tensors up.  The attention
+    backward writes the gradients of packed slices into the slices of ONE buffer (flash_attention_v2_bias.packed_slices): when
+    the incoming gradients are exactly those, the buffer itself is the result (no kernel at all); otherwise one stack."""
+
+    @staticmethod
+    def forward(ctx, x, n, H):
+        B, S, W = x.shape
+        D = W // (n * H)
+        ctx.dims = (B, S, n, H, D)
+        p = x.view(B, S, n, H, D)
+        return tuple(p[:, :, i].permute(0, 2, 1, 3) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, S, n, H, D = ctx.dims
+        row = n * H * D
+        g0 = gs[0]
+        if all(g is not None for g in gs):
+            same = all(g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and g.dtype == g0.dtype and
+                       g.stride() == (S * row, D, row, 1) and g.storage_offset() == g0.storage_offset() + i * H * D
+                       for i, g in enumerate(gs))
+            if same and g0.untyped_storage().nbytes() >= (g0.storage_offset() + B * S * row) * g0.element_size():
+                return g0.as_strided((B, S, row), (S * row, row, 1), g0.storage_offset()), None, None
+        ref = next(g for g in gs if g is not None)
+        parts = [(g if g is not None else torch.zeros_like(ref)).permute(0, 2, 1, 3) for g in gs]  # (B, S, H, D) each
+        return torch.stack(parts, 2).reshape(B, S, row), None, None
+
+
+def unpack_heads(x, n, n_heads):
+    """the n head-major (B, H, S, D) views of a packed (B, S, n * H * D) projection output (see _UnpackHeads)"""
+    return _UnpackHeads.apply(x, n, n_heads)
+
+
 class FlashT5Attention(nn.Module):
     def __init__(self, config, has_positional_encoding=False, is_causal=False):
         super().__init__()
@@ -83,13 +119,11 @@ class FlashT5Attention(nn.Module):
         B, M = hidden_states.shape[:2]
         H, Dh = self.n_heads, self.key_value_proj_dim
         if key_value_states is None:  # self-attention: ONE GEMM for q, k, v
-            qkv = rmsnorm_linear(hidden_states, norm_weight, (self.Wq.weight, self.Wk.weight, self.Wv.weight), eps).view(B, M, 3, H, Dh)
-            q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            q, k, v = unpack_heads(rmsnorm_linear(hidden_states, norm_weight, (self.Wq.weight, self.Wk.weight, self.Wv.weight), eps), 3, H)
         else:                         # cross-attention: the decoder side is normed, the encoder output is not (:330-336)
             N = key_value_states.shape[1]
             q = rmsnorm_linear(hidden_states, norm_weight, self.Wq.weight, eps).view(B, M, H, Dh).permute(0, 2, 1, 3)
-            kv = torch.nn.functional.linear(key_value_states, torch.cat((self.Wk.weight, self.Wv.weight), 0)).view(B, N, 2, H, Dh)
-            k, v = (kv[:, :, i].permute(0, 2, 1, 3) for i in range(2))
+            k, v = unpack_heads(torch.nn.functional.linear(key_value_states, torch.cat((self.Wk.weight, self.Wv.weight), 0)), 2, H)
         out, position_bias = self._attend(q, k, v, hidden_states.dtype, mask, key_value_states is None, position_bias)
         return linear_residual(out, self.o.weight, hidden_states), position_bias
 

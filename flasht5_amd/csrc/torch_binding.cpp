@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <vector>
 #include "fat5.h"
 
 namespace {
@@ -34,6 +35,30 @@ Tensor prep(const Tensor& t) { return kernel_ready(t) ? t : t.contiguous(); }
 Tensor empty_like_ready(const Tensor& t) {
   Tensor e = at::empty_like(t);
   return kernel_ready(e) ? e : at::empty(t.sizes(), t.options());
+}
+// Gradients of PACKED projections: when the (B, H, S, D) inputs are the slices [:, :, i] of one (B, S, n, H, D) projection output
+// (n = 3: q, k, v of a self-attention block from one GEMM; n = 2: k, v of a cross-attention block), their gradients are
+// allocated as the same slices of ONE (B, S, n, H, D) buffer: the kernels write them in place (any strides with unit inner
+// stride are fine for them) and the caller hands the buffer to the projection's backward GEMMs as it is -- no zero-filled
+// full-size tensor per slice, no strided copies, no additions of the slices' gradients.
+bool packed_slices(const std::vector<const Tensor*>& ts) {
+  const Tensor& a = *ts[0];
+  const int64_t n = (int64_t)ts.size(), H = a.size(1), S = a.size(2), D = a.size(3), row = n * H * D;
+  if (a.stride(3) != 1 || a.stride(1) != D || a.stride(2) != row || a.stride(0) != S * row) return false;
+  for (int64_t i = 1; i < n; ++i) {
+    const Tensor& t = *ts[i];
+    if (t.sizes() != a.sizes() || t.strides() != a.strides() || t.scalar_type() != a.scalar_type()) return false;
+    if (reinterpret_cast<const char*>(t.data_ptr()) - reinterpret_cast<const char*>(a.data_ptr()) != i * H * D * (int64_t)a.element_size()) return false;
+  }
+  return true;
+}
+std::vector<Tensor> empty_packed_like(const std::vector<const Tensor*>& ts) {
+  const Tensor& a = *ts[0];
+  const int64_t n = (int64_t)ts.size(), H = a.size(1), S = a.size(2), D = a.size(3);
+  Tensor base = at::empty({a.size(0), S, n, H, D}, a.options());
+  std::vector<Tensor> out;
+  for (int64_t i = 0; i < n; ++i) out.push_back(base.select(2, i).permute({0, 2, 1, 3}));
+  return out;
 }
 void set3(int64_t (&d)[3], const Tensor& t) {
   d[0] = t.stride(0);
@@ -116,7 +141,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> attn_bwd(const Tensor& o_, const Tens
                                                     const Tensor& L, bool causal, double scale, bool need_dbias,
                                                     const OptT& bucket, int64_t num_buckets) {
   Tensor q = prep(q_), k = prep(k_), v = prep(v_), o = prep(o_), dout = prep(do_);
-  Tensor dq = empty_like_ready(q), dk = empty_like_ready(k), dv = empty_like_ready(v);  // reference :140-141,:191
+  Tensor dq, dk, dv;  // reference :140-141,:191
+  if (q.sizes() == k.sizes() && packed_slices({&q, &k, &v})) {
+    auto g = empty_packed_like({&q, &k, &v});
+    dq = g[0]; dk = g[1]; dv = g[2];
+  } else if (packed_slices({&k, &v})) {
+    auto g = empty_packed_like({&k, &v});
+    dq = empty_like_ready(q); dk = g[0]; dv = g[1];
+  } else {
+    dq = empty_like_ready(q); dk = empty_like_ready(k); dv = empty_like_ready(v);
+  }
   fat5_attn_params p;
   base_params(p, q, k, v, causal, scale);
   p.o = o.data_ptr(); p.lse = (float*)L.data_ptr(); set3(p.o_stride, o);

@@ -126,17 +126,41 @@ def _attn_fwd(q, k, v, bias, rpe1d, radius, causal, sm_scale):
     return o, L
 
 
+def packed_slices(ts):
+    """True when the (B, H, S, D) tensors `ts` are the slices [:, :, i] of ONE (B, S, n, H, D) projection output (n = len(ts): q, k, v
+    of a self-attention block from one GEMM; k, v of a cross-attention block).  Their gradients are then allocated as the same
+    slices of one (B, S, n, H, D) buffer -- the kernels write them in place, the projection's backward GEMMs take the buffer as it
+    is: no zero-filled full-size tensor per slice, no strided copies, no additions (attention_module.unpack_heads)."""
+    a, n = ts[0], len(ts)
+    _, H, S, D = a.shape
+    row = n * H * D
+    if a.stride() != (S * row, D, row, 1):
+        return False
+    return all(t.shape == a.shape and t.stride() == a.stride() and t.dtype == a.dtype and
+               t.data_ptr() - a.data_ptr() == i * H * D * a.element_size() for i, t in enumerate(ts))
+
+
+def empty_packed_like(ts):
+    a, n = ts[0], len(ts)
+    B, H, S, D = a.shape
+    base = torch.empty((B, S, n, H, D), dtype=a.dtype, device=a.device)
+    return tuple(base[:, :, i].permute(0, 2, 1, 3) for i in range(n))
+
+
 def _attn_bwd(o, do, q, k, v, bias, rpe1d, radius, L, causal, sm_scale, need_dbias, rpe_bucket=None, num_buckets=0):
     q, k, v, o, do = _prep(q), _prep(k), _prep(v), _prep(o), _prep(do)
     B, H, M, D = q.shape
     N = k.shape[2]
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)  # reference :140-141,:191
-    if not _lib.kernel_ready(dq):
-        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
-    if not _lib.kernel_ready(dk):
-        dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
-    if not _lib.kernel_ready(dv):
-        dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    def like(t):  # reference :140-141,:191
+        e = torch.empty_like(t)
+        return e if _lib.kernel_ready(e) else torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    # gradients of PACKED projections are allocated as slices of one buffer (see packed_slices)
+    if q.shape == k.shape and packed_slices((q, k, v)):
+        dq, dk, dv = empty_packed_like((q, k, v))
+    elif packed_slices((k, v)):
+        dq, (dk, dv) = like(q), empty_packed_like((k, v))
+    else:
+        dq, dk, dv = like(q), like(k), like(v)
     p = _base_params(q, k, v, causal, sm_scale)
     p.o, p.lse, p.o_stride = o.data_ptr(), L.data_ptr(), _lib.strides3(o)
     p.dout, p.dq, p.dk, p.dv = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()

@@ -919,3 +919,49 @@ def test_native_host_path_equals_ctypes_path():
     assert on.shape == (1, 2, 96, 16) and torch.equal(on, oc)
     for x, y in zip(torch.autograd.grad(on, ln, do16), torch.autograd.grad(oc, lc, do16)):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("mode", ["self", "cross", "self_rpe", "broken"])
+def test_packed_projection_gradients_land_in_one_buffer(mode, monkeypatch):
+    """q, k, v as slices of ONE projection output (attention_module.unpack_heads): the attention backward writes dq / dk / dv into
+    the slices of one buffer and unpack's backward returns that buffer -- no stack / cat / zero-fill -- with the same values as
+    autograd's own select path.  'broken': an op between unpack and attention breaks the packing -> the stack fallback, same values."""
+    from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe
+    from flasht5_amd.attention_module import unpack_heads
+    B, S, N, H, D = 2, 384, 256, 6, 64
+    g = torch.Generator().manual_seed(12)
+    n = 2 if mode == "cross" else 3
+    x = (torch.randn(B, N if mode == "cross" else S, n * H * D, generator=g) * 0.5).cuda().bfloat16()
+    qx = (torch.randn(B, S, H * D, generator=g) * 0.5).cuda().bfloat16()
+    table = (torch.randn(32, H, generator=g) * 0.5).cuda()
+    do = torch.randn(B, H, S, D, generator=g).cuda().bfloat16()
+
+    def run(unpack):
+        xs, qs = x.clone().requires_grad_(), qx.clone().requires_grad_()
+        if unpack:
+            parts = unpack_heads(xs, n, H)
+        else:
+            p5 = xs.view(B, xs.shape[1], n, H, D)
+            parts = tuple(p5[:, :, i].permute(0, 2, 1, 3) for i in range(n))
+        if mode == "cross":
+            q, (k, v) = qs.view(B, S, H, D).permute(0, 2, 1, 3), parts
+        else:
+            q, k, v = parts
+        if mode == "broken":
+            k = k * 1.0
+        if mode == "self_rpe":
+            o = flash_attention_v2_rpe(q, k, v, table, True, 32, 128, False, 0.125)
+        else:
+            o = flash_attention_v2_bias(q, k, v, None, mode != "cross", 0.125)
+        o.backward(do)
+        return o.detach(), xs.grad, qs.grad
+
+    o0, gx0, gq0 = run(False)
+    calls = {"n": 0}
+    real_stack = torch.stack
+    monkeypatch.setattr(torch, "stack", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), real_stack(*a, **k))[1])
+    o1, gx1, gq1 = run(True)
+    assert torch.equal(o0, o1) and torch.equal(gx0, gx1)
+    if mode == "cross":
+        assert torch.equal(gq0, gq1)
+    assert calls["n"] == (1 if mode == "broken" else 0)
