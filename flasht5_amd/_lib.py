@@ -104,7 +104,7 @@ def load():
     lib.fat5_gated_act_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp]
     lib.fat5_fold_weights_bwd_scratch_bytes.argtypes = [i64, i64]
     lib.fat5_rmsnorm_unit_bwd.restype = ctypes.c_int
-    lib.fat5_rmsnorm_unit_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]
+    lib.fat5_rmsnorm_unit_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, i64, i32, vp]
     lib.fat5_fold_weights.restype = ctypes.c_int
     lib.fat5_fold_weights.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, i32, vp]
     lib.fat5_ce_bwd.restype = ctypes.c_int

@@ -119,13 +119,15 @@ class FlashT5Attention(nn.Module):
         B, M = hidden_states.shape[:2]
         H, Dh = self.n_heads, self.key_value_proj_dim
         if key_value_states is None:  # self-attention: ONE GEMM for q, k, v
-            q, k, v = unpack_heads(rmsnorm_linear(hidden_states, norm_weight, (self.Wq.weight, self.Wk.weight, self.Wv.weight), eps), 3, H)
+            qkv, res = rmsnorm_linear(hidden_states, norm_weight, (self.Wq.weight, self.Wk.weight, self.Wv.weight), eps, return_residual=True)
+            q, k, v = unpack_heads(qkv, 3, H)
         else:                         # cross-attention: the decoder side is normed, the encoder output is not (:330-336)
             N = key_value_states.shape[1]
-            q = rmsnorm_linear(hidden_states, norm_weight, self.Wq.weight, eps).view(B, M, H, Dh).permute(0, 2, 1, 3)
+            q, res = rmsnorm_linear(hidden_states, norm_weight, self.Wq.weight, eps, return_residual=True)
+            q = q.view(B, M, H, Dh).permute(0, 2, 1, 3)
             k, v = unpack_heads(torch.nn.functional.linear(key_value_states, torch.cat((self.Wk.weight, self.Wv.weight), 0)), 2, H)
         out, position_bias = self._attend(q, k, v, hidden_states.dtype, mask, key_value_states is None, position_bias)
-        return linear_residual(out, self.o.weight, hidden_states), position_bias
+        return linear_residual(out, self.o.weight, res), position_bias
 
     def _attend(self, q, k, v, dtype, mask, is_self, position_bias):
         """attention of projected (B, H, S, D) views -> (B, M, inner_dim), plus the position bias to hand on"""

@@ -756,12 +756,13 @@ int fat5_gated_act_bwd(const void* dout, const void* h0, const void* h1, void* d
 }
 
 int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n, int64_t gy_stride,
-                          int64_t x_stride, int64_t dx_stride, int64_t xhat_stride, int dtype, void* stream_) {
+                          int64_t x_stride, int64_t dx_stride, int64_t xhat_stride, const void* dres, int64_t dres_stride, int dtype,
+                          void* stream_) {
   if (!gy || !x || !rstd || !dx || !xhat) return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: null pointer");
   if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: bad dtype");
   const int v = vec_of(dtype);
   if (rows <= 0 || n <= 0 || n % v || n > 4 * 64 * v || gy_stride % v || x_stride % v || dx_stride % v || xhat_stride % v || !aligned16(gy) ||
-      !aligned16(x) || !aligned16(dx) || !aligned16(xhat))
+      !aligned16(x) || !aligned16(dx) || !aligned16(xhat) || (dres && (!aligned16(dres) || dres_stride % v)))
     return fail(FAT5_EINVAL, "rmsnorm_unit_bwd: n must be a multiple of %d and at most %d; 16-byte aligned rows", v, 4 * 64 * v);
   hipStream_t stream = (hipStream_t)stream_;
   const int grid = (int)((rows + 3) / 4);
@@ -769,9 +770,9 @@ int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void
   dispatch_dtype(dtype, [&](auto dt_) {
     constexpr int DT = decltype(dt_)::value;
     if (nch <= 2)
-      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 2>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride);
+      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 2>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride, dres, dres_stride);
     else
-      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 4>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride);
+      hipLaunchKernelGGL((rmsnorm_unit_bwd_kernel<DT, 4>), dim3(grid), dim3(256), 0, stream, gy, x, rstd, dx, xhat, rows, (int)n, gy_stride, x_stride, dx_stride, xhat_stride, dres, dres_stride);
   });
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rmsnorm_unit_bwd launch");

@@ -265,7 +265,7 @@ template <int XDT, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_unit_bwd_kernel(const void* __restrict__ gy_, const void* __restrict__ x_,
                                                                const float* __restrict__ rstd, void* __restrict__ dx_,
                                                                void* __restrict__ xhat_, int64_t rows, int n, int64_t gys, int64_t xs,
-                                                               int64_t dxs, int64_t xhs) {
+                                                               int64_t dxs, int64_t xhs, const void* __restrict__ dres_, int64_t drs) {
   typedef Elem<XDT> X;
   constexpr int VEC = X::VEC;
   const int lane = threadIdx.x & 63;
@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256) void rmsnorm_unit_bwd_kernel(const void* __res
   const typename X::T* gy = reinterpret_cast<const typename X::T*>(gy_) + row * gys;
   typename X::T* dx = reinterpret_cast<typename X::T*>(dx_) + row * dxs;
   typename X::T* xh_out = reinterpret_cast<typename X::T*>(xhat_) + row * xhs;
+  // dres: the gradient that reaches x along the residual connection (h + sublayer(norm(h))): added here instead of by a kernel of its own
+  const typename X::T* dres = dres_ ? reinterpret_cast<const typename X::T*>(dres_) + row * drs : nullptr;
   const float r = rstd[row];
   float xh[NCH][VEC], gv[NCH][VEC];
   float c1 = 0.f;
@@ -299,6 +301,12 @@ __global__ __launch_bounds__(256) void rmsnorm_unit_bwd_kernel(const void* __res
       float o[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = (gv[i][j] - xh[i][j] * c1) * r;
+      if (dres) {
+        float dr[VEC];
+        X::load(dres + c, dr);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] += dr[j];
+      }
       X::store(dx + c, o);
       X::store(xh_out + c, xh[i]);
     }

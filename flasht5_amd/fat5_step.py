@@ -106,7 +106,7 @@ class FAT5LayerFF(nn.Module):  # :148-164
         from .fused_linear import rmsnorm_linear, linear_residual
         a = self.act
         if a.glu:
-            g = rmsnorm_linear(h, self.layer_norm.weight, (a.wi_0.weight, a.wi_1.weight), self.layer_norm.variance_epsilon)
+            g, h = rmsnorm_linear(h, self.layer_norm.weight, (a.wi_0.weight, a.wi_1.weight), self.layer_norm.variance_epsilon, return_residual=True)
             if a.fused_ok(g) and a.wi_0.weight.shape[0] % 8 == 0:
                 from .gated_act import gated_act_packed
                 t = gated_act_packed(g, a.act_name)  # (its gradient is ONE (…, 2 d_ff) tensor: no concatenation in front of the backward GEMMs)
@@ -114,7 +114,8 @@ class FAT5LayerFF(nn.Module):  # :148-164
                 g0, g1 = g.split(a.wi_0.weight.shape[0], dim=-1)
                 t = a.act(g0) * g1
         else:
-            t = a.act(rmsnorm_linear(h, self.layer_norm.weight, a.wi.weight, self.layer_norm.variance_epsilon))
+            t, h = rmsnorm_linear(h, self.layer_norm.weight, a.wi.weight, self.layer_norm.variance_epsilon, return_residual=True)
+            t = a.act(t)
         return linear_residual(t, self.wo.weight, h)
 
     def forward_deferred(self, h, pending):

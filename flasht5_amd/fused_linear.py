@@ -71,7 +71,7 @@ class RMSNormLinear(torch.autograd.Function):
     (the separate ops: norm + 3 GEMMs forward; 6 GEMMs + 2 norm-backward kernels + 2 gradient accumulations backward)"""
 
     @staticmethod
-    def forward(ctx, x, norm_weight, eps, *weights):
+    def forward(ctx, x, norm_weight, eps, with_residual, *weights):
         shape = x.shape
         x2 = _rows(x)
         # the norm weight rides in the projection: (x rstd g) W^T = rstd (x (W diag g)^T)
@@ -79,11 +79,22 @@ class RMSNormLinear(torch.autograd.Function):
         out, rstd = _launch(x2, wg, None, True, eps, True)
         ctx.save_for_backward(x2, norm_weight, rstd, wg, *weights)  # (wg: a few MB per layer -- the normalised activation is what is NOT kept)
         ctx.shape = shape
-        return out.reshape(*shape[:-1], wg.shape[0])
+        ctx.with_residual = bool(with_residual)
+        ctx.set_materialize_grads(False)  # (an unused output's gradient arrives as None, not as a zero-filled tensor)
+        out = out.reshape(*shape[:-1], wg.shape[0])
+        if with_residual:
+            # x handed back as a second output: the sub-layer adds IT to its result (h + f(norm(h))), so the gradient of that
+            # residual path arrives here and joins dx inside fat5_rmsnorm_unit_bwd instead of in an add kernel of autograd's
+            return out, x.view_as(x)
+        return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dres=None):
         x2, g, rstd, wg, *weights = ctx.saved_tensors
+        if dout is None:  # only the residual alias was used
+            return (dres, None, None, None, *([None] * len(weights)))
+        if dres is not None:
+            dres = _rows(dres if dres.dtype == x2.dtype else dres.to(x2.dtype))
         d2 = _rows(dout)
         if d2.dtype != x2.dtype:
             d2 = d2.to(x2.dtype)
@@ -94,11 +105,12 @@ class RMSNormLinear(torch.autograd.Function):
         xhat = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
         with _lib.on_device(x2.device):
             _lib.check(lib.fat5_rmsnorm_unit_bwd(gy.data_ptr(), x2.data_ptr(), rstd.data_ptr(), dx.data_ptr(), xhat.data_ptr(), M, K,
-                                                 gy.stride(0), x2.stride(0), K, K, _lib.dtype_code(x2.dtype), _lib.stream_ptr(x2.device)),
-                       "fat5_rmsnorm_unit_bwd")
+                                                 gy.stride(0), x2.stride(0), K, K, dres.data_ptr() if dres is not None else None,
+                                                 dres.stride(0) if dres is not None else 0, _lib.dtype_code(x2.dtype),
+                                                 _lib.stream_ptr(x2.device)), "fat5_rmsnorm_unit_bwd")
         dg = None
         dWs = [None] * len(weights)
-        if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[3:]):
+        if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[4:]):
             dwg = d2.t() @ xhat                                          # gradient of the folded weight [W_i] diag(g): (N, K)
             ws = [w if (w.stride(-1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0) else w.contiguous() for w in weights]
             gq = g.to(x2.dtype).contiguous()
@@ -114,8 +126,8 @@ class RMSNormLinear(torch.autograd.Function):
                                                      gq.data_ptr(), dptr[0], dptr[1], dptr[2], dgq.data_ptr(), K, _lib.dtype_code(x2.dtype),
                                                      scratch.data_ptr(), scratch.numel() * 4, _lib.stream_ptr(x2.device)), "fat5_fold_weights_bwd")
             dg = dgq.to(g.dtype) if ctx.needs_input_grad[1] else None
-            dWs = [(t.to(w.dtype) if ctx.needs_input_grad[3 + i] else None) for i, (t, w) in enumerate(zip(dWs, weights))]
-        return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None, dg, None, *dWs)
+            dWs = [(t.to(w.dtype) if ctx.needs_input_grad[4 + i] else None) for i, (t, w) in enumerate(zip(dWs, weights))]
+        return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None, dg, None, None, *dWs)
 
 
 class LinearResidual(torch.autograd.Function):
@@ -137,11 +149,13 @@ class LinearResidual(torch.autograd.Function):
         return da, dW, (dout if ctx.needs_input_grad[2] else None)
 
 
-def rmsnorm_linear(x, norm_weight, weight, eps=1e-6):
+def rmsnorm_linear(x, norm_weight, weight, eps=1e-6, return_residual=False):
     """F.linear(fast_rms_layernorm(x, norm_weight, eps), weight) in one MFMA kernel; x (..., K), weight (N, K) -> (..., N).
     `weight` may be a tuple of up to three weights applied to the same normalised input (Wq, Wk, Wv / wi_0, wi_1): their outputs
     come back concatenated along the last dim (one GEMM).  Shapes the kernel does not take (K % 64, N % 8, fp32) run the two
-    HIP / library ops one after the other."""
+    HIP / library ops one after the other.
+    return_residual: also return `x` itself (an alias) -- the tensor the caller adds to the sub-layer's result, `h + f(norm(h))`: the
+    gradient of that residual path then joins the norm's input gradient inside the backward kernel (no add kernel)."""
     if not x.is_cuda:
         raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
     weights = tuple(weight) if isinstance(weight, (tuple, list)) else (weight,)
@@ -149,8 +163,9 @@ def rmsnorm_linear(x, norm_weight, weight, eps=1e-6):
             x.shape[-1] > 2048):  # (fat5_rmsnorm_unit_bwd keeps a row in registers: up to 2048 16-bit elements)
         from .rms_norm import fast_rms_layernorm
         y = fast_rms_layernorm(x, norm_weight, eps)
-        return torch.cat([torch.nn.functional.linear(y, w) for w in weights], -1) if len(weights) > 1 else torch.nn.functional.linear(y, weights[0])
-    return RMSNormLinear.apply(x, norm_weight, float(eps), *weights)
+        out = torch.cat([torch.nn.functional.linear(y, w) for w in weights], -1) if len(weights) > 1 else torch.nn.functional.linear(y, weights[0])
+        return (out, x) if return_residual else out
+    return RMSNormLinear.apply(x, norm_weight, float(eps), bool(return_residual), *weights)
 
 
 def linear_residual(a, weight, residual):

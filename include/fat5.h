@@ -208,14 +208,15 @@ int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0
 /* Backward pieces of fat5_linear_fused(norm = 1) (the two gradient GEMMs are plain GEMMs):
  *  - fat5_rmsnorm_unit_bwd: gy = dout (W diag g) = dL/dxhat, xhat = x * rstd ->  dx = (gy - xhat * mean_k(xhat * gy)) * rstd (the
  *    backward of rms_norm.py:113-124 with unit weight), and xhat itself -- the operand of the dout^T xhat GEMM -- in the same pass;
- *    x_dtype tensors, n <= 2048 (16-bit) / 1024 (fp32).
+ *    x_dtype tensors, n <= 2048 (16-bit) / 1024 (fp32).  dres (optional, NULL = none): the gradient arriving at x along the
+ *    residual connection of the sub-layer (h + f(norm(h))), added to dx in the same pass (fp32 sum, one rounding).
  *  - fat5_fold_weights_bwd: dwg (N, K) = dout^T xhat, the gradient of the folded weight [w0; w1; w2] diag(g) ->
  *    dw_i = dwg rows * g (contiguous (n_i, K), any of them may be NULL), dg[k] = sum_n dwg[n][k] * w[n][k] (fp32, fixed order; may be NULL).
  *    K a multiple of 64.  dg needs `scratch` of fat5_fold_weights_bwd_scratch_bytes(n0 + n1 + n2, K) bytes (row slabs are summed by
  *    separate workgroups, the slab sums added in order by a second launch); contents need no initialisation. */
 int fat5_rmsnorm_unit_bwd(const void* gy, const void* x, const float* rstd, void* dx, void* xhat, int64_t rows, int64_t n,
-                          int64_t gy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, int64_t xhat_row_stride, int dtype,
-                          void* hip_stream);
+                          int64_t gy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, int64_t xhat_row_stride,
+                          const void* dres, int64_t dres_row_stride, int dtype, void* hip_stream);
 int fat5_fold_weights_bwd(const void* dwg, const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0,
                           int64_t ld1, int64_t ld2, const void* g, void* dw0, void* dw1, void* dw2, void* dg, int64_t K, int dtype,
                           void* scratch, size_t scratch_bytes, void* hip_stream);

@@ -188,3 +188,38 @@ def test_cfg5_fused_norm_linear_matches_separate_ops():
         assert p1.grad is not None and torch.isfinite(p1.grad.float()).all(), n
         rel = 2.0 ** -3 if "relative_attention_bias" in n else 2.0 ** -4  # (every activation differs in its last bf16 bit between the two formulations)
         assert maxdiff(p1.grad, p0.grad) <= rel * max(p0.grad.float().abs().max().item(), 1e-6), (n, maxdiff(p1.grad, p0.grad))
+
+
+def test_rmsnorm_linear_return_residual_joins_the_gradients_in_the_kernel():
+    """`h + f(norm(h))` with the residual alias handed back by rmsnorm_linear: same forward bits, and the input gradient equals
+    dx + dres (the fused kernel adds in fp32 and rounds once: within one ulp of autograd's rounded sum of two rounded terms)"""
+    from flasht5_amd import rmsnorm_linear, linear_residual
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(512, 768, generator=g).cuda().bfloat16()
+    gw = (1 + 0.1 * torch.randn(768, generator=g)).cuda().bfloat16()
+    W = (torch.randn(1536, 768, generator=g) / 768 ** 0.5).cuda().bfloat16()
+    Wo = (torch.randn(768, 1536, generator=g) / 1536 ** 0.5).cuda().bfloat16()
+    dout = torch.randn(512, 768, generator=g).cuda().bfloat16()
+    outs = []
+    for fused in (False, True):
+        xs, gs, Ws, Wos = (t.clone().requires_grad_() for t in (x, gw, W, Wo))
+        if fused:
+            y, res = rmsnorm_linear(xs, gs, Ws, 1e-6, return_residual=True)
+        else:
+            y, res = rmsnorm_linear(xs, gs, Ws, 1e-6), xs
+        out = linear_residual(torch.nn.functional.gelu(y, approximate="tanh"), Wos, res)
+        out.backward(dout)
+        outs.append((out.detach(), xs.grad, gs.grad, Ws.grad, Wos.grad))
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    for u, v in zip(a[2:], b[2:]):
+        assert torch.equal(u, v)
+    # (autograd rounds dx, then rounds dx + dres; the kernel rounds the fp32 sum once: they differ by the rounding of the larger TERM)
+    d = (a[1].float() - b[1].float()).abs()
+    term = torch.maximum(torch.maximum(a[1].float().abs(), dout.float().abs()), (a[1].float() - dout.float()).abs())
+    assert bool((d <= 2.0 ** -7 * term.clamp_min(1e-2)).all()), float((d / term.clamp_min(1e-2)).max())
+    # the alias alone (projection output unused): the gradient passes through
+    xs = x.clone().requires_grad_()
+    _, res = rmsnorm_linear(xs, gw, W, 1e-6, return_residual=True)
+    res.backward(dout)
+    assert torch.equal(xs.grad, dout)
