@@ -609,12 +609,23 @@ int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, 
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "linear_fused: grid too large");
   hipStream_t stream = (hipStream_t)stream_;
   const bool bf16 = dtype == FAT5_BF16;
+  // Stage ring of the kernel (linear_fused.h): two 32-KiB stages leave room for two workgroups per CU -- what a grid of more than 256
+  // tiles wants (measured, tools/lin_tune.py: 4096 x 4096 x 768 38.9 us against 49 us with three or four stages and one workgroup
+  // per CU); a grid that gives every CU at most one tile runs a deeper ring instead (4096 x 768 x 2048: 27.8 against 31.5 us).
+  using LC2 = LinCfgT<64, 2>; using LC3 = LinCfgT<64, 3>; using LC4 = LinCfgT<64, 4>;
+  const int ring = grid > 256 ? 2 : (K >= 1024 ? 4 : (grid > 128 ? 3 : 2));
+#define LIN_LAUNCH_C(BF, NO, RE, CFG)                                                                                           \
+  do {                                                                                                                          \
+    auto kern = linear_fused_kernel<BF, NO, RE, CFG>;                                                                           \
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::SMEM); \
+    if (ea != hipSuccess) return hip_fail(ea, "linear_fused attribute");                                                        \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), CFG::SMEM, stream, p);                                            \
+  } while (0)
 #define LIN_LAUNCH(BF, NO, RE)                                                                                                  \
   do {                                                                                                                          \
-    auto kern = linear_fused_kernel<BF, NO, RE>;                                                                                \
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LinCfg::SMEM); \
-    if (ea != hipSuccess) return hip_fail(ea, "linear_fused attribute");                                                        \
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LinCfg::SMEM, stream, p);                                         \
+    if (ring == 4) LIN_LAUNCH_C(BF, NO, RE, LC4);                                                                               \
+    else if (ring == 3) LIN_LAUNCH_C(BF, NO, RE, LC3);                                                                          \
+    else LIN_LAUNCH_C(BF, NO, RE, LC2);                                                                                         \
   } while (0)
   if (bf16) {
     if (norm && res) LIN_LAUNCH(true, true, true);
@@ -627,6 +638,7 @@ int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, 
     else if (res) LIN_LAUNCH(false, false, true);
     else LIN_LAUNCH(false, false, false);
   }
+#undef LIN_LAUNCH_C
 #undef LIN_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "linear_fused launch");

@@ -22,15 +22,17 @@
 
 namespace fat5 {
 
-struct LinCfg {
-  static constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-  static constexpr int IMG = rm_bytes<BK, BM>();      // one 128-row x 64-element image: 16 KiB
+// BK_ elements of K per stage, NS_ stages in the ring
+template <int BK_, int NS_>
+struct LinCfgT {
+  static constexpr int BM = 128, BN = 128, BK = BK_, NS = NS_, NT = 256;
+  static constexpr int IMG = rm_bytes<BK, BM>();      // one 128-row x BK-element image
   static constexpr int STAGE = 2 * IMG;               // A + W
   static constexpr int CROW = 2 * BN + 8;             // staged output row: 256 bytes + 8 (bank spread for the per-lane row writes)
-  static constexpr int RSTD = 2 * STAGE;              // 128 floats behind the two stages
-  static constexpr int SMEM = 2 * STAGE + BM * 4;
-  static_assert(BM * CROW <= 2 * STAGE, "output staging reuses the operand stages");
+  static constexpr int SMEM = NS * STAGE;
+  static_assert(BM * CROW <= NS * STAGE, "output staging reuses the operand stages");
 };
+using LinCfg = LinCfgT<64, 2>;
 
 template <bool BF16>
 FAT5_DEV void dot2_acc(float& acc, uint32_t a) {
@@ -137,12 +139,10 @@ struct LinArgs {
   float eps;
 };
 
-template <bool BF16, bool NORM, bool RES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void linear_fused_kernel(const LinArgs p) {
-  using Cfg = LinCfg;
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::NT, IMG = Cfg::IMG;
+template <bool BF16, bool NORM, bool RES, typename Cfg = LinCfg>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2 * Cfg::SMEM <= 160 * 1024 ? 2 : 1))) void linear_fused_kernel(const LinArgs p) {
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NS = Cfg::NS, NT = Cfg::NT, IMG = Cfg::IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sR = reinterpret_cast<float*>(smem + Cfg::RSTD);
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;
   const int wm = w >> 1, wn = w & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   const int nk = p.K / BK;
 
   using Dma = DmaStage<BK, BM, NT>;
-  static_assert(Dma::NV == 1 && Dma::PER == 4, "four 1-KiB pieces per wave and tile");
+  static_assert(Dma::NV == 1, "one swizzle phase per piece");
+  constexpr int PER = Dma::PER;  // 1-KiB pieces per wave, operand and stage
   Dma ast, wst;
   ast.init(p.lda, tid);
   wst.init(p.ldw, tid);
@@ -159,12 +160,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   const __amdgpu_buffer_rsrc_t wrs = make_rows_rsrc(p.w + (int64_t)n0 * p.ldw, p.ldw, min(BN, p.N - n0), p.K);
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)w * 1024u);
-  auto dma_stage = [&](int kt, int buf) {
+  auto dma_stage = [&](int kt, int slot) {
     const uint32_t koff = (uint32_t)(kt * BK * 2);
 #pragma unroll
-    for (int i = 0; i < Dma::PER; ++i) dma16_asm(ars, wave_lds + (uint32_t)(buf * Cfg::STAGE + NT * 16 * i), ast.voff[0], koff + ast.piece_step * i);
+    for (int i = 0; i < PER; ++i) dma16_asm(ars, wave_lds + (uint32_t)(slot * Cfg::STAGE + NT * 16 * i), ast.voff[0], koff + ast.piece_step * i);
 #pragma unroll
-    for (int i = 0; i < Dma::PER; ++i) dma16_asm(wrs, wave_lds + (uint32_t)(buf * Cfg::STAGE + IMG + NT * 16 * i), wst.voff[0], koff + wst.piece_step * i);
+    for (int i = 0; i < PER; ++i) dma16_asm(wrs, wave_lds + (uint32_t)(slot * Cfg::STAGE + IMG + NT * 16 * i), wst.voff[0], koff + wst.piece_step * i);
+  };
+  // wait until all but the last `stages` requested stages of this wave have landed (LDS-DMA requests retire in order)
+  auto wait_but = [&](int stages) {
+    if constexpr (NS >= 4) if (stages >= 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER * 2) : "memory"); return; }
+    if constexpr (NS >= 3) if (stages >= 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER * 1) : "memory"); return; }
+    wait_dma_all();
   };
 
   FragAddr<BK> fa;
@@ -176,20 +183,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
-  float ss = 0.f;  // NORM: this thread's share of sum_k a[row][k]^2, row = tid / 2, 32 of every 64 elements
-  const int srow = tid >> 1, shalf = tid & 1;
+  // NORM: sum_k a[row][k]^2 of the lane's OWN two rows (64 wm + 32 mb + lq), from the A fragments on their way into the MFMAs (a lane
+  // holds chunk 2 kk + hi of its row: the two halves of a wave meet in one cross-lane add at the end) -- the rows whose scale
+  // the lane needs in the epilogue, so the statistics never go through LDS
+  float ss[2] = {0.f, 0.f};
 
-  dma_stage(0, 0);
+  // Ring: stage kt lives in slot kt % NS.  Iteration kt: wait for the own pieces of stage kt (everything but the NS - 2 younger
+  // requests), barrier (all pieces of kt are in LDS, and every wave is done with the reads of kt - 1), request stage kt + NS - 1
+  // into the slot of kt - 1, contract stage kt.  NS - 1 stages are in flight while one is contracted; ONE barrier per iteration.
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) dma_stage(s0, s0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      dma_stage(kt + 1, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER) : "memory");  // everything but the stage just requested
-    } else {
-      wait_dma_all();
-    }
+    const int slot = kt % NS;
+    wait_but(min(NS - 2, nk - 1 - kt));
     __syncthreads();
-    const char* imgA = smem + buf * Cfg::STAGE;
+    if (kt + NS - 1 < nk) dma_stage(kt + NS - 1, (kt + NS - 1) % NS);
+    const char* imgA = smem + slot * Cfg::STAGE;
     const char* imgW = imgA + IMG;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -202,32 +212,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = mfma32<BF16>(wf[nb], af[mb], acc[nb][mb]);
-    }
-    if constexpr (NORM) {
+      if constexpr (NORM) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(imgA + rm_off<BK>(srow, 4 * shalf + c));
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dot2_acc<BF16>(ss, v[j]);
+          for (int j = 0; j < 4; ++j) dot2_acc<BF16>(ss[mb], af[mb][j]);
       }
     }
-    __syncthreads();  // this stage is free for the request of the next iteration
   }
+  __syncthreads();  // (the ring becomes the output staging area)
+  float rs[2] = {1.f, 1.f};
   if constexpr (NORM) {
-    ss += __shfl_xor(ss, 1, 64);
-    const float rstd = rsqrtf(ss / (float)p.K + p.eps);
-    if (shalf == 0) {
-      sR[srow] = rstd;
-      if (nt == 0 && p.rstd_out && m0 + srow < p.M) p.rstd_out[m0 + srow] = rstd;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const float tot = ss[mb] + __shfl_xor(ss[mb], 32, 64);
+      rs[mb] = rsqrtf(tot / (float)p.K + p.eps);
+      const int m = m0 + 64 * wm + 32 * mb + lq;
+      if (nt == 0 && wn == 0 && hi == 0 && p.rstd_out && m < p.M) p.rstd_out[m] = rs[mb];
     }
-    __syncthreads();
   }
   // ---- epilogue: scale, round, stage the 128 x 128 tile in LDS as rows of m, leave as whole rows (+ residual) ----
   char* sC = smem;
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int ml = 64 * wm + 32 * mb + lq;
-    const float sc = NORM ? sR[ml] : 1.f;
+    const float sc = rs[mb];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
