@@ -215,3 +215,68 @@ def test_native_torch_binding_loads_and_exports(lib):
         assert callable(getattr(nat, name))
     import ctypes
     assert nat.sizeof_attn_params() == ctypes.sizeof(_lib.AttnParams)
+
+
+def test_packed_slice_detection_and_unpack_fallback():
+    """host logic of the packed q / k / v path without a GPU: which tensors count as slices of one projection output
+    (flash_attention_v2_bias.packed_slices), the layout of the gradient buffer handed out for them, and unpack_heads' backward --
+    the packed buffer when the gradients are its slices, one stack otherwise -- against autograd's own select path"""
+    from flasht5_amd.flash_attention_v2_bias import packed_slices, empty_packed_like
+    from flasht5_amd.attention_module import unpack_heads
+    B, S, H, D = 2, 5, 3, 8
+    x = torch.randn(B, S, 3 * H * D)
+    p5 = x.view(B, S, 3, H, D)
+    q, k, v = (p5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    assert packed_slices((q, k, v)) and not packed_slices((q, v, k)) and not packed_slices((k, v))  # (k, v alone: a row holds three slices)
+    assert not packed_slices((q.contiguous(), k.contiguous(), v.contiguous()))
+    kv = torch.randn(B, S, 2 * H * D).view(B, S, 2, H, D)
+    assert packed_slices((kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)))
+    g = empty_packed_like((q, k, v))
+    assert all(t.shape == q.shape and t.stride() == q.stride() for t in g) and packed_slices(g)
+
+    # unpack_heads: same views, and both backward paths give the gradient of the select formulation
+    xs = x.clone().requires_grad_()
+    parts = unpack_heads(xs, 3, H)
+    assert all(torch.equal(a, b) and a.stride() == b.stride() for a, b in zip(parts, (q, k, v)))
+    w = [torch.randn(B, H, S, D) for _ in range(3)]
+    sum((a * b).sum() for a, b in zip(parts, w)).backward()                      # unpacked gradients -> the stack fallback
+    xr = x.clone().requires_grad_()
+    r5 = xr.view(B, S, 3, H, D)
+    sum((r5[:, :, i].permute(0, 2, 1, 3) * w[i]).sum() for i in range(3)).backward()
+    assert torch.equal(xs.grad, xr.grad)
+
+    class PackedGrad(torch.autograd.Function):  # stands in for the attention backward: gradients as slices of one buffer
+        @staticmethod
+        def forward(ctx, a, b, c):
+            ctx.save_for_backward(a, b, c)
+            return a + 0, b + 0, c + 0
+
+        @staticmethod
+        def backward(ctx, ga, gb, gc):
+            out = empty_packed_like(ctx.saved_tensors)
+            for o, gi in zip(out, (ga, gb, gc)):
+                o.copy_(gi)
+            return out
+    xs2 = x.clone().requires_grad_()
+    outs = PackedGrad.apply(*unpack_heads(xs2, 3, H))
+    real_stack, calls = torch.stack, []
+    torch.stack = lambda *a, **kw: (calls.append(1), real_stack(*a, **kw))[1]
+    try:
+        sum((a * b).sum() for a, b in zip(outs, w)).backward()
+    finally:
+        torch.stack = real_stack
+    assert not calls and torch.equal(xs2.grad, xr.grad)
+
+
+def test_graphed_train_step_and_capturable_optimizer_argument_checks():
+    from flasht5_amd import GraphedTrainStep, AdamWScale
+    lin = torch.nn.Linear(8, 8)
+    with pytest.raises(TypeError):
+        GraphedTrainStep(lin, torch.optim.SGD(lin.parameters(), lr=0.1))
+    opt = AdamWScale(lin.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError):
+        opt.graph_advance()  # nothing captured
+    opt.init_state()        # CPU parameters: state is created, no device arena
+    assert all("exp_avg" in opt.state[p] for p in lin.parameters()) and opt._graph_arena == {}
+    with pytest.raises(RuntimeError):
+        opt._arena_take(torch.device("cpu"), 64)
