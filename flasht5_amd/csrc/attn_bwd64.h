@@ -65,8 +65,11 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 }
 
 
+// (b, h, nblk): the key block of this workgroup; part_row: its row among the a.part_stride partial diagonal-sum rows of (b, h);
+// part_zero_next: the row behind it is nobody's and has to read zero (a 256-key workgroup of a launch that counts rows in
+// 128-key units: attn_bwd_kv64_mixed_kernel)
 template <int D, bool BF16, int BIAS, bool HALF>
-FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
+FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
   using Cfg = Bwd64Cfg<D, HALF>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
@@ -76,8 +79,6 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
   const int pr = HALF ? (w >> 1) : 0;  // HALF: wave pair = which half of the query steps
   const int wp = HALF ? (w & 1) : w;   // wave inside its pair / workgroup = which 64 keys
-  int b, h, nblk;
-  decode_unit(a, bid, a.n_nblk, b, h, nblk);
   const int bh = b * a.H + h;
   const int M = a.M, N = a.N;
   const int n0 = nblk * BNK;
@@ -670,12 +671,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int bid) {
         sD0[(2 * w) * n1 + 2 * a.R] += far_pos;
       }
       __syncthreads();
-      float* out = a.drpe_part + ((int64_t)bh * a.n_nblk + nblk) * n1;
+      float* out = a.drpe_part + ((int64_t)bh * a.part_stride + part_row) * n1;
       for (int i2 = tid; i2 < n1; i2 += NT) {
         float acc = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 2 * Cfg::NW; ++ww) acc += sD0[ww * n1 + i2];
         out[i2] = acc;
+        if (part_zero_next) out[n1 + i2] = 0.f;
       }
     }
   }
@@ -1156,7 +1158,42 @@ void attn_bwd_q64_kernel(const AttnArgs a) {
 template <int D, bool BF16, int BIAS, bool HALF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_kv64_kernel(const AttnArgs a) {
-  attn_bwd_kv64_body<D, BF16, BIAS, HALF>(a, blockIdx.x);
+  int b, h, nblk;
+  decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+  // (part_rows2: a 256-key launch over some units of a problem whose other units run half-length -- a unit range of a mixed launch)
+  const bool two = !HALF && a.part_rows2;
+  attn_bwd_kv64_body<D, BF16, BIAS, HALF>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);
+}
+
+// Both variants in one launch.  One workgroup per CU (512 registers per lane): `w` 256-key workgroups take ceil(w / 256) rounds, the
+// last of them mostly empty at mid sizes ((4,12,2048,64): 384 = 1.5 rounds).  Here the first a.mix_full (b, h) pairs of every XCD
+// run as 256-key workgroups -- whole rounds -- and the others as 128-key half-length ones (two per key block, ~0.65-0.73 of a full
+// workgroup's time each), which fill the last round evenly: 1 + 0.7 instead of 2 rounds.  Workgroup -> XCD as in decode_block
+// (blockIdx % 8; pairs dealt round-robin), full pairs first inside every XCD.  Pairs are numbered HEAD-major here (u = h * B + b,
+// the numbering of unit ranges): the full-length pairs are then the units [0, 8 * mix_full) and a unit-range launch of the same
+// problem splits into at most one 256-key and one half-length launch that run every pair through the same body -- sharded and
+// unsharded results stay bit-identical.  Partial diagonal sums: a.part_stride = 128-key rows per pair; a 256-key workgroup j
+// writes row 2j and zeroes row 2j + 1.
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_kv64_mixed_kernel(const AttnArgs a) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int nth = a.part_stride, ntf = (a.N + 255) / 256;
+  const int nfull = a.mix_full * ntf;
+  int pair, tile;
+  const bool full = idx < nfull;
+  if (full) {
+    pair = idx / ntf;
+    tile = idx - pair * ntf;
+  } else {
+    const int i2 = idx - nfull;
+    pair = a.mix_full + i2 / nth;
+    tile = i2 - (i2 / nth) * nth;
+  }
+  const int ui = pair * 8 + xcd;
+  const int h = ui / a.B, b = ui - h * a.B;
+  if (full) attn_bwd_kv64_body<D, BF16, BIAS, false>(a, b, h, tile, 2 * tile, 2 * tile + 1 < nth);
+  else attn_bwd_kv64_body<D, BF16, BIAS, true>(a, b, h, tile, tile, false);
 }
 
 }  // namespace fat5

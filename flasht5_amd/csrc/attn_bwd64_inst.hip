@@ -1,6 +1,7 @@
 // Instantiations of the 64-keys-per-wave pipelined dK/dV body (attn_bwd64.h) for one head_dim (-DFAT5_INST_D=64).
 #include "attn_bwd64.h"
 #include "attn_launch.h"
+#include <algorithm>
 
 #ifndef FAT5_INST_D
 #error "FAT5_INST_D must be defined"
@@ -45,8 +46,25 @@ static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int gr
     return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, HALF>(a, grid, s);
   return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_NONE, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_NONE, HALF>(a, grid, s);
 }
-// nw == 2: the half-length variant (128-key workgroups, two wave pairs each walking half of the query steps); otherwise 256 keys
+template <int D, bool BF16, int BIAS>
+static hipError_t launch_kv64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS), Bwd64Cfg<D, true>::smem(a.R, BIAS));
+  auto kern = attn_bwd_kv64_mixed_kernel<D, BF16, BIAS>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+// nw == 2: the half-length variant (128-key workgroups, two wave pairs each walking half of the query steps); nw == 3: both in one
+// launch (a.mix_full pairs per XCD as 256-key workgroups, the others half-length); otherwise 256 keys
 hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  if (nw == 3) {
+    if (bias == FAT5_BIAS_RPE1D)
+      return bf16 ? launch_kv64_mixed<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_kv64_mixed<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
+    return bf16 ? launch_kv64_mixed<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_kv64_mixed<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
+  }
   return nw == 2 ? launch_kv64_bias<true>(a, bf16, bias, grid, s) : launch_kv64_bias<false>(a, bf16, bias, grid, s);
 }
 size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }

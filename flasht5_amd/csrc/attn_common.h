@@ -270,6 +270,9 @@ struct AttnArgs {
   int32_t bias_dma;         // dense bias rows are 16-byte aligned: tiles can go global -> LDS directly
   int32_t n_mblk, n_nblk;   // tiles per (b,h) for the m-parallel / n-parallel kernels
   int32_t n_kv_blocks;      // fused backward launch: workgroups [0, n_kv_blocks) run the dK/dV body
+  int32_t mix_full;         // attn_bwd_kv64_mixed_kernel: (b, h) pairs per XCD that run as 256-key workgroups
+  int32_t part_stride;      // 64-key dK/dV bodies: partial diagonal-sum rows per (b, h) (= n_nblk unless 256-key and half-length workgroups share a problem)
+  int32_t part_rows2;       // ... and a 256-key workgroup j owns rows 2j, 2j + 1 of them
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
   float scale;

@@ -49,6 +49,7 @@ struct BwdLayout {
   size_t delta_off, stat2_off, ds_off, drpe_off, scratch_off, total;
   bool kv64;        // dK/dV by the 64-keys-per-wave pipelined body (attn_bwd64.h); the dQ kernel then also writes its statistics
   bool kv64_half;   // ... in its half-length variant (128-key workgroups: two wave pairs, each half of the query steps)
+  int kv64_mix_pf;  // > 0: both variants in one launch, this many (b, h) pairs per XCD as 256-key workgroups (attn_bwd_kv64_mixed_kernel)
   bool q64;         // dQ by the 64-rows-per-wave pipelined body (attn_bwd64.h)
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
@@ -210,16 +211,63 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   // the 64-key bodies take over only without bias.
   const long wg256 = bh * ((p->N + 255) / 256);
   const int kvh_env = vsel(p->variant, FAT5_V_KV64_HALF_ON, FAT5_V_KV64_HALF_OFF);
+  const int mix_env = vsel(p->variant, FAT5_V_KV64_MIX_ON, FAT5_V_KV64_MIX_OFF);
   const double r_full = (double)((wg256 + 255) / 256), r_half = 0.5 * 1.04 * (double)((2 * wg256 + 255) / 256);
   L.kv64_half = kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full);
-  const size_t kv64_lds = L.kv64_half ? smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode) : smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode);
+  // Both variants in one launch (attn_bwd_kv64_mixed_kernel): the first `pf` (b, h) pairs of every XCD as 256-key workgroups, the
+  // others half-length.  pf by a list-scheduling model of one XCD (32 CUs, one workgroup per CU, launch order; a half-length
+  // workgroup costs 0.65 of a full one without bias, 0.73 with the T5 bias: measured round times 56 / 36 us and 70 / 51 us at
+  // S = 2048); taken when it beats both pure variants by 5 %.
+  L.kv64_mix_pf = -1;
+  double mix_gain = 1.0;
+  if (bh % 8 == 0 && mix_env != 0 && kvh_env == -1) {
+    const int per = (int)(bh / 8), ntf = (p->N + 255) / 256, nth = (p->N + 127) / 128;
+    const double rh = p->bias_mode == FAT5_BIAS_NONE ? 0.65 : 0.73;
+    auto makespan = [&](int pf) {
+      double t[32] = {0};
+      const long nfull = (long)pf * ntf, nall = nfull + (long)(per - pf) * nth;
+      for (long i = 0; i < nall; ++i) {
+        int best = 0;
+        for (int c = 1; c < 32; ++c)
+          if (t[c] < t[best]) best = c;
+        t[best] += i < nfull ? 1.0 : rh;
+      }
+      double m = 0;
+      for (int c = 0; c < 32; ++c) m = std::max(m, t[c]);
+      return m;
+    };
+    if ((long)per * nth <= 4096) {  // (the model walks every workgroup of an XCD)
+      const double pure = std::min(makespan(per), L.kv64_half || p->bias_mode == FAT5_BIAS_NONE ? makespan(0) : 1e30);
+      double best = 1e30;
+      int best_pf = -1;
+      for (int pf = 1; pf < per; ++pf) {
+        const double m = makespan(pf);
+        if (m < best) { best = m; best_pf = pf; }
+      }
+      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure)) {
+        L.kv64_mix_pf = best_pf;
+        mix_gain = best / makespan(per);
+      }
+    }
+  }
+  const size_t kv64_lds = L.kv64_mix_pf > 0 ? std::max(smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode), smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode))
+                                            : (L.kv64_half ? smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode) : smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode));
+  // (the 64-key bodies take over from the 32-key one at 512 workgroups of 256 keys; from 320 where the last round is filled by
+  //  half-length workgroups -- the mixed launch, or without bias the pure half-length variant)
+  const bool fills = L.kv64_mix_pf > 0 ? mix_gain <= 0.9 : L.kv64_half;
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || wg256 >= (L.kv64_half ? 320 : 512)) && kv64_lds <= 160 * 1024;
-  if (L.kv64) {
+           (b64_env == 1 || wg256 >= (fills ? 320 : 512)) && kv64_lds <= 160 * 1024;
+  if (L.kv64 && L.kv64_mix_pf > 0) {
+    L.kv64_half = false;
+    L.nw_kv = 3;  // (launch_bwd_kv64: 3 selects the mixed launch)
+    L.n_nblk = (p->N + 127) / 128;
+  } else if (L.kv64) {
+    L.kv64_mix_pf = -1;
     L.nw_kv = L.kv64_half ? 2 : 4;  // (launch_bwd_kv64: 2 selects the half-length variant)
     L.n_nblk = L.kv64_half ? (p->N + 127) / 128 : (p->N + 255) / 256;
   } else {
     L.kv64_half = false;
+    L.kv64_mix_pf = -1;
   }
   const int q64_env = vsel(p->variant, FAT5_V_Q64_ON, FAT5_V_Q64_OFF);
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
@@ -396,7 +444,31 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     if (stages & FAT5_BWD_DKDV) {
       launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
       if (L.kv64) fn = launch_bwd_kv64_d64;
-      hipError_t e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)grid_kv, stream);
+      a.part_stride = a.n_nblk;
+      hipError_t e = hipSuccess;
+      if (L.kv64 && L.kv64_mix_pf > 0 && p->unit_count == 0) {
+        // (a.n_nblk counts 128-key rows; the 256-key workgroups cover two of them each)
+        a.mix_full = L.kv64_mix_pf;
+        const long gkv = 8L * ((long)L.kv64_mix_pf * ((p->N + 255) / 256) + (bh / 8 - L.kv64_mix_pf) * (long)a.n_nblk);
+        e = fn(a, bf16, p->bias_mode, 3, (int)gkv, stream);
+      } else if (L.kv64 && L.kv64_mix_pf > 0) {
+        // a unit range of a problem whose whole-problem launch is mixed: units [0, 8 pf) are the 256-key pairs (head-major numbering,
+        // attn_bwd_kv64_mixed_kernel) -> at most one 256-key and one half-length launch, every pair through the body it has unsharded
+        const int split = 8 * L.kv64_mix_pf, ub = p->unit_begin, ue = p->unit_begin + p->unit_count;
+        AttnArgs af = a;
+        if (ub < std::min(ue, split)) {
+          af.unit_begin = ub; af.unit_count = std::min(ue, split) - ub;
+          af.n_nblk = (p->N + 255) / 256; af.part_rows2 = 1;
+          e = fn(af, bf16, p->bias_mode, 4, (int)((long)af.unit_count * af.n_nblk), stream);
+        }
+        if (e == hipSuccess && std::max(ub, split) < ue) {
+          af = a;
+          af.unit_begin = std::max(ub, split); af.unit_count = ue - af.unit_begin;
+          e = fn(af, bf16, p->bias_mode, 2, (int)((long)af.unit_count * af.n_nblk), stream);
+        }
+      } else {
+        e = fn(a, bf16, p->bias_mode, L.nw_kv, (int)grid_kv, stream);
+      }
       if (e != hipSuccess) return hip_fail(e, "attn_bwd_kv launch");
     }
   }

@@ -221,3 +221,37 @@ def test_bwd64_stage_split_equals_one_call():
         torch.cuda.synchronize()
         for x, y in ((a.dq, b.dq), (a.dk, b.dk), (a.dv, b.dv), (a.dbias, b.dbias)):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,mode", [
+    (4, 12, 2048, 2048, False, "rpe"),    # the shape the mixed launch is for: 48 (b, h) pairs, 384 256-key workgroups = 1.5 rounds
+    (4, 12, 2048, 2048, True, "none"),
+    (2, 8, 1100, 1300, False, "rpe"),     # ragged: an odd number of 128-key rows (the last 256-key workgroup has no second row to zero)
+    (4, 4, 512, 768, True, "rpe"),        # M < N, bottom-right causal
+])
+def test_bwd64_mixed_launch_matches_the_256_key_launch(B, H, M, N, causal, mode):
+    """256-key and half-length workgroups in ONE launch (attn_bwd_kv64_mixed_kernel: the first pairs of every XCD full, the others
+    half-length) against the plain 256-key launch: dq identical (the dQ kernel is the same), dk / dv equal to output rounding of
+    the same fp32 sums in another order, the table gradient to fp32 summation order; and against the oracle's bound."""
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    q, k, v, _, do = make_inputs(B, H, M, N, 64, torch.bfloat16, None, seed=M + N, strided=True)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    kw = dict(causal=causal, sm_scale=0.125)
+    if mode == "rpe":
+        kw.update(rpe1d=pe.rpe1d_from_table(table), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+    outs = []
+    for bits in (_lib.V_KV64_ON | _lib.V_Q64_ON | _lib.V_KV64_HALF_OFF | _lib.V_KV64_MIX_OFF, _lib.V_KV64_ON | _lib.V_Q64_ON | _lib.V_KV64_MIX_ON):
+        plan = AttentionPlan(q, k, v, do, variant=bits, **kw)
+        plan.forward(); plan.backward(); torch.cuda.synchronize()
+        outs.append([t.clone() for t in (plan.dq, plan.dk, plan.dv)] + ([plan.dbias.clone()] if plan.dbias is not None else []))
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:3], b[1:3]):
+        assert maxdiff(x, y) <= 2.0 ** -7 * float(x.float().abs().max())
+    if mode == "rpe":
+        assert maxdiff(a[3], b[3]) <= 1e-3 * max(1.0, float(a[3].abs().max()))
+    ref = oracle_all(q, k, v, pe.compute_bias(table, M, N).to(torch.bfloat16) if mode == "rpe" else None, do, 0.125, causal)
+    for key, got in zip(("dq", "dk", "dv"), b[:3]):
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], torch.bfloat16), key
