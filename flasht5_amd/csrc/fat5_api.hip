@@ -223,20 +223,24 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   if (bh % 8 == 0 && mix_env != 0 && kvh_env == -1) {
     const int per = (int)(bh / 8), ntf = (p->N + 255) / 256, nth = (p->N + 127) / 128;
     const double rh = p->bias_mode == FAT5_BIAS_NONE ? 0.65 : 0.73;
+    // Greedy list scheduling with two job sizes, without walking the jobs (this runs on the host inside every backward call): the F unit
+    // jobs leave `rem` CUs at load a + 1 and the others at a; the k-th half-length job of a CU starts at load + (k - 1) * rh, greedy fills
+    // these start slots in increasing order, so the makespan is (Hn-th smallest start) + rh -- O(Hn / 32) steps per candidate.
     auto makespan = [&](int pf) {
-      double t[32] = {0};
-      const long nfull = (long)pf * ntf, nall = nfull + (long)(per - pf) * nth;
-      for (long i = 0; i < nall; ++i) {
-        int best = 0;
-        for (int c = 1; c < 32; ++c)
-          if (t[c] < t[best]) best = c;
-        t[best] += i < nfull ? 1.0 : rh;
+      const long F = (long)pf * ntf, Hn = (long)(per - pf) * nth;
+      const long a = F / 32, rem = F % 32, n_lo = 32 - rem, n_hi = rem;
+      const double base = (double)(a + (rem ? 1 : 0));
+      if (Hn == 0) return base;
+      long jl = 0, jh = 0, count = 0;
+      double t = 0;
+      while (count < Hn) {
+        const double tl = (double)a + jl * rh, th = (double)(a + 1) + jh * rh;
+        if (n_hi == 0 || tl <= th) { t = tl; count += n_lo; ++jl; }
+        else { t = th; count += n_hi; ++jh; }
       }
-      double m = 0;
-      for (int c = 0; c < 32; ++c) m = std::max(m, t[c]);
-      return m;
+      return std::max(t + rh, base);
     };
-    if ((long)per * nth <= 4096) {  // (the model walks every workgroup of an XCD)
+    {
       const double pure = std::min(makespan(per), L.kv64_half || p->bias_mode == FAT5_BIAS_NONE ? makespan(0) : 1e30);
       double best = 1e30;
       int best_pf = -1;
@@ -255,8 +259,13 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   // (the 64-key bodies take over from the 32-key one at 512 workgroups of 256 keys; from 320 where the last round is filled by
   //  half-length workgroups -- the mixed launch, or without bias the pure half-length variant)
   const bool fills = L.kv64_mix_pf > 0 ? mix_gain <= 0.9 : L.kv64_half;
+  // Causal: the steps of a workgroup that touch the diagonal (256 keys / 32 rows = 8 of them) run the general, unpipelined iteration
+  // at ~2.5x the cost of a pipelined step -- half of all steps at S = 1024, 6 % at 8192.  Measured dK/dV, 64-key against 32-key body:
+  // (4,12,8192) 853 vs 940 us, (4,12,4096) 239 vs 246, (4,12,2048) T5 bias 118 vs 104, (16,12,2048) 298 vs 273, (16,12,1024) 111 vs 95
+  // -> causal problems take the 64-key body from 4096 keys on.
+  const bool kv64_causal_ok = !p->causal || p->N >= 4096;
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || wg256 >= (fills ? 320 : 512)) && kv64_lds <= 160 * 1024;
+           (b64_env == 1 || (wg256 >= (fills ? 320 : 512) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
   if (L.kv64 && L.kv64_mix_pf > 0) {
     L.kv64_half = false;
     L.nw_kv = 3;  // (launch_bwd_kv64: 3 selects the mixed launch)
@@ -270,8 +279,11 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     L.kv64_mix_pf = -1;
   }
   const int q64_env = vsel(p->variant, FAT5_V_Q64_ON, FAT5_V_Q64_OFF);
+  // (the 64-row dQ body: its prologue and the diagonal steps of a causal problem need long key streams to pay -- measured against the
+  //  32-row body: non-causal (16,12,1024) 92 vs 85 us, (4,12,8192) 1115 vs ~1250; causal (4,12,4096) 215 vs 189, (16,12,2048) 262 vs 202,
+  //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
-          (q64_env == 1 || bh * ((p->M + 255) / 256) >= 512);
+          (q64_env == 1 || (bh * ((p->M + 255) / 256) >= 512 && p->N >= 2048 && (!p->causal || p->M >= 16384)));
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;
