@@ -173,6 +173,10 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
       // (fp16: P would overflow at 2^16 without the running maximum, so its 64-row body is the exact, unpipelined pass -- still
       //  ahead of the 32-row body once the chip is full: 953 vs 987 us at (4,12,8192,64))
       (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 2048) &&
+                        // (512 keys are 8 tiles: too few for the pipeline's prologue to pay once the 32-row body fills the chip by itself
+                        //  -- tools/dispatch_audit.py: (16,12,512) 22.2 vs 24.8 us -- or when half of them sit on the causal diagonal:
+                        //  (4,12,512) causal 10.0 vs 11.2, (8,12,512) causal 15.7 vs 17.5)
+                        !(p->N <= 512 && (p->causal || waves64 > 1024)) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     fn = launch_fwd64_d64;
@@ -182,7 +186,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     // slower everywhere else (S = 1024: 22.0 vs 19.7 us, 4096: 207 vs 190, 8192: 794 vs 724).  The hardware packs the workgroups of the
     // last, half-empty round two to a CU, so the finer grain buys less than a per-SIMD issue model predicts.
     const int ks_env = vsel(p->variant, FAT5_V_FWD64_KSPLIT_ON, FAT5_V_FWD64_KSPLIT_OFF);
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512));
+    // Causal: the workgroups of a (b, h) pair have unequal lengths, finer units balance better -- (4,12,1024) 22.0 vs 23.5 us, (8,12,2048)
+    // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 || (p->causal && waves64 <= 8192)));
     nw = ksplit ? 2 : 4;
     a.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
   }
@@ -248,7 +254,9 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
         const double m = makespan(pf);
         if (m < best) { best = m; best_pf = pf; }
       }
-      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure)) {
+      // (causal: workgroups of unequal length -- the finer units of a mixed launch balance better than the uniform model says:
+      //  (4,12,4096) causal 218 vs 233 us, T5 bias 271 vs 285; (8,12,4096) 432 vs 445 / 526 vs 549)
+      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure || p->causal)) {
         L.kv64_mix_pf = best_pf;
         mix_gain = best / makespan(per);
       }
@@ -283,7 +291,9 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   //  32-row body: non-causal (16,12,1024) 92 vs 85 us, (4,12,8192) 1115 vs ~1250; causal (4,12,4096) 215 vs 189, (16,12,2048) 262 vs 202,
   //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
-          (q64_env == 1 || (bh * ((p->M + 255) / 256) >= 512 && p->N >= 2048 && (!p->causal || p->M >= 16384)));
+          (q64_env == 1 || (bh * ((p->M + 255) / 256) >= 512 && p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 8192 : 2048) &&
+                            (!p->causal || p->M >= 16384)));  // (T5 bias: its band steps are unpipelined here -- (8,12,2048) 170 vs 154 us,
+                                                              //  (16,12,2048) 345 vs 321, (4,12,4096) 291 vs 288, (4,12,8192) 1098 vs 1110)
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;

@@ -1,0 +1,78 @@
+"""Dispatch audit (developer tool): for a grid of shapes, every stage of the attention path timed with the library's own choice of
+kernel body and with each body forced (fat5_attn_params.variant) -- graph replay, i.e. GPU time without host time -- and a flag
+wherever the default is more than 5 % behind the best forced variant.  How the causal mis-dispatch of round 3 was found
+((16,12,1024) causal: the 64-wide backward bodies 20 % behind the 32-wide ones).
+
+    python tools/dispatch_audit.py [--bh 4x12,16x12] [--S 512,1024,2048,4096,8192] [--modes none,rpe] [--quick]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from attn_helpers import make_inputs
+from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+from flasht5_amd import positional_encoding as pe, _lib as L
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bh", default="4x12,8x12,16x12"); ap.add_argument("--S", default="512,1024,2048,4096,8192"); ap.add_argument("--modes", default="none,rpe")
+ap.add_argument("--max-work", type=float, default=48 * 8192.0 ** 2 * 1.01)
+a = ap.parse_args()
+
+FWD = {"default": 0, "32row": L.V_FWD64_OFF, "64row": L.V_FWD64_ON | L.V_FWD64_KSPLIT_OFF, "64row-ksplit": L.V_FWD64_ON | L.V_FWD64_KSPLIT_ON}
+DQ = {"default": 0, "32row": L.V_Q64_OFF, "64row": L.V_Q64_ON}
+KV = {"default": 0, "32key": L.V_KV64_OFF, "64key": L.V_KV64_ON | L.V_KV64_HALF_OFF | L.V_KV64_MIX_OFF, "64key-half": L.V_KV64_ON | L.V_KV64_HALF_ON,
+      "64key-mixed": L.V_KV64_ON | L.V_KV64_MIX_ON}
+
+
+def gpu_time(fn, it):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(it):
+            fn()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:  # leave the idle clock
+        g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / it * 1e3)
+    return best
+
+
+flags = []
+for bh in a.bh.split(","):
+    B, H = (int(x) for x in bh.split("x"))
+    for S in (int(x) for x in a.S.split(",")):
+        if B * H * float(S) ** 2 > a.max_work:
+            continue
+        for causal in (False, True):
+            for mode in a.modes.split(","):
+                q, k, v, _, do = make_inputs(B, H, S, S, 64, torch.bfloat16, None, seed=1, strided=True)
+                table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+                kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128) if mode == "rpe" else {}
+                plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=0.125, **kw)
+                plan.forward(); plan.backward(); torch.cuda.synchronize()
+                it = max(2, min(20, int(2e10 / (B * H * float(S) ** 2))))
+                line = f"({B:2d},{H},{S:5d}) {'causal' if causal else 'full  '} {mode:4s}"
+                fused = plan.bwd_launches() == 1  # (short problems: dQ and dK/dV share ONE launch -- the stage timings below are not the real path)
+                for stage, table_, fn in (("fwd", FWD, plan.forward), ("dq", DQ, lambda: plan.backward(1)), ("dkdv", KV, lambda: plan.backward(2))):
+                    if fused and stage != "fwd":
+                        line += f" | {stage}: (fused launch)"
+                        continue
+                    res = {}
+                    for name, bits in table_.items():
+                        plan.set_variant(bits)
+                        res[name] = gpu_time(fn, it)
+                    plan.set_variant(0)
+                    best = min((t, n) for n, t in res.items() if n != "default")
+                    bad = res["default"] > 1.05 * best[0]
+                    line += f" | {stage}: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
+                    if bad:
+                        flags.append((B, H, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
+                print(line, flush=True)
+                del plan, q, k, v, do
+print("\nmis-dispatches (> 5 % behind the best forced body):", len(flags))
+for f in flags:
+    print("  ", f)
