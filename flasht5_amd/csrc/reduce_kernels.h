@@ -35,29 +35,50 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
 #pragma unroll
   for (int j = 0; j < 8; ++j) vis[j] = true;
   if (causal_n > 0) {
+    if (full) {  // (the chunk lies inside one row: ONE division instead of eight 64-bit ones)
+      const int64_t m = e0 / causal_n;
+      const int64_t n0 = e0 - m * causal_n;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t idx = e0 + j, m = idx / causal_n;
-      vis[j] = (idx - m * causal_n) <= m + causal_p;
+      for (int j = 0; j < 8; ++j) vis[j] = n0 + j <= m + causal_p;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t idx = e0 + j, m = idx / causal_n;
+        vis[j] = (idx - m * causal_n) <= m + causal_p;
+      }
     }
   }
   const bool any_vis = vis[0] || !full;  // (full chunks lie inside one row: keys ascend, so the first one decides)
-  for (int b = b_lo; b < b_hi && any_vis; ++b)
-    for (int h = h_lo; h < h_hi; ++h) {
-      const uint16_t* src = ds + ((int64_t)b * H + h) * MN + e0;
-      if (full) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+  if (full && any_vis) {
+    // slices in groups of eight, every load of a group in flight before the first add (the sum keeps the order b-major, h-minor)
+    const int nb = b_hi - b_lo, nh = h_hi - h_lo, ns = nb * nh;
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+      u32x4 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[2 * j] += cvt_lo<BF16>(v[j]);
-          acc[2 * j + 1] += cvt_hi<BF16>(v[j]);
+      for (int u = 0; u < 8; ++u) {
+        const int si = min(s0 + u, ns - 1);
+        const int b = b_lo + si / nh, h = h_lo + si % nh;
+        v[u] = *reinterpret_cast<const u32x4*>(ds + ((int64_t)b * H + h) * MN + e0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < ns) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += cvt_lo<BF16>(v[u][j]);
+            acc[2 * j + 1] += cvt_hi<BF16>(v[u][j]);
+          }
         }
-      } else {
+    }
+  } else if (any_vis) {
+    for (int b = b_lo; b < b_hi; ++b)
+      for (int h = h_lo; h < h_hi; ++h) {
+        const uint16_t* src = ds + ((int64_t)b * H + h) * MN + e0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (e0 + j < MN && vis[j]) acc[j] += cvt16<BF16>(src[j]);
       }
-    }
+  }
   uint16_t* dst = out + ((int64_t)bb * Hb + hb) * MN + e0;
   if (full) {
     u32x4 v;
