@@ -173,10 +173,11 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
       // (fp16: P would overflow at 2^16 without the running maximum, so its 64-row body is the exact, unpipelined pass -- still
       //  ahead of the 32-row body once the chip is full: 953 vs 987 us at (4,12,8192,64))
       (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 2048) &&
-                        // (512 keys are 8 tiles: too few for the pipeline's prologue to pay once the 32-row body fills the chip by itself
-                        //  -- tools/dispatch_audit.py: (16,12,512) 22.2 vs 24.8 us -- or when half of them sit on the causal diagonal:
-                        //  (4,12,512) causal 10.0 vs 11.2, (8,12,512) causal 15.7 vs 17.5)
-                        !(p->N <= 512 && (p->causal || waves64 > 1024)) &&
+                        // (512 keys are 8 tiles: too few for the pipeline's prologue to pay when half of them sit on the causal diagonal --
+                        //  tools/dispatch_audit.py: (4,12,512) causal 10.0 vs 11.2 us, (8,12,512) causal 15.7 vs 17.5 -- or in the 1.5-waves-per-SIMD
+                        //  range where the 64-row waves fill the chip unevenly: (16,12,512) 22.2 vs 24.8; (16,12,1024x512) and (16,12,2048x512),
+                        //  2 and 4 full rounds, stay on the 64-row body: 33.6 vs 36.8, 62.4 vs 68.5)
+                        !(p->N <= 512 && (p->causal || (waves64 > 1024 && waves64 < 2048))) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     fn = launch_fwd64_d64;
@@ -188,7 +189,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     const int ks_env = vsel(p->variant, FAT5_V_FWD64_KSPLIT_ON, FAT5_V_FWD64_KSPLIT_OFF);
     // Causal: the workgroups of a (b, h) pair have unequal lengths, finer units balance better -- (4,12,1024) 22.0 vs 23.5 us, (8,12,2048)
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 || (p->causal && waves64 <= 8192)));
+    // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 ||
+                                                        (p->causal && waves64 <= 8192 && p->N < 2 * p->M)));
     nw = ksplit ? 2 : 4;
     a.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
   }

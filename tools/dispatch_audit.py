@@ -15,6 +15,7 @@ from flasht5_amd import positional_encoding as pe, _lib as L
 ap = argparse.ArgumentParser()
 ap.add_argument("--bh", default="4x12,8x12,16x12"); ap.add_argument("--S", default="512,1024,2048,4096,8192"); ap.add_argument("--modes", default="none,rpe")
 ap.add_argument("--max-work", type=float, default=48 * 8192.0 ** 2 * 1.01)
+ap.add_argument("--MN", default="")  # rectangular problems instead of --S: "512x1024,2048x512" (M x N)
 a = ap.parse_args()
 
 FWD = {"default": 0, "32row": L.V_FWD64_OFF, "64row": L.V_FWD64_ON | L.V_FWD64_KSPLIT_OFF, "64row-ksplit": L.V_FWD64_ON | L.V_FWD64_KSPLIT_ON}
@@ -44,18 +45,19 @@ def gpu_time(fn, it):
 flags = []
 for bh in a.bh.split(","):
     B, H = (int(x) for x in bh.split("x"))
-    for S in (int(x) for x in a.S.split(",")):
-        if B * H * float(S) ** 2 > a.max_work:
+    shapes = [tuple(int(v) for v in x.split("x")) for x in a.MN.split(",")] if a.MN else [(int(x), int(x)) for x in a.S.split(",")]
+    for M, S in shapes:  # (S: the number of keys)
+        if B * H * float(M) * S > a.max_work:
             continue
         for causal in (False, True):
             for mode in a.modes.split(","):
-                q, k, v, _, do = make_inputs(B, H, S, S, 64, torch.bfloat16, None, seed=1, strided=True)
+                q, k, v, _, do = make_inputs(B, H, M, S, 64, torch.bfloat16, None, seed=1, strided=True)
                 table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
                 kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128) if mode == "rpe" else {}
                 plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=0.125, **kw)
                 plan.forward(); plan.backward(); torch.cuda.synchronize()
-                it = max(2, min(20, int(2e10 / (B * H * float(S) ** 2))))
-                line = f"({B:2d},{H},{S:5d}) {'causal' if causal else 'full  '} {mode:4s}"
+                it = max(2, min(20, int(2e10 / (B * H * float(M) * S))))
+                line = f"({B:2d},{H},{M:5d}x{S:5d}) {'causal' if causal else 'full  '} {mode:4s}"
                 fused = plan.bwd_launches() == 1  # (short problems: dQ and dK/dV share ONE launch -- the stage timings below are not the real path)
                 for stage, table_, fn in (("fwd", FWD, plan.forward), ("dq", DQ, lambda: plan.backward(1)), ("dkdv", KV, lambda: plan.backward(2))):
                     if fused and stage != "fwd":
@@ -70,7 +72,7 @@ for bh in a.bh.split(","):
                     bad = res["default"] > 1.05 * best[0]
                     line += f" | {stage}: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
                     if bad:
-                        flags.append((B, H, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
+                        flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
                 print(line, flush=True)
                 del plan, q, k, v, do
 print("\nmis-dispatches (> 5 % behind the best forced body):", len(flags))
