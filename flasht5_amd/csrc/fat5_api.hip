@@ -276,7 +276,10 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   // -> causal problems take the 64-key body from 4096 keys on.
   const bool kv64_causal_ok = !p->causal || p->N >= 4096;
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || (wg256 >= (fills ? 320 : 512) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
+           (b64_env == 1 || ((wg256 >= (fills ? 320 : 512) ||
+                              // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
+                              //  (4,12,8192x1024) 190 vs 234; with the T5 bias 117 vs 146 and 213 vs 274)
+                              (wg256 >= 160 && p->M >= 4096 && !p->causal)) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
   if (L.kv64 && L.kv64_mix_pf > 0) {
     L.kv64_half = false;
     L.nw_kv = 3;  // (launch_bwd_kv64: 3 selects the mixed launch)
@@ -294,8 +297,8 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   //  32-row body: non-causal (16,12,1024) 92 vs 85 us, (4,12,8192) 1115 vs ~1250; causal (4,12,4096) 215 vs 189, (16,12,2048) 262 vs 202,
   //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
-          (q64_env == 1 || (bh * ((p->M + 255) / 256) >= 512 && p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 8192 : 2048) &&
-                            (!p->causal || p->M >= 16384)));  // (T5 bias: its band steps are unpipelined here -- (8,12,2048) 170 vs 154 us,
+          (q64_env == 1 || ((bh * ((p->M + 255) / 256) >= 512 || (bh * ((p->M + 255) / 256) >= 160 && p->N >= 8192)) &&  // ((4,12,1024x8192): 153 vs 166 us)
+                            p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 8192 : 2048) && (!p->causal || p->M >= 16384)));  // (T5 bias: its band steps are unpipelined here -- (8,12,2048) 170 vs 154 us,
                                                               //  (16,12,2048) 345 vs 321, (4,12,4096) 291 vs 288, (4,12,8192) 1098 vs 1110)
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
