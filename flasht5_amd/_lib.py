@@ -46,7 +46,7 @@ class AttnParams(ctypes.Structure):
 
 EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
-    "fat5_attn_bwd_stages", "fat5_rpe1d_from_table",
+    "fat5_attn_bwd_stages", "fat5_attn_describe", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
     "fat5_ce_fwd", "fat5_ce_bwd", "fat5_linear_fused", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_fold_weights_bwd_scratch_bytes", "fat5_rmsnorm_unit_bwd", "fat5_gated_act_fwd", "fat5_gated_act_bwd",
     "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_scale_step_dev", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
@@ -75,6 +75,8 @@ def load():
     lib.fat5_attn_bwd_stages.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_int, ctypes.c_void_p]
     lib.fat5_attn_bwd_launches.restype = ctypes.c_int
     lib.fat5_attn_bwd_launches.argtypes = [ctypes.POINTER(AttnParams)]
+    lib.fat5_attn_describe.restype = ctypes.c_int
+    lib.fat5_attn_describe.argtypes = [ctypes.POINTER(AttnParams), ctypes.c_char_p, ctypes.c_size_t]
     lib.fat5_attn_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.fat5_attn_bwd_workspace_bytes.argtypes = [ctypes.POINTER(AttnParams)]
     lib.fat5_rpe1d_from_table.restype = ctypes.c_int
@@ -234,3 +236,23 @@ def strides3(t):
 def kernel_ready(t):
     """The kernels need last-dim stride 1, 16-byte aligned base and strides that are multiples of 8."""
     return (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % 8 == 0 for s in t.stride()[:-1]))
+
+
+def describe(B, H, M, N, D=64, dtype=FAT5_BF16, causal=False, bias_mode=0, radius=0, need_dbias=False, variant=0):
+    """Which kernel bodies the library would run for a problem -- {"fwd": "64row-ksplit", "dq": "32row", "dkdv": "64key-mixed:4",
+    "fused": "0", "dbias": "direct"} -- from shapes alone (fat5_attn_describe: host-only, works without a GPU)."""
+    p = AttnParams()
+    p.B, p.H, p.M, p.N, p.D = B, H, M, N, D
+    p.dtype, p.causal, p.bias_mode, p.rpe_radius, p.variant = dtype, int(causal), bias_mode, radius, variant
+    if bias_mode == BIAS_DENSE:
+        p.bias = 16  # (never followed)
+        p.bias_stride[0], p.bias_stride[1], p.bias_stride[2] = 0, M * N, N  # the model's (1, H, M, N) bias, shared by the batch
+        if need_dbias:
+            p.dbias, p.dbias_batch, p.dbias_heads = 16, 1, H
+    elif bias_mode == BIAS_RPE1D:
+        p.rpe1d = 16
+        if need_dbias:
+            p.drpe1d = 16
+    buf = ctypes.create_string_buffer(256)
+    check(load().fat5_attn_describe(ctypes.byref(p), buf, 256), "fat5_attn_describe")
+    return dict(kv.split("=") for kv in buf.value.decode().split())

@@ -136,35 +136,28 @@ int fat5_version(void) { return FAT5_VERSION; }
 const char* fat5_last_error(void) { return g_err; }
 size_t fat5_sizeof_attn_params(void) { return sizeof(fat5_attn_params); }
 
-int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
-  int rc = check_common(p);
-  if (rc) return rc;
-  hipStream_t stream = (hipStream_t)stream_;
-  if (!p->q || !p->k || !p->v || !p->o || !p->lse) return fail(FAT5_EINVAL, "fwd: null tensor pointer");
-  if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||
-      !strides_ok(p->o, p->o_stride))
-    return fail(FAT5_EINVAL, "fwd: q/k/v/o must be 16-byte aligned with strides that are multiples of 8 elements");
-  if (!slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) || !slice_fits(p->M, p->q_stride[2], p->D))
-    return fail(FAT5_EINVAL, "fwd: one (batch, head) slice must span less than 2 GiB");
-  if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
-  if (p->cu_seqlens_q && p->bias_mode == FAT5_BIAS_DENSE) return fail(FAT5_EINVAL, "varlen: dense bias unsupported (none or rpe1d)");
-
-  AttnArgs a;
-  fill_common(p, a);
-  // Kernel variants (waves per workgroup, split / pipelined bodies) are chosen from the FULL problem, the grid from this call's
-  // units: a unit-range call runs exactly the code the whole-problem call would run on those units, so sharded and unsharded
-  // results are bit-identical.
+// Forward: which body runs a problem (waves per workgroup, split / pipelined bodies).  Chosen from the FULL problem -- the grid comes
+// from the call's units: a unit-range call runs exactly the code the whole-problem call would run on those units, so sharded and
+// unsharded results are bit-identical.
+struct FwdChoice {
+  int nw;        // launcher code: waves per workgroup of the 32-row body, -4 = its two-waves-per-32-rows split form; 64-row body: 4, 2 = key-split
+  int n_mblk;    // query tiles per (b, h)
+  bool fwd64;    // the 64-rows-per-wave pipelined body (attn_fwd64.h)
+  bool ksplit;
+};
+static FwdChoice fwd_choice(const fat5_attn_params* p) {
+  FwdChoice c;
+  c.fwd64 = c.ksplit = false;
   const long bh = (long)p->B * p->H;
   int nw = pick_nw(bh * ((p->M + 127) / 128));
-  a.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
+  c.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
   // short sequences: with 4-wave tiles the grid is smaller than the chip and every wave walks all keys alone -> two
   // waves per 32 query rows, each taking one 32-key block of every tile (attn_fwd_split_kernel)
   const long ctas4 = bh * ((p->M + 127) / 128);
   if (!(p->variant & FAT5_V_NO_SPLIT) && ctas4 <= 256 && bh * ((p->M + 63) / 64) >= 96 && p->N >= 128) {
     nw = -4;
-    a.n_mblk = (p->M + 63) / 64;
+    c.n_mblk = (p->M + 63) / 64;
   }
-  launch_fn fn = p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128);
   // long sequences: 64 query rows per wave, software-pipelined tile loop (attn_fwd64.h) once its 256-row workgroups fill
   // the chip (fat5_attn_params.variant: FAT5_V_FWD64_OFF disables, FAT5_V_FWD64_ON forces wherever the body applies)
   const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
@@ -180,7 +173,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
                         !(p->N <= 512 && (p->causal || (waves64 > 1024 && waves64 < 2048))) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
-    fn = launch_fwd64_d64;
+    c.fwd64 = true;
     // Key-split variant (two waves per 64 rows, 128-row workgroups): where the 64-row waves fill between one and two slots of the
     // chip's 1024 SIMDs -- half the SIMDs then carry two full-length waves and the others one.  Measured at (4,12,2048,64) (tools/
     // attn_time.py): 60.7 vs 63.8 us with the T5 bias (a 128-row workgroup also crosses fewer band tiles), 58.4 vs 59.1 without;
@@ -192,9 +185,33 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 ||
                                                         (p->causal && waves64 <= 8192 && p->N < 2 * p->M)));
+    c.ksplit = ksplit;
     nw = ksplit ? 2 : 4;
-    a.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
+    c.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
   }
+  c.nw = nw;
+  return c;
+}
+
+int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
+  int rc = check_common(p);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!p->q || !p->k || !p->v || !p->o || !p->lse) return fail(FAT5_EINVAL, "fwd: null tensor pointer");
+  if (!strides_ok(p->q, p->q_stride) || !strides_ok(p->k, p->k_stride) || !strides_ok(p->v, p->v_stride) ||
+      !strides_ok(p->o, p->o_stride))
+    return fail(FAT5_EINVAL, "fwd: q/k/v/o must be 16-byte aligned with strides that are multiples of 8 elements");
+  if (!slice_fits(p->N, p->k_stride[2], p->D) || !slice_fits(p->N, p->v_stride[2], p->D) || !slice_fits(p->M, p->q_stride[2], p->D))
+    return fail(FAT5_EINVAL, "fwd: one (batch, head) slice must span less than 2 GiB");
+  if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr)) return fail(FAT5_EINVAL, "cu_seqlens_q/k must both be set");
+  if (p->cu_seqlens_q && p->bias_mode == FAT5_BIAS_DENSE) return fail(FAT5_EINVAL, "varlen: dense bias unsupported (none or rpe1d)");
+
+  AttnArgs a;
+  fill_common(p, a);
+  const FwdChoice fc = fwd_choice(p);
+  int nw = fc.nw;
+  a.n_mblk = fc.n_mblk;
+  launch_fn fn = fc.fwd64 ? launch_fwd64_d64 : (p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
   const long grid = n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
@@ -359,6 +376,25 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
   return bwd_fusable(L, grid_q, grid_kv, p->D, p->variant) ? 1 : 2;
+}
+
+// Which kernel bodies a problem runs, as text (tests pin the dispatch rules with it; no device needed, no pointer of `p` is followed)
+int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
+  int rc = check_common(p);
+  if (rc) return rc;
+  if (!out || n == 0) return fail(FAT5_EINVAL, "describe: no buffer");
+  const FwdChoice fc = fwd_choice(p);
+  BwdLayout L;
+  bwd_layout(p, L);
+  const long bh = (long)p->B * p->H;
+  const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
+  const bool fused = bwd_fusable(L, grid_q, grid_kv, p->D, p->variant);
+  char kv[48];
+  if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
+  else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
+  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.ksplit ? "64row-ksplit" : "64row") : (fc.nw == -4 ? "32row-split" : "32row"),
+           L.q64 ? "64row" : "32row", kv, fused ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
+  return FAT5_OK;
 }
 
 int fat5_attn_bwd(const fat5_attn_params* p, void* stream_) { return fat5_attn_bwd_stages(p, FAT5_BWD_ALL, stream_); }

@@ -147,6 +147,9 @@ int fat5_attn_bwd(const fat5_attn_params* p, void* hip_stream);
  * launch (short sequences: both grids fit the chip together), 2 = dQ kernel then dK/dV kernel; 0 on invalid params.
  * (Profilers use it to name the dominant kernel; the reduction launch is not counted.) */
 int fat5_attn_bwd_launches(const fat5_attn_params* p);
+/* Which kernel bodies this problem runs -- "fwd=64row-ksplit dq=32row dkdv=64key-mixed:4 fused=0 dbias=direct" -- written to `out`
+ * (n bytes).  Host-only (no device, no pointer of `p` is followed): tests pin the dispatch rules with it. */
+int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n);
 /* the same backward, one stage at a time (profiling / stream overlap).  Order matters:
  * FAT5_BWD_DQ (writes delta + dq) must precede FAT5_BWD_DKDV (reads delta; writes dk, dv, dS / partial
  * diagonal sums), which must precede FAT5_BWD_REDUCE (dbias / drpe1d).  fat5_attn_bwd == FAT5_BWD_ALL.

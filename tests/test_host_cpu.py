@@ -280,3 +280,47 @@ def test_graphed_train_step_and_capturable_optimizer_argument_checks():
     assert all("exp_avg" in opt.state[p] for p in lin.parameters()) and opt._graph_arena == {}
     with pytest.raises(RuntimeError):
         opt._arena_take(torch.device("cpu"), 64)
+
+
+def test_dispatch_rules_are_pinned():
+    """fat5_attn_describe (host-only): the kernel body every stage of a problem runs.  Each line is a MEASURED decision
+    (tools/dispatch_audit.py / tools/attn_time.py on MI355X): the test keeps a later threshold edit from silently
+    moving a shape to a slower body."""
+    from flasht5_amd import _lib as L
+    rpe = dict(bias_mode=L.BIAS_RPE1D, radius=128, need_dbias=True)
+    dense = dict(bias_mode=L.BIAS_DENSE, need_dbias=True)
+    cases = [
+        # the three headline shapes (T5 bias): one fused backward launch at S = 512; mixed dK/dV launch at 2048; 64-wide everywhere at 8192
+        (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="32row", dkdv="32key", fused="1")),
+        (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4", fused="0")),
+        (dict(B=4, H=12, M=8192, N=8192, **rpe), dict(fwd="64row", dq="64row", dkdv="64key")),
+        (dict(B=4, H=12, M=8192, N=8192), dict(fwd="64row", dq="64row", dkdv="64key")),
+        (dict(B=4, H=12, M=4096, N=4096), dict(fwd="64row", dq="64row", dkdv="64key")),
+        (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="32row", dkdv="64key")),            # T5 bias: the 64-row dQ body waits for 8192 keys
+        # causal: diagonal steps are unpipelined in the 64-wide backward bodies
+        (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
+        (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="32key")),
+        (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
+        (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
+        (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
+        (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),
+        (dict(B=16, H=12, M=1024, N=4096, causal=True), dict(fwd="64row")),                    # N >= 2M: the mask shortens nothing
+        # large batch, short keys: the uneven 1.5-waves-per-SIMD range keeps the 32-row forward; whole rounds do not
+        (dict(B=16, H=12, M=512, N=512), dict(fwd="32row")),
+        (dict(B=16, H=12, M=1024, N=512), dict(fwd="64row")),
+        (dict(B=16, H=12, M=1024, N=1024), dict(fwd="64row", dq="32row", dkdv="64key")),
+        # under-filled grids with long streams
+        (dict(B=4, H=12, M=4096, N=1024), dict(dq="32row", dkdv="64key")),
+        (dict(B=4, H=12, M=1024, N=8192), dict(dq="64row")),
+        # dense bias never runs the 64-wide bodies; the batch-shared gradient is formed in-kernel once the staging tensor would be large
+        (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="32row", dq="32row", dkdv="32key", dbias="inkernel")),
+        (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dbias="staged")),
+        # head dims other than 64: the 32-wide bodies
+        (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="32row", dq="32row", dkdv="32key")),
+        # forced per call
+        (dict(B=4, H=12, M=1024, N=1024, variant=L.V_KV64_ON | L.V_KV64_HALF_ON | L.V_Q64_ON | L.V_FWD64_OFF), dict(fwd="32row", dq="64row", dkdv="64key-half")),
+    ]
+    for args, want in cases:
+        got = L.describe(**args)
+        for k, v in want.items():
+            assert got[k] == v, (args, k, got)
