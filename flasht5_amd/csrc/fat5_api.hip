@@ -184,7 +184,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 ||
-                                                        (p->causal && waves64 <= 8192 && p->N < 2 * p->M)));
+                                                        (p->causal && waves64 <= std::min<long>(8192, 2L * p->N) && p->N < 2 * p->M)));
+    // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
+    //  interleaved A/B timings: tools/ab_variants.py)
     c.ksplit = ksplit;
     nw = ksplit ? 2 : 4;
     c.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
