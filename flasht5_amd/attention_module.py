@@ -60,6 +60,10 @@ class _UnpackHeads(torch.autograd.Function):
 
 def unpack_heads(x, n, n_heads):
     """the n head-major (B, H, S, D) views of a packed (B, S, n * H * D) projection output (see _UnpackHeads)"""
+    from . import _lib
+    nat = None if (torch.compiler.is_compiling() or not x.is_cuda) else _lib.native()
+    if nat is not None:  # (the same function in C++: csrc/torch_binding.cpp::UnpackHeadsFn)
+        return tuple(nat.unpack_heads_apply(x, int(n), int(n_heads)))
     return _UnpackHeads.apply(x, n, n_heads)
 
 

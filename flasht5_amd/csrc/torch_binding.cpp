@@ -391,6 +391,242 @@ Tensor rpe1d_apply(const Tensor& q, const Tensor& k, const Tensor& v, const Tens
   return Rpe1dFn::apply(q, k, v, rpe1d, r1, radius, causal, scale);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fused projections and the passes around them (flasht5_amd/fused_linear.py, gated_act.py, attention_module.unpack_heads) as
+// C++ autograd functions: same host logic as the Python classes, whose per-call cost -- above all in the BACKWARD, which the
+// engine runs on its device thread and which has to take the GIL for every Python-defined node -- was what kept the FAT5-base
+// step host-bound in eager mode (22-28 ms of enqueue time around 15 ms of kernels).
+// ------------------------------------------------------------------------------------------------
+hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream(); }
+bool lin_ready(const Tensor& t) { return t.stride(-1) == 1 && (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0 && t.stride(0) % 8 == 0; }
+Tensor lin_rows(const Tensor& t) {
+  Tensor r = t.reshape({-1, t.size(-1)});
+  return lin_ready(r) ? r : r.contiguous();
+}
+int lin_dtype(const Tensor& t) {
+  TORCH_CHECK(t.scalar_type() == at::kHalf || t.scalar_type() == at::kBFloat16, "fused linear: float16 or bfloat16");
+  return t.scalar_type() == at::kHalf ? FAT5_F16 : FAT5_BF16;
+}
+// [w0; w1; w2] diag(g) in one launch (fat5_fold_weights); g undefined: the plain stack
+Tensor fold_weights(const std::vector<Tensor>& ws_, const Tensor& g_) {
+  TORCH_CHECK(ws_.size() >= 1 && ws_.size() <= 3, "fold_weights: one to three weights");
+  std::vector<Tensor> ws;
+  for (const Tensor& w : ws_) ws.push_back(lin_ready(w) ? w : w.contiguous());
+  const int64_t K = ws[0].size(1);
+  int64_t n[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, ntot = 0;
+  const void* ptr[3] = {nullptr, nullptr, nullptr};
+  for (size_t i = 0; i < ws.size(); ++i) { n[i] = ws[i].size(0); ld[i] = ws[i].stride(0); ptr[i] = ws[i].data_ptr(); ntot += n[i]; }
+  Tensor out = at::empty({ntot, K}, ws[0].options());
+  Tensor g = g_.defined() ? g_.to(ws[0].scalar_type()).contiguous() : Tensor();
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(out.device());
+  check_rc(fat5_fold_weights(ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2], g.defined() ? g.data_ptr() : nullptr, out.data_ptr(), K,
+                             lin_dtype(out), cur_stream(out)), "fat5_fold_weights");
+  return out;
+}
+std::tuple<Tensor, Tensor> lin_launch(const Tensor& a, const Tensor& w, const Tensor& res, bool norm, double eps, bool want_rstd) {
+  const int64_t M = a.size(0), K = a.size(1), N = w.size(0);
+  Tensor out = at::empty({M, N}, a.options());
+  Tensor rstd = want_rstd ? at::empty({M}, a.options().dtype(at::kFloat)) : Tensor();
+  if (M == 0) return {out, rstd};
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+  check_rc(fat5_linear_fused(a.data_ptr(), w.data_ptr(), res.defined() ? res.data_ptr() : nullptr, out.data_ptr(),
+                             rstd.defined() ? (float*)rstd.data_ptr() : nullptr, M, N, K, a.stride(0), w.stride(0), res.defined() ? res.stride(0) : 0,
+                             out.stride(0), norm ? 1 : 0, (float)eps, lin_dtype(a), cur_stream(a)), "fat5_linear_fused");
+  return {out, rstd};
+}
+
+// rmsnorm_linear (fused_linear.py::RMSNormLinear): inputs x, norm_weight, w0, w1?, w2? (undefined = absent)
+struct RmsNormLinearFn : public torch::autograd::Function<RmsNormLinearFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x, const Tensor& norm_weight, double eps, bool with_residual, const Tensor& w0,
+                               const OptT& w1_, const OptT& w2_) {
+    const Tensor w1 = w1_.has_value() ? *w1_ : Tensor(), w2 = w2_.has_value() ? *w2_ : Tensor();
+    std::vector<Tensor> ws{w0};
+    if (w1.defined()) ws.push_back(w1);
+    if (w2.defined()) ws.push_back(w2);
+    Tensor x2 = lin_rows(x);
+    Tensor wg = fold_weights(ws, norm_weight);
+    auto [out, rstd] = lin_launch(x2, wg, Tensor(), true, eps, true);
+    ctx->save_for_backward({x2, norm_weight, rstd, wg, w0, w1, w2});
+    ctx->saved_data["shape"] = x.sizes().vec();
+    ctx->set_materialize_grads(false);
+    std::vector<int64_t> oshape = x.sizes().vec();
+    oshape.back() = wg.size(0);
+    Tensor o = out.reshape(oshape);
+    if (with_residual) return {o, x.view_as(x)};
+    return {o};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &x2 = s[0], &g = s[1], &rstd = s[2], &wg = s[3];
+    const Tensor dout = grads[0];
+    Tensor dres = grads.size() > 1 ? grads[1] : Tensor();
+    const auto shape = ctx->saved_data["shape"].toIntVector();
+    if (!dout.defined()) return {dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};  // only the residual alias was used
+    const int64_t M = x2.size(0), K = x2.size(1);
+    Tensor d2 = lin_rows(dout.scalar_type() == x2.scalar_type() ? dout : dout.to(x2.scalar_type()));
+    if (dres.defined()) dres = lin_rows(dres.scalar_type() == x2.scalar_type() ? dres : dres.to(x2.scalar_type()));
+    Tensor gy = at::matmul(d2, wg);  // dL/dxhat: (M, K)
+    Tensor dx = at::empty({M, K}, x2.options()), xhat = at::empty({M, K}, x2.options());
+    {
+      c10::hip::HIPGuardMasqueradingAsCUDA guard(x2.device());
+      check_rc(fat5_rmsnorm_unit_bwd(gy.data_ptr(), x2.data_ptr(), (const float*)rstd.data_ptr(), dx.data_ptr(), xhat.data_ptr(), M, K, gy.stride(0),
+                                     x2.stride(0), K, K, dres.defined() ? dres.data_ptr() : nullptr, dres.defined() ? dres.stride(0) : 0,
+                                     lin_dtype(x2), cur_stream(x2)), "fat5_rmsnorm_unit_bwd");
+    }
+    Tensor dg, dw[3];
+    const bool need_g = ctx->needs_input_grad(1);
+    // (needs_input_grad counts the TENSOR inputs that are present: x, norm_weight, w0 [, w1 [, w2]])
+    const bool need_w[3] = {ctx->needs_input_grad(2), s[5].defined() && ctx->needs_input_grad(3), s[6].defined() && ctx->needs_input_grad(4)};
+    if (need_g || need_w[0] || need_w[1] || need_w[2]) {
+      Tensor dwg = at::matmul(d2.t(), xhat);  // gradient of the folded weight [W_i] diag(g): (N, K)
+      std::vector<Tensor> ws;
+      for (int i = 0; i < 3; ++i)
+        if (s[4 + i].defined()) ws.push_back(lin_ready(s[4 + i]) ? s[4 + i] : s[4 + i].contiguous());
+      int64_t n[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, ntot = 0;
+      const void* ptr[3] = {nullptr, nullptr, nullptr};
+      void* dptr[3] = {nullptr, nullptr, nullptr};
+      Tensor dws[3];
+      for (size_t i = 0; i < ws.size(); ++i) {
+        n[i] = ws[i].size(0); ld[i] = ws[i].stride(0); ptr[i] = ws[i].data_ptr(); ntot += n[i];
+        dws[i] = at::empty({n[i], K}, x2.options());
+        dptr[i] = dws[i].data_ptr();
+      }
+      Tensor gq = g.to(x2.scalar_type()).contiguous();
+      Tensor dgq = at::empty({K}, x2.options());
+      const size_t sbytes = fat5_fold_weights_bwd_scratch_bytes(ntot, K);
+      Tensor scratch = at::empty({(int64_t)std::max<size_t>(sbytes, 4) / 4}, x2.options().dtype(at::kFloat));
+      c10::hip::HIPGuardMasqueradingAsCUDA guard(x2.device());
+      check_rc(fat5_fold_weights_bwd(dwg.data_ptr(), ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2], gq.data_ptr(), dptr[0], dptr[1],
+                                     dptr[2], dgq.data_ptr(), K, lin_dtype(x2), scratch.data_ptr(), (size_t)scratch.numel() * 4, cur_stream(x2)),
+               "fat5_fold_weights_bwd");
+      if (need_g) dg = dgq.to(g.scalar_type());
+      for (size_t i = 0; i < ws.size(); ++i)
+        if (need_w[i]) dw[i] = dws[i].to(s[4 + i].scalar_type());
+    }
+    return {ctx->needs_input_grad(0) ? dx.reshape(shape) : Tensor(), dg, Tensor(), Tensor(), dw[0], dw[1], dw[2]};
+  }
+};
+
+// linear_residual (fused_linear.py::LinearResidual)
+struct LinearResidualFn : public torch::autograd::Function<LinearResidualFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& a, const Tensor& weight, const Tensor& residual) {
+    Tensor a2 = lin_rows(a), r2 = lin_rows(residual);
+    auto [out, unused] = lin_launch(a2, lin_rows(weight), r2, false, 0.0, false);
+    (void)unused;
+    ctx->save_for_backward({a2, weight});
+    ctx->saved_data["ashape"] = a.sizes().vec();
+    return out.reshape(residual.sizes());
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor &a2 = s[0], &W = s[1];
+    const Tensor& dout = grads[0];
+    Tensor d2 = dout.reshape({-1, dout.size(-1)});
+    Tensor da, dW;
+    if (ctx->needs_input_grad(0)) da = at::matmul(d2, W).reshape(ctx->saved_data["ashape"].toIntVector());
+    if (ctx->needs_input_grad(1)) dW = at::matmul(d2.t(), a2).to(W.scalar_type());
+    return {da, dW, ctx->needs_input_grad(2) ? dout : Tensor()};
+  }
+};
+
+// gated activation (gated_act.py): h0, h1 the two projections -- for the packed form the two halves of one (rows, 2F) tensor
+Tensor gated_fwd(const Tensor& h0, const Tensor& h1, int64_t act) {
+  Tensor a = lin_rows(h0), b = lin_rows(h1);
+  Tensor out = at::empty(a.sizes(), a.options());
+  if (a.size(0)) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+    check_rc(fat5_gated_act_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.size(0), a.size(1), a.stride(0), b.stride(0), out.stride(0), (int)act,
+                                any_dtype_code(a), cur_stream(a)), "fat5_gated_act_fwd");
+  }
+  return out.reshape(h0.sizes());
+}
+Tensor gated_bwd(const Tensor& dout, const Tensor& h0, const Tensor& h1, int64_t act) {  // -> (rows, 2F): [dh0 | dh1]
+  Tensor a = lin_rows(h0), b = lin_rows(h1);
+  Tensor g = lin_rows(dout.scalar_type() == a.scalar_type() ? dout : dout.to(a.scalar_type()));
+  const int64_t F = a.size(1);
+  Tensor dh = at::empty({a.size(0), 2 * F}, a.options());
+  if (a.size(0)) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+    check_rc(fat5_gated_act_bwd(g.data_ptr(), a.data_ptr(), b.data_ptr(), dh.data_ptr(), (char*)dh.data_ptr() + F * dh.element_size(), a.size(0), F,
+                                g.stride(0), a.stride(0), b.stride(0), 2 * F, 2 * F, (int)act, any_dtype_code(a), cur_stream(a)),
+             "fat5_gated_act_bwd");
+  }
+  return dh;
+}
+struct GatedActPackedFn : public torch::autograd::Function<GatedActPackedFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& h, int64_t act) {
+    const int64_t F = h.size(-1) / 2;
+    ctx->save_for_backward({h});
+    ctx->saved_data["act"] = act;
+    return gated_fwd(h.narrow(-1, 0, F), h.narrow(-1, F, F), act);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const Tensor& h = s[0];
+    const int64_t F = h.size(-1) / 2;
+    return {gated_bwd(grads[0], h.narrow(-1, 0, F), h.narrow(-1, F, F), ctx->saved_data["act"].toInt()).reshape(h.sizes()), Tensor()};
+  }
+};
+struct GatedActFn : public torch::autograd::Function<GatedActFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& h0, const Tensor& h1, int64_t act) {
+    ctx->save_for_backward({h0, h1});
+    ctx->saved_data["act"] = act;
+    return gated_fwd(h0, h1, act);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    const int64_t F = s[0].size(-1);
+    Tensor dh = gated_bwd(grads[0], s[0], s[1], ctx->saved_data["act"].toInt());
+    return {dh.narrow(1, 0, F).reshape(s[0].sizes()), dh.narrow(1, F, F).reshape(s[1].sizes()), Tensor()};
+  }
+};
+
+// unpack_heads (attention_module.py::_UnpackHeads): (B, S, n H D) -> n views (B, H, S, D); the backward hands the packed gradient
+// buffer on when the incoming gradients are its slices (attn_bwd above allocates them that way), one stack otherwise
+struct UnpackHeadsFn : public torch::autograd::Function<UnpackHeadsFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& x, int64_t n, int64_t H) {
+    const int64_t B = x.size(0), S = x.size(1), D = x.size(2) / (n * H);
+    ctx->saved_data["dims"] = std::vector<int64_t>{B, S, n, H, D};
+    ctx->set_materialize_grads(false);
+    Tensor p = x.view({B, S, n, H, D});
+    variable_list out;
+    for (int64_t i = 0; i < n; ++i) out.push_back(p.select(2, i).permute({0, 2, 1, 3}));
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list gs) {
+    const auto d = ctx->saved_data["dims"].toIntVector();
+    const int64_t B = d[0], S = d[1], n = d[2], H = d[3], D = d[4], row = n * H * D;
+    bool all = true;
+    for (const Tensor& g : gs) all = all && g.defined();
+    if (all) {
+      const Tensor& g0 = gs[0];
+      bool same = true;
+      for (int64_t i = 0; i < n && same; ++i) {
+        const Tensor& g = gs[i];
+        same = g.storage().data() == g0.storage().data() && g.scalar_type() == g0.scalar_type() && g.stride(0) == S * row && g.stride(1) == D &&
+               g.stride(2) == row && g.stride(3) == 1 && g.storage_offset() == g0.storage_offset() + i * H * D;
+      }
+      if (same && (int64_t)g0.storage().nbytes() >= (g0.storage_offset() + B * S * row) * (int64_t)g0.element_size())
+        return {g0.as_strided({B, S, row}, {S * row, row, 1}, g0.storage_offset()), Tensor(), Tensor()};
+    }
+    Tensor ref;
+    for (const Tensor& g : gs)
+      if (g.defined()) ref = g;
+    std::vector<Tensor> parts;
+    for (const Tensor& g : gs) parts.push_back((g.defined() ? g : at::zeros_like(ref)).permute({0, 2, 1, 3}));
+    return {at::stack(parts, 2).reshape({B, S, row}), Tensor(), Tensor()};
+  }
+};
+
+std::vector<Tensor> rmsnorm_linear_apply(const Tensor& x, const Tensor& norm_weight, double eps, bool with_residual, const std::vector<Tensor>& ws) {
+  TORCH_CHECK(ws.size() >= 1 && ws.size() <= 3, "rmsnorm_linear: one to three weights");
+  return RmsNormLinearFn::apply(x, norm_weight, eps, with_residual, ws[0], ws.size() > 1 ? OptT(ws[1]) : OptT(), ws.size() > 2 ? OptT(ws[2]) : OptT());
+}
+Tensor linear_residual_apply(const Tensor& a, const Tensor& weight, const Tensor& residual) { return LinearResidualFn::apply(a, weight, residual); }
+Tensor gated_act_packed_apply(const Tensor& h, int64_t act) { return GatedActPackedFn::apply(h, act); }
+Tensor gated_act_apply(const Tensor& h0, const Tensor& h1, int64_t act) { return GatedActFn::apply(h0, h1, act); }
+std::vector<Tensor> unpack_heads_apply(const Tensor& x, int64_t n, int64_t H) { return UnpackHeadsFn::apply(x, n, H); }
+
 }  // namespace
 
 PYBIND11_MODULE(_fat5_torch, m) {
@@ -402,6 +638,11 @@ PYBIND11_MODULE(_fat5_torch, m) {
   m.def("rpe1d_apply", &rpe1d_apply);
   m.def("rpe1d_of", &rpe1d_of);
   m.def("rmsnorm_apply", &rmsnorm_apply);
+  m.def("rmsnorm_linear_apply", &rmsnorm_linear_apply);
+  m.def("linear_residual_apply", &linear_residual_apply);
+  m.def("gated_act_packed_apply", &gated_act_packed_apply);
+  m.def("gated_act_apply", &gated_act_apply);
+  m.def("unpack_heads_apply", &unpack_heads_apply);
   m.def("add_rmsnorm_apply", &add_rmsnorm_apply);
   m.def("sizeof_attn_params", []() { return (int64_t)sizeof(fat5_attn_params); });
   m.def("set_variant", [](int64_t bits) { g_variant.store((int)bits); });

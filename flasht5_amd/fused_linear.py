@@ -165,6 +165,10 @@ def rmsnorm_linear(x, norm_weight, weight, eps=1e-6, return_residual=False):
         y = fast_rms_layernorm(x, norm_weight, eps)
         out = torch.cat([torch.nn.functional.linear(y, w) for w in weights], -1) if len(weights) > 1 else torch.nn.functional.linear(y, weights[0])
         return (out, x) if return_residual else out
+    nat = None if torch.compiler.is_compiling() else _lib.native()
+    if nat is not None:  # (C++ autograd function: same host logic, a fraction of the per-call cost -- above all in the backward)
+        r = nat.rmsnorm_linear_apply(x, norm_weight, float(eps), bool(return_residual), list(weights))
+        return (r[0], r[1]) if return_residual else r[0]
     return RMSNormLinear.apply(x, norm_weight, float(eps), bool(return_residual), *weights)
 
 
@@ -174,4 +178,7 @@ def linear_residual(a, weight, residual):
         raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
     if not fused_linear_supported(a, weight) or residual.dtype != a.dtype or residual.shape[-1] != weight.shape[0]:
         return residual + torch.nn.functional.linear(a, weight)
+    nat = None if torch.compiler.is_compiling() else _lib.native()
+    if nat is not None:
+        return nat.linear_residual_apply(a, weight, residual)
     return LinearResidual.apply(a, weight, residual)

@@ -964,4 +964,6 @@ def test_packed_projection_gradients_land_in_one_buffer(mode, monkeypatch):
     assert torch.equal(o0, o1) and torch.equal(gx0, gx1)
     if mode == "cross":
         assert torch.equal(gq0, gq1)
-    assert calls["n"] == (1 if mode == "broken" else 0)
+    # (the Python form of unpack_heads stacks through torch.stack; the C++ form -- the default -- through at::stack, which the patch does not see)
+    from flasht5_amd import _lib
+    assert calls["n"] == (1 if mode == "broken" and _lib.native() is None else 0)

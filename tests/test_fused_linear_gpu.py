@@ -223,3 +223,35 @@ def test_rmsnorm_linear_return_residual_joins_the_gradients_in_the_kernel():
     _, res = rmsnorm_linear(xs, gw, W, 1e-6, return_residual=True)
     res.backward(dout)
     assert torch.equal(xs.grad, dout)
+
+
+def test_native_host_path_equals_python_functions():
+    """rmsnorm_linear / linear_residual / gated_act_packed / unpack_heads through the C++ autograd functions (csrc/torch_binding.cpp, the
+    eager default) and through the Python classes: the same C-ABI calls in the same order -> identical outputs and gradients"""
+    from flasht5_amd import _lib, rmsnorm_linear, linear_residual, gated_act_packed
+    from flasht5_amd.fused_linear import RMSNormLinear, LinearResidual
+    from flasht5_amd.gated_act import GatedActPacked
+    if _lib.native() is None:
+        pytest.skip("lib/_fat5_torch.so not built")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 192, 768, generator=g).cuda().bfloat16()
+    gw = (1 + 0.1 * torch.randn(768, generator=g)).cuda().bfloat16()
+    W0, W1 = ((torch.randn(1024, 768, generator=g) / 768 ** 0.5).cuda().bfloat16() for _ in range(2))
+    Wo = (torch.randn(768, 1024, generator=g) / 32).cuda().bfloat16()
+    dout = torch.randn(2, 192, 768, generator=g).cuda().bfloat16()
+
+    def run(native):
+        leaves = [t.clone().requires_grad_() for t in (x, gw, W0, W1, Wo)]
+        xs, gs, w0, w1, wo = leaves
+        if native:
+            h, res = rmsnorm_linear(xs, gs, (w0, w1), 1e-6, return_residual=True)
+            t = gated_act_packed(h, "gelu_tanh")
+            out = linear_residual(t, wo, res)
+        else:
+            h, res = RMSNormLinear.apply(xs, gs, 1e-6, True, w0, w1)
+            t = GatedActPacked.apply(h, 0)
+            out = LinearResidual.apply(t, wo, res)
+        out.backward(dout)
+        return [out.detach()] + [t_.grad for t_ in leaves]
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)

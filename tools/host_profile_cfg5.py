@@ -1,8 +1,10 @@
 import sys, time, cProfile, pstats
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
-cfg = FAT5Config(); cfg.fuse_add_norm = True
+cfg = FAT5Config()
+setattr(cfg, sys.argv[1] if len(sys.argv) > 1 else 'fuse_norm_linear', True)
 torch.manual_seed(0)
 m = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
 ids = torch.randint(0, cfg.vocab_size, (4, 1024)).cuda(); labels = torch.randint(0, cfg.vocab_size, (4, 512)).cuda()
@@ -19,4 +21,16 @@ print(f"backward host {(t1-t0)*1e3:.2f} ms, total {(t2-t0)*1e3:.2f} ms")
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): fwd()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+# the backward runs on autograd's device thread: profile it there
+import threading
+pr2 = cProfile.Profile()
+threading.setprofile(lambda *a: None)
+def bwd_profile():
+    l = fwd()
+    torch.cuda.synchronize()
+    pr2.enable(); l.backward(); pr2.disable()
+for _ in range(3): bwd_profile()
+torch.cuda.synchronize()
+print("---- backward (calling thread only: the Python of custom Functions runs on the engine's device thread) ----")
+pstats.Stats(pr2).sort_stats("tottime").print_stats(8)
