@@ -153,7 +153,7 @@ class AdamWScale(Optimizer):
                     scalars = self._arena_take(device, 12).view(torch.float32)
                     self._graph_jobs.append((group, [st for _, _, st in items], scalars, raw, host))
                 else:
-                    raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(device, non_blocking=False)
+                    raw = self._upload(device, table)
                     scalars = None
                 partials = torch.empty(chunk, dtype=torch.float32, device=device)
                 flags = (1 if kahan else 0) | (0 if group["correct_bias"] else 2)  # FAT5_ADAMW_KAHAN | FAT5_ADAMW_PLAIN_STEP
@@ -218,6 +218,33 @@ class AdamWScale(Optimizer):
                         count[p.device] = count.get(p.device, 0) + 1
             self._graph_arena = {dev: [torch.empty((2 * n + 8 * len(self.param_groups) + 8) * 128, dtype=torch.uint8, device=dev), 0]
                                  for dev, n in count.items()}
+
+    def _upload(self, device, table):
+        """descriptor table -> device, ASYNCHRONOUSLY: through one of eight rotating pinned staging buffers (a copy from pageable memory
+        makes the host wait for the stream, i.e. for the whole backward pass in front of it -- the host could never run ahead of the
+        device).  A staging buffer is rewritten only after the copy issued from it eight uploads ago has completed."""
+        n = ctypes.sizeof(table)
+        ring = self.__dict__.setdefault("_staging", {}).setdefault(device, {"i": 0, "slot": 0, "pin": None, "ev": [None] * 8})
+        if ring["pin"] is None or ring["slot"] < n:  # (ONE pinned allocation for the whole ring: hipHostMalloc costs milliseconds)
+            for ev in ring["ev"]:
+                if ev is not None:
+                    ev.synchronize()
+            ring["slot"] = max(2 * n, 1 << 16)
+            ring["pin"] = torch.empty(8 * ring["slot"], dtype=torch.uint8).pin_memory()
+            ring["ev"] = [None] * 8
+        i = ring["i"]
+        ring["i"] = (i + 1) % 8
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        buf = ring["pin"][i * ring["slot"]:(i + 1) * ring["slot"]]
+        ctypes.memmove(buf.data_ptr(), ctypes.addressof(table), n)
+        raw = torch.empty(n, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            raw.copy_(buf[:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        ring["ev"][i] = ev
+        return raw
 
     def _arena_take(self, device, nbytes):
         """`nbytes` of the pre-capture arena of `device` (64-byte aligned pieces, handed out in order)"""
