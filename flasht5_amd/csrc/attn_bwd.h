@@ -22,6 +22,7 @@
 #pragma once
 #include "attn_common.h"
 #include "attn_fwd.h"  // load_bias_block
+#include "diag_sum.h"  // per-diagonal sums of dS on the VALU (DPP row rotations)
 
 namespace fat5 {
 
@@ -374,13 +375,10 @@ struct BwdKVCfg {
   static constexpr int QRM = rm_bytes<D, BMQ>();
   static constexpr int STAT = BMQ * 4 * 2;  // -L*log2e and delta for the BMQ rows
   static constexpr int STAGE = 2 * QRM + STAT;
-  static constexpr int SKEW_ROW = 160;         // bytes per row of a wave's 32 x 64 bf16 skew tile (padded: tr reads conflict free)
-  static constexpr int SKEW = 32 * SKEW_ROW;
   static constexpr int BIASB = BMQ * BNK * 2;  // dense mode: one (64 query rows x BNK keys) 16-bit bias tile per buffer
   static size_t smem(int R, int bias_mode) {
-    // rpe: table + one private accumulator per wave
-    // rpe: table + one private diagonal accumulator per wave + one private 32x64 fp32 skew tile per wave
-    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0) +
+    // rpe: table + one private diagonal accumulator per wave
+    return 2 * STAGE + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) : 0) +
            (bias_mode == FAT5_BIAS_DENSE ? 2 * (size_t)BIASB : 0);
   }
   static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * NW + 63) / 64 * 64; }
@@ -451,42 +449,33 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   const int n1 = 2 * a.R + 1;
   float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);  // NW wave-private (2R+1) diagonal accumulators behind the four table copies
   float* sD = sD0 + w * n1;
-  // Per-wave 32x64 bf16 "skew tile": dS of a near block is stored with row q shifted by -q (element (q, k) at column
-  // k - q + 31), so diagonals become columns.  Column sums = ones(32x32) x tile on the matrix pipe (4 MFMAs, operand
-  // fragments by transposing reads), one value per lane -- this replaces 16 LDS float atomics per lane (ds_add_f32 costs
-  // ~600 cycles per wave instruction on gfx950; tools/time_kv.py) and, before that, 32 reads + 32 adds per lane.
-  // dS enters rounded to the input dtype, exactly like the reference's bias gradient (ds.to(dtype), :720 / :214).
-  char* sG = smem + 2 * Cfg::STAGE + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
-  // element r of this lane (row crow(r, hi), key lq): byte offset sk_w + 158 * ((r & 3) + 8 * (r >> 2))
-  const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
-  int sk_r[2];  // transposing reads of a 16x16x32 B fragment: rows 8*(l >> 4) + 4*u + e, 8-byte piece c (+32 bytes per 16 columns)
-  {
-    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g4 = l >> 4;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) sk_r[u] = (8 * g4 + 4 * u + e) * Cfg::SKEW_ROW + 8 * c;
-  }
-  const uint32_t one2s = pack2<BF16>(1.f, 1.f);
-  const u32x4 ones = {one2s, one2s, one2s, one2s};
-  // column c of the block at query row mb is the diagonal  krow0 - mb - 31 + c.  Columns 32..63 of block j are the
-  // diagonals of columns 0..31 of block j-1 (mb grows by 32): `carry` holds those until the next block completes them.
-  float carry = 0.f;
-  int carry_d0 = 0;          // diagonal of lane 0's carried value
-  bool carry_valid = false;  // wave-uniform
+  // Per-diagonal sums of dS (the gradient of the bias generator) on the VALU: diag_sum.h -- one DPP row rotation per element and a
+  // few cross-lane operations per block, no LDS round trip (rounds 1-3: a skewed LDS tile + column sums on the matrix pipe, before
+  // that 16 LDS float atomics per lane: ds_add_f32 costs ~600 cycles per wave instruction on gfx950).  `dcar` carries the partial
+  // diagonals from one 32-row block to the next (query blocks ascend); a finished diagonal is handed over exactly once.
+  DiagCarry dcar;
+  diag_carry_zero(dcar);
+  bool diag_run = false;  // (wave-uniform) dcar holds partial diagonals of the block at diag_mb
+  int diag_mb = 0;
   float far_neg = 0.f, far_pos = 0.f;
-  // one finished diagonal sum per lane of the lower half-wave (both halves hold the same columns): far bins in
-  // registers, near bins stored into the wave-private (zero-initialised) array
-  auto emit_diag = [&](float v, int d) {
+  // lanes 0..31 of F: the finished sums of the diagonals base + lane; far bins in registers, near bins stored into the wave-private
+  // (zero-initialised) array
+  auto diag_emit = [&](const float F, const int base) {
     if (hi == 0) {
-      if (d <= -a.R) far_neg += v;
-      else if (d >= a.R) far_pos += v;
-      else sD[d + a.R] = v;  // every near diagonal of a wave is finished exactly once (query blocks ascend)
+      const int d = base + lq;
+      if (d <= -a.R) far_neg += F;
+      else if (d >= a.R) far_pos += F;
+      else sD[d + a.R] = F;  // every near diagonal of a wave is finished exactly once (query blocks ascend)
     }
   };
-  auto flush_carry = [&]() {
-    if (carry_valid) {
-      emit_diag(carry, carry_d0 + lq);
-      carry_valid = false;
-      carry = 0.f;
+  auto diag_flush = [&]() {  // the end of a run: the two 32-diagonal windows below the last block's leave the carry
+    if (diag_run) {
+      DiagStep z;
+      diag_step_zero(z);
+      const int base = krow0 - diag_mb;
+      diag_emit(diag_finish(dcar, z, l), base - 32);
+      diag_emit(diag_finish(dcar, z, l), base - 64);
+      diag_run = false;
     }
   };
   auto tree16 = [](const f32x16& x) {  // balanced tree: no long dependent chain, one live register afterwards
@@ -604,7 +593,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
     for (int i = tid; i < n1 * NW; i += NT) sD0[i] = 0.f;
-    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
   if (ntile > 0) store_stats(smem);
   __syncthreads();
@@ -735,33 +723,26 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         pbv[t2] = pack8<BF16>(p, t2);
         dsv[t2] = pack8<BF16>(s, t2);
       }
-      bool near_blk = false;  // wave-uniform: this block's diagonal sums go through the skew tile
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         if (want_drpe) {
           if constexpr (FAST) {
-            flush_carry();
+            diag_flush();
             if constexpr (FARSIDE < 0) far_neg += tree16(s); else far_pos += tree16(s);
           } else {
             const int R = a.R;
             const int dmin = krow0 - (mb + 31), dmax = krow0 + 31 - mb;
             if (dmax <= -R || dmin >= R) {
-              flush_carry();
+              diag_flush();
               const float acc = tree16(s);
               if (dmax <= -R) far_neg += acc; else far_pos += acc;
             } else {
-              near_blk = true;
-              // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31: a fixed set of positions per
-              // row, the rest of the tile stays zero)
-              char* gw = sG + sk_w;
-#pragma unroll
-              for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) {
-                  const int r = 8 * t2 + 2 * wd;
-                  const uint32_t word = dsv[t2][wd];
-                  *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
-                  *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
-                }
+              // the block's dS (fp32, masked elements zero) onto its diagonals
+              DiagStep st;
+              diag_step_zero(st);
+              static_for<16>([&](auto ri) { diag_elem<decltype(ri)::value>(st, s[decltype(ri)::value], l & 15); });
+              diag_emit(diag_finish(dcar, st, l), krow0 - mb);
+              diag_run = true;
+              diag_mb = mb;
             }
           }
         }
@@ -773,36 +754,6 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         for (int db = 0; db < DB; ++db) {
           dvacc[db] = mfma32<BF16>(ld_tr<D>(sDO, fa, qbk, t2, db), pbv[t2], dvacc[db]);
           dkacc[db] = mfma32<BF16>(ld_tr<D>(sQ, fa, qbk, t2, db), dsv[t2], dkacc[db]);
-        }
-      }
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        if (near_blk) {
-          // column sums of the skew tile on the matrix pipe: C = ones(16x32) x tile[32 rows][16 columns] per 16x16x32
-          // MFMA (all 32 rows in one k-step); every row of C is the vector of column sums, lane l holds column (l & 15)
-          // of its 16-column group.  (The row order inside a fragment is irrelevant.)  Tried and dropped: deferring
-          // this to the next block (issue behind its S / dP MFMAs, consume after its softmax) -- slower, the extra
-          // state and code in every tile variant cost more than the hidden latency.
-          typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-          float cs[4];
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            const char* p0 = sG + sk_r[0] + 32 * cb;
-            const char* p1 = sG + sk_r[1] + 32 * cb;
-            const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
-            const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
-            const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
-            cs[cb] = mfma16<BF16>(ones, fr, zero4)[0];
-          }
-          // lane c < 32: column c is in group c >> 4 (low half), column 32 + c in group 2 + (c >> 4)
-          const bool up = (lq & 16) != 0;
-          const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
-          const int d_hi0 = krow0 - mb + 1;  // diagonal of column 32
-          if (carry_valid && carry_d0 != d_hi0) flush_carry();
-          emit_diag(c_hi + (carry_valid ? carry : 0.f), d_hi0 + lq);
-          carry = c_lo;
-          carry_d0 = krow0 - mb - 31;
-          carry_valid = true;
         }
       }
     }
@@ -866,7 +817,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   // (stores count on vmcnt), i.e. for a full memory round trip on the critical path of the workgroup
   if constexpr (BIAS == FAT5_BIAS_RPE1D) {
     if (want_drpe) {
-      flush_carry();
+      diag_flush();
       // wave-reduce the far sums (fixed order), fold into the wave's private array
       far_neg = wave_sum(far_neg);
       far_pos = wave_sum(far_pos);

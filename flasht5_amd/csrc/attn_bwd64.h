@@ -22,8 +22,23 @@
 #pragma once
 #include "attn_common.h"
 #include "attn_fwd64.h"  // static_for, integer-address LDS reads, asm LDS-DMA, pinned VALU ops
+#include "diag_sum.h"    // per-diagonal sums of dS on the VALU (DPP row rotations)
+
+#ifndef FAT5_ABL
+#define FAT5_ABL 0  // developer ablations of the dK/dV body (timing only, wrong results): 1 no diagonal ops, 2 no finish / hand-over, 4 no table reads, 8 no table fill / zeroing in the prologue, 16 no partial sums in the epilogue, 32 no far-bin MFMAs
+#endif
+
+#ifndef FAT5_TRACE
+#define FAT5_TRACE 0  // developer build: thread 0 of every workgroup stamps s_memtime at its phase boundaries into the delta scratch (tools/trace64.py)
+#endif
 
 namespace fat5 {
+
+#if FAT5_TRACE
+#define FAT5_STAMP(slot) do { if (threadIdx.x == 0) reinterpret_cast<long long*>(a.delta)[(int64_t)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FAT5_STAMP(slot) do { } while (0)
+#endif
 
 // HALF (mid sequence lengths): the four waves form two PAIRS; both pairs own the same 128 keys (64 per wave) and each walks one
 // half of the query steps through a ring of its own, then the second pair hands its dK^T / dV^T over through LDS.  With 256-key
@@ -38,11 +53,11 @@ struct Bwd64Cfg {
   static constexpr int RING = NS * SLOT;
   static constexpr int RINGS = HALF ? 2 : 1;     // one ring of query steps per wave pair
   static constexpr int RPE0 = RINGS * RING;      // the RPE state sits behind the ring(s)
-  static constexpr int SKEW_ROW = 160, SKEW = 32 * SKEW_ROW;  // (see BwdKVCfg)
   static_assert(!HALF || 2 * 128 * 64 * 4 <= RPE0, "the hand-over of dK^T / dV^T (128 registers x 64 lanes per wave) reuses the rings");
-  // rpe: four aligned table copies + one private diagonal accumulator per (wave, key block) + one skew tile per wave
-  static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * 2 * NW + 63) / 64 * 64; }
-  static size_t smem(int R, int bias_mode) { return RPE0 + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) + (size_t)NW * SKEW : 0); }
+  // rpe: four aligned table copies + one private diagonal accumulator per (wave, key block)
+  // (+ one scratch word per thread: the target of the lanes that have no near diagonal to store)
+  static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * 2 * NW + NT * 4 + 63) / 64 * 64; }
+  static size_t smem(int R, int bias_mode) { return RPE0 + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) : 0); }
 };
 
 FAT5_DEV float asm_mul(float a, float b) {
@@ -71,6 +86,7 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 template <int D, bool BF16, int BIAS, bool HALF>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
+  FAT5_STAMP(0);
   using Cfg = Bwd64Cfg<D, HALF>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -103,46 +119,63 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
   }
 
-  // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators, skew tile) ----
+  // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators) ----
   float* sT = reinterpret_cast<float*>(smem + Cfg::RPE0) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int n1 = 2 * a.R + 1;
   float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);
-  char* sG = smem + Cfg::RPE0 + Cfg::rpe_off(a.R) + w * Cfg::SKEW;
-  const int sk_w = (4 * hi) * (Cfg::SKEW_ROW - 2) + 2 * (lq + 31);
-  int sk_r[2];
-  {
-    const int i16 = l & 15, e = i16 >> 2, c = i16 & 3, g4 = l >> 4;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) sk_r[u] = (8 * g4 + 4 * u + e) * Cfg::SKEW_ROW + 8 * c;
-  }
   const uint32_t one2s = pack2<BF16>(1.f, 1.f);
   u32x4 ones = {one2s, one2s, one2s, one2s};
   // (opaque: a constant tuple is re-materialised by v_mov right in front of the asm MFMA that reads it — and no wait states are
   // generated between a VALU write and an asm consumer)
   asm volatile("" : "+v"(ones));
-  float carry[2] = {0.f, 0.f};
-  int carry_d0[2] = {0, 0};
-  bool carry_valid[2] = {false, false};
+  // Per-diagonal sums of dS (the gradient of the bias generator) on the VALU: diag_sum.h.  One carry per key block along a run of
+  // consecutive band / masked steps.  The homes of key block 1 at a step are those of key block 0 one step earlier, so the two meet
+  // in registers (dprev0) and ONE value per lane and step leaves: near diagonals into the (wave, half-wave)'s private array -- every
+  // diagonal exactly once, a plain store --, everything beyond the band into two per-lane sums.  Branch-free: a lane without a near
+  // diagonal stores into a scratch slot of its own.
+  DiagCarry dcar[2];
+  diag_carry_zero(dcar[0]);
+  diag_carry_zero(dcar[1]);
+  float dprev0 = 0.f;
+  bool diag_run = false;  // (wave-uniform) a run is open: dcar / dprev0 hold partial diagonals of the step at diag_mb
+  int diag_mb = 0;
+  // borrow masks of the pinned form (destination lane: position p' of its row of 16 took its value from p' + ql0 - 16 of the row above in key order)
+  float dmask[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int ql0 = i < 3 ? i + 1 : i + 5;  // 1, 2, 3, 8, 9, 10, 11
+    dmask[i] = ((l & 15) + ql0 >= 16) ? 1.f : 0.f;
+    asm volatile("" : "+v"(dmask[i]));
+  }
   float far_neg = 0.f, far_pos = 0.f;
   const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
-  auto emit_diag = [&](int kb, float v, int d) {
-    if (hi == 0) {
-      if (d <= -a.R) far_neg += v;
-      else if (d >= a.R) far_pos += v;
-      else sD0[(2 * w + kb) * n1 + d + a.R] = v;  // every near diagonal of a (wave, key block) is finished exactly once
-    }
+  float* const dsum = sD0 + (2 * w + hi) * n1 + a.R - 4 * hi + lq;  // (this lane's diagonal base + lane - 4 hi at dsum[base])
+  float* const dtrash = sD0 + 2 * Cfg::NW * n1 + tid;
+  // E: the finished sums of the diagonals base + (lane & 31) - 4 hi
+  auto diag_store = [&](const float E, const int base) {
+    const int d = base + lq - 4 * hi;
+    far_neg += d <= -a.R ? E : 0.f;
+    far_pos += d >= a.R ? E : 0.f;
+    *((d > -a.R && d < a.R) ? dsum + base : dtrash) = E;
   };
-  auto flush_carry = [&](int kb) {
-    if (carry_valid[kb]) {
-      emit_diag(kb, carry[kb], carry_d0[kb] + lq);
-      carry_valid[kb] = false;
-      carry[kb] = 0.f;
-    }
+  // end of a step at query row mb: st[kb] = the step's accumulators of key block kb
+  auto diag_step_end = [&](const DiagStep (&st)[2], const int mb) {
+    const float F0 = diag_finish_halves(dcar[0], st[0], l), F1 = diag_finish_halves(dcar[1], st[1], l);
+    diag_store(F1 + dprev0, kw0 + 32 - mb);
+    dprev0 = F0;
+    diag_run = true;
+    diag_mb = mb;
   };
-  auto tree16 = [](const f32x16& x) {
-    const float t0 = (x[0] + x[1]) + (x[2] + x[3]), t1 = (x[4] + x[5]) + (x[6] + x[7]);
-    const float t2 = (x[8] + x[9]) + (x[10] + x[11]), t3 = (x[12] + x[13]) + (x[14] + x[15]);
-    return (t0 + t1) + (t2 + t3);
+  // the end of a run: the diagonals still in the carries (the two 32-diagonal windows below the last step's) leave
+  auto diag_flush = [&]() {
+    if (diag_run) {
+      diag_store(dcar[1].cur + dprev0, kw0 - diag_mb);
+      diag_store(dcar[0].cur, kw0 - diag_mb - 32);
+      diag_carry_zero(dcar[0]);
+      diag_carry_zero(dcar[1]);
+      dprev0 = 0.f;
+      diag_run = false;
+    }
   };
 
   f32x16 dk[2][DB], dv[2][DB];
@@ -210,13 +243,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 #pragma unroll
   for (int rg = 0; rg < Cfg::RINGS; ++rg)
     for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + rg * Cfg::RING + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+  if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 8)) {
     rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
     for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
-    for (int i = l; i < Cfg::SKEW / 16; i += 64) reinterpret_cast<u32x4*>(sG)[i] = u32x4{0u, 0u, 0u, 0u};
   }
   wait_dma_all();
   __syncthreads();
+  FAT5_STAMP(1);
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -323,52 +356,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       }
   };
 
-  // Per-diagonal sums of the rounded dS (DS[kb], the words the dK GEMM consumes) of key block kb at query step mb -- the bias-table
-  // gradient's share of one 32 x 32 block.  `far_sum`: the block's sum for the case that it lies entirely beyond the band.
-  auto diag_sums = [&](const int kb, const int mb, const float far_sum) {
-    const int R = a.R;
-    const int k0 = kw0 + 32 * kb;
-    const int dmin = k0 - (mb + 31), dmax = k0 + 31 - mb;
-    if (dmax <= -R || dmin >= R) {
-      flush_carry(kb);
-      if (dmax <= -R) far_neg += far_sum; else far_pos += far_sum;
-    } else {
-      // skew-store the rounded dS (element (q, k) -> row q, column k - q + 31), column sums on the matrix pipe
-      char* gw = sG + sk_w;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-        for (int wd = 0; wd < 4; ++wd) {
-          const int r = 8 * t2 + 2 * wd;
-          const uint32_t word = DS[kb][t2][wd];
-          *reinterpret_cast<uint16_t*>(gw + ((r & 3) + 8 * (r >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word & 0xffffu);
-          *reinterpret_cast<uint16_t*>(gw + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * (Cfg::SKEW_ROW - 2)) = (uint16_t)(word >> 16);
-        }
-      typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-      const f32x4 zf4 = {0.f, 0.f, 0.f, 0.f};
-      float cs[4];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const char* p0 = sG + sk_r[0] + 32 * cb;
-        const char* p1 = sG + sk_r[1] + 32 * cb;
-        const u32x2 fa0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p0));
-        const u32x2 fa1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)p1));
-        const u32x4 fr = {fa0[0], fa0[1], fa1[0], fa1[1]};
-        cs[cb] = mfma16<BF16>(ones, fr, zf4)[0];
-      }
-      const bool up = (lq & 16) != 0;
-      const float c_lo = up ? cs[1] : cs[0], c_hi = up ? cs[3] : cs[2];
-      const int d_hi0 = k0 - mb + 1;  // diagonal of column 32
-      if (carry_valid[kb] && carry_d0[kb] != d_hi0) flush_carry(kb);
-      emit_diag(kb, c_hi + (carry_valid[kb] ? carry[kb] : 0.f), d_hi0 + lq);
-      carry[kb] = c_lo;
-      carry_d0[kb] = k0 - mb - 31;
-      carry_valid[kb] = true;
-    }
-  };
-
   // general softmax stage of the step at query row mb: S, DP -> PB, DS (+ per-diagonal sums of dS)
   auto softmax_generic = [&](const int mb) {
+    DiagStep gst[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16& s = S[kb];
@@ -416,9 +406,12 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         DS[kb][t2] = pack8<BF16>(s, t2);
       }
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-        if (want_drpe) diag_sums(kb, mb, tree16(s));
+        // the block's dS (fp32, masked elements zero) onto its diagonals; whole blocks beyond the band included
+        diag_step_zero(gst[kb]);
+        static_for<16>([&](auto ri) { diag_elem<decltype(ri)::value>(gst[kb], s[decltype(ri)::value], l & 15); });
       }
     }
+    if constexpr (BIAS == FAT5_BIAS_RPE1D) diag_step_end(gst, mb);
   };
 
   // the stages of one iteration one after the other (band / masked steps)
@@ -458,11 +451,23 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     u32x4 T[2][4];
     uint32_t tadr1 = 0u;
     if constexpr (BAND) T[0][0] = TN0;
+    // BAND: the step's dS onto its diagonals (diag_sum.h), element e three gaps after its exponent argument: one rotating add for
+    // everything, one rotating multiply-add by the borrow mask (both read Dv[e], written one gap earlier: no DPP hazard)
+    [[maybe_unused]] DiagStep dst[2];
+    if constexpr (BAND) {
+      diag_step_zero(dst[0]);
+      diag_step_zero(dst[1]);
+    }
     f32x16 Sn[2], DPn[2];
     [[maybe_unused]] f32x16 NL, DL;
     u32x4 PBn[2][2], DSn[2][2], qa[KK], da[KK];
     u32x2 trh[4][2][2], tnd[2], tnq[2];
     float X[32], Pv[32], Dv[32];
+    auto diag_el = [&]<int E>() {
+      constexpr int r = E & 15, ql0 = diag_ql0(r);
+      diag_elem_u<r>(dst[E >> 4], Dv[E]);
+      if constexpr (ql0 != 0) diag_elem_bm<r>(dst[E >> 4], Dv[E], dmask[ql0 < 8 ? ql0 - 1 : ql0 - 5]);
+    };
     auto pack_pair = [&]<int E0>() {
       constexpr int kb = E0 >> 4, r0 = E0 & 15, t2 = r0 >> 3, wd = (r0 & 7) >> 1;
       PBn[kb][t2][wd] = asm_cvt_pk<BF16>(Pv[E0], Pv[E0 + 1]);
@@ -521,9 +526,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
       if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
       if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
-      if constexpr (BAND) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
+      if constexpr (BAND && !(FAT5_ABL & 4)) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
       else X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
-      if constexpr (BAND) {  // table entries: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
+      if constexpr (BAND && !(FAT5_ABL & 4)) {  // table entries: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
         if constexpr (g == 1) T[0][1] = lds_rd128(tadr0 - 32u);
         else if constexpr (g == 5) T[0][2] = lds_rd128(tadr0 - 64u);
         else if constexpr (g == 9) T[0][3] = lds_rd128(tadr0 - 96u);
@@ -535,18 +540,25 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else if constexpr (g == 28) tadr0 = tab_addr(0, (mt0 + j + 1) * 32);  // the next step: rows 32 further down, window 32 entries lower
         else if constexpr (g == 29) TN0 = lds_rd128(tadr0);
       }
+      if constexpr (BAND && g >= 3 && !(FAT5_ABL & 1)) diag_el.template operator()<g - 3>();
       if constexpr (g == 31) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
         Pv[31] = asm_exp2(X[31]);
         Dv[30] = asm_mul(Pv[30], DP[1][14]);
         pack_pair.template operator()<28>();
         Dv[31] = asm_mul(Pv[31], DP[1][15]);
         pack_pair.template operator()<30>();
+        if constexpr (BAND && !(FAT5_ABL & 1)) {
+          diag_el.template operator()<29>();
+          diag_el.template operator()<30>();
+          asm volatile("s_nop 1" ::: "memory");  // (Dv[31] was written two instructions ago: DPP operands need two wait states)
+          diag_el.template operator()<31>();
+        }
       }
       }
       // far-bin sum of the step's dS: one 16x16x32 MFMA (16 cycles of the pipe, inside the gap's slack) per four packed words once they
       // are complete — 16 v_dot2c_f32_bf16 per step measured 9 % of this kernel. The last group's words come from the asm ops just
       // above (no hazard padding for asm producers: two wait states by hand)
-      if constexpr (BIAS == FAT5_BIAS_RPE1D && !BAND && (g == 12 || g == 20 || g == 28 || g == 31)) {
+      if constexpr (BIAS == FAT5_BIAS_RPE1D && !BAND && !(FAT5_ABL & 32) && (g == 12 || g == 20 || g == 28 || g == 31)) {
         constexpr int grp = g == 31 ? 3 : (g - 12) >> 3;
         if constexpr (g == 31) asm volatile("s_nop 1" ::: "memory");
         // (asm, accumulating in place: a builtin may pick a fresh destination, and a C operand that is not the destination is still
@@ -568,18 +580,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
     TRD = u32x4{tnd[0][0], tnd[0][1], tnd[1][0], tnd[1][1]};
     TRQ = u32x4{tnq[0][0], tnq[0][1], tnq[1][0], tnq[1][1]};
-    if constexpr (BAND && BIAS == FAT5_BIAS_RPE1D) {
-      if (want_drpe) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          float fs = 0.f;  // (a block of the step entirely beyond the band: the sum of its rounded words)
-#pragma unroll
-          for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int wd = 0; wd < 4; ++wd) fs += cvt_lo<BF16>(DS[kb][t2][wd]) + cvt_hi<BF16>(DS[kb][t2][wd]);
-          diag_sums(kb, (mt0 + j) * 32, fs);
-        }
-      }
+    if constexpr (BAND && BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 2)) {
+      const int mb = (mt0 + j) * 32;
+      asm volatile("s_nop 1" : "+v"(dst[1].u1), "+v"(dst[1].b1));  // (asm producers: see above)
+      diag_step_end(dst, mb);
     }
   };
 
@@ -592,6 +596,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       for (int t2 = 0; t2 < 2; ++t2) { PB[kb][t2] = zero4; DS[kb][t2] = zero4; }
     TRD = zero4;
     TRQ = zero4;
+    FAT5_STAMP(2);
 
     // this wave's 64 keys x the step's 32 rows: all visible and one constant bias?  (wave-uniform; rows past M contribute
     // nothing by their statistics).  side: +1 far-positive (k - q >= R), -1 far-negative / no bias
@@ -617,10 +622,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       // first and the last step of a trip decide for all four.  Steps that do not fill an aligned trip run the general iteration.
       while (j + 4 <= nsteps && (j & 3) == 0 && classify(j, side) && classify(j + 3, side3) && side3 == side) {
         const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
-        if constexpr (BIAS == FAT5_BIAS_RPE1D) {
-          flush_carry(0);
-          flush_carry(1);
-        }
+        if constexpr (BIAS == FAT5_BIAS_RPE1D) diag_flush();
         static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(j + decltype(si)::value, cst); });
         j += 4;
         if constexpr (BIAS == FAT5_BIAS_RPE1D) {
@@ -655,15 +657,16 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       }
     }
     // drain: the products of the last step
+    FAT5_STAMP(3);
     product_step((uint32_t)(((nsteps - 1) & 3) * SLOT));
   }
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
+  FAT5_STAMP(4);
   // ---- partial per-diagonal sums of this key block (before the dK / dV stores: see attn_bwd.h) ----
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+  if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 16)) {
     if (want_drpe) {
-      flush_carry(0);
-      flush_carry(1);
+      diag_flush();
       far_neg = wave_sum(far_neg);
       far_pos = wave_sum(far_pos);
       if (l == 0) {
@@ -682,6 +685,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
   }
 
+  FAT5_STAMP(5);
   if constexpr (HALF) {
     // ---- the second pair hands its dK^T / dV^T over (lane-major 16-byte pieces: conflict-free), the first adds and stores ----
     __syncthreads();  // every wave is done with the rings
@@ -736,6 +740,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         }
     }
   }
+  FAT5_STAMP(6);
 }
 
 // =============================================================================================
@@ -761,6 +766,7 @@ struct BwdQ64Cfg {
 template <int D, bool BF16, int BIAS>
 FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
+  FAT5_STAMP(0);
   using Cfg = BwdQ64Cfg<D>;
   constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -811,7 +817,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
     }
     const float delta = pair_sum(dsum);
-    if (a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
+    if (!FAT5_TRACE && a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
     const float Lq = a.lse[stat_off + qrow_c];
     nL2[qb] = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;  // (dead rows: see attn_bwd.h)
     if (a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
@@ -879,6 +885,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   wait_dma_all();
   __syncthreads();
+  FAT5_STAMP(1);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -903,6 +910,24 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // band steps of the pipelined loop (round 4): LDS byte address of entry 0 of this lane's padded table copy per query block and the
+  // lane's position term -- the entries of keys nb + 4 hi + 8 gg + (0..3), gg = 0..3, are the 16 bytes at tab_addr(qb, nb) + 32 gg
+  // (the window runs UP with the key; see softmax_generic) -- and the first entries of the step whose softmax is due (fetched one
+  // iteration ahead)
+  uint32_t tabA[2] = {0u, 0u};
+  int posb[2] = {0, 0};
+  u32x4 TN0;
+  uint32_t tadr0 = 0u;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qw0 + 32 * qb + lq;
+      tabA[qb] = (uint32_t)(uintptr_t)sTa[qb];
+      posb[qb] = a.R + 4 * hi - qrow - ((a.R - qrow) & 3);
+    }
+  }
+  const int tclamp_hi = rpe_n1p(a.R) - kRpePad - 28;  // (rpe_clamp_asc)
+  auto tab_addr = [&](int qb, int nb) { return tabA[qb] + 4u * (uint32_t)min(max(posb[qb] + nb, -kRpePad), tclamp_hi); };
 
   // Pipeline state between two iterations (iteration i = key step i is in its softmax stage):
   //   S, DP     S^T = K Q^T and dP'^T = V dO^T - delta of step i (lane = query row, register r <-> key crow(r, hi))
@@ -1006,14 +1031,29 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   //          gaps 12..15 the V row-major fragments of step i+1; gaps 22..25 the K^T fragments (t2 = 0) of step i
   // SL = the step's ring slot, a compile-time constant: the steady state runs four steps (slots 0..3) per trip, straight-line --
   // slot offsets are instruction immediates and S / Sn (...) trade registers from one step to the next instead of being copied.
+  // BAND (round 4): the same iteration for steps that cross the T5 band (every key visible): the bias of element (k, q) comes from this
+  // lane's padded table copy -- four 16-byte reads per query block, each issued three or more gaps ahead of its first use (the first one
+  // during the previous iteration: TN0) -- plus the row's -L2 (one v_add in front of the FMA: the rounding of the general iteration).
+  // A band step was the general, unpipelined iteration before (the 64-row body lost to the 32-row one below 8192 keys for it).
   constexpr int NG = 24, G_DP = 16;  // (G_DP: first gap of the dP k-steps)
-  auto fast_iter = [&]<int SL>(const int t, const float ad0, const float ad1) {
+  auto fast_iter = [&]<int SL, bool BAND>(const int t, const float ad0, const float ad1) {
     constexpr uint32_t o_prev = (uint32_t)(((SL + 3) & 3) * SLOT), o_cur = (uint32_t)(SL * SLOT), o_next = (uint32_t)(((SL + 1) & 3) * SLOT);
     f32x16 Sn[2], DPn[2];
     u32x4 DSn[2][2], kf[KK], vf[KK];
     u32x2 th[2][2], tn[2][2];  // [db][half]: K^T fragments t2 = 1 of step i-1 / t2 = 0 of step i
     float X[32], Pv[32], Dv[32];
-    auto stA_ = [&]<int E>() { X[E] = asm_fma(S[E >> 4][E & 15], c2, (E >> 4) == 0 ? ad0 : ad1); };
+    u32x4 T[2][4];
+    uint32_t tadr1 = 0u;
+    if constexpr (BAND) T[0][0] = TN0;
+    auto stA_ = [&]<int E>() {
+      if constexpr (BAND) {
+        float tn_ = __uint_as_float(T[E >> 4][(E & 15) >> 2][E & 3]);
+        asm_add(tn_, (E >> 4) == 0 ? ad0 : ad1);  // (ad = -L2 of the lane's row: entry + ad, then the FMA -- as the general iteration rounds)
+        X[E] = asm_fma(S[E >> 4][E & 15], c2, tn_);
+      } else {
+        X[E] = asm_fma(S[E >> 4][E & 15], c2, (E >> 4) == 0 ? ad0 : ad1);
+      }
+    };
     auto stB_ = [&]<int E>() { Pv[E] = asm_exp2(X[E]); };
     auto stC_ = [&]<int E>() { Dv[E] = asm_mul(Pv[E], DP[E >> 4][E & 15]); };
     auto stD_ = [&]<int E0>() {
@@ -1054,6 +1094,18 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       } else if constexpr (g >= NG - 4) {
         constexpr int db = (g - (NG - 4)) >> 1, half = g & 1;
         tn[db][half] = lds_rd_tr_half(trA[half][db] + o_cur);
+      }
+      if constexpr (BAND) {  // table entries: (query block, key group gg) is first used in gap 0, 3, 5, 8 | 11, 13, 16, 19
+        if constexpr (g == 0) T[0][1] = lds_rd128(tadr0 + 32u);
+        else if constexpr (g == 2) T[0][2] = lds_rd128(tadr0 + 64u);
+        else if constexpr (g == 5) T[0][3] = lds_rd128(tadr0 + 96u);
+        else if constexpr (g == 6) tadr1 = tab_addr(1, t * 32);
+        else if constexpr (g == 8) T[1][0] = lds_rd128(tadr1);
+        else if constexpr (g == 9) T[1][1] = lds_rd128(tadr1 + 32u);
+        else if constexpr (g == 11) T[1][2] = lds_rd128(tadr1 + 64u);
+        else if constexpr (g == 16) T[1][3] = lds_rd128(tadr1 + 96u);
+        else if constexpr (g == 17) tadr0 = tab_addr(0, (t + 1) * 32);  // the next step: keys 32 further up
+        else if constexpr (g == 18) TN0 = lds_rd128(tadr0);
       }
       // ---- VALU ----
       {
@@ -1097,38 +1149,59 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = zero4;
     TRK[0] = zero4;
     TRK[1] = zero4;
-    // this wave's 64 rows x the step's 32 keys: all visible and one constant bias?  (wave-uniform)
-    auto classify = [&](const int t, float& cst) {
+    FAT5_STAMP(2);
+    // this wave's 64 rows x the step's 32 keys: all visible and one constant bias?  (wave-uniform)  side: -1 far-negative / no bias, +1 far-positive
+    auto classify = [&](const int t, int& side) {
       const int nb = t * 32;
       bool fast = nb + 32 <= N && (!a.causal || nb + 31 <= qw0 + P);
-      cst = 0.f;
+      side = -1;
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         const bool fneg = nb + 31 - qw0 <= -a.R, fpos = nb - (qw0 + 63) >= a.R;
         fast = fast && (fneg || fpos);
-        cst = fneg ? cst_neg : cst_pos;
+        side = fneg ? -1 : 1;
       }
       return fast;
     };
-    // (two single-body inner loops, not one loop over `fast ? A : B`: the register allocator keeps one assignment per loop and
+    // every key of the step visible to all 64 rows of the wave (no key tail, no causal mask)?  Monotone: earlier steps see more
+    auto all_visible = [&](const int t) { return t * 32 + 32 <= N && (!a.causal || t * 32 + 31 <= qw0 + P); };
+    // (single-body inner loops, not one loop over `fast ? A : B`: the register allocator keeps one assignment per loop and
     //  pays its copies only at the few transitions)
     int t = 0;
     while (t < nt) {
-      float cst, cst3;
+      int side, side3;
       // steady state: four steps (ring slots 0..3) per trip; the fast steps of one side are contiguous, so the first and the last
-      // step of a trip decide for all four.  Fast steps that do not fill an aligned trip run the general iteration.
-      while (t + 4 <= nt && (t & 3) == 0 && classify(t, cst) && classify(t + 3, cst3) && cst3 == cst) {
+      // step of a trip decide for all four.  Steps that do not fill an aligned trip run the general iteration.
+      while (t + 4 <= nt && (t & 3) == 0 && classify(t, side) && classify(t + 3, side3) && side3 == side) {
+        const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
         const float ad0 = cst + nL2[0], ad1 = cst + nL2[1];
-        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(t + decltype(si)::value, ad0, ad1); });
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(t + decltype(si)::value, ad0, ad1); });
         t += 4;
       }
-      if (t < nt) {
-        generic_iter(t);
-        ++t;
+      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        // trips that touch the band but see every key (band-mode iterations)
+        while (t + 4 <= nt && (t & 3) == 0 && all_visible(t + 3) && !(classify(t, side) && classify(t + 3, side3) && side3 == side)) {
+          tadr0 = tab_addr(0, t * 32);
+          TN0 = lds_rd128(tadr0);
+          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, true>(t + decltype(si)::value, nL2[0], nL2[1]); });
+          t += 4;
+        }
+        // (after a band trip the far side may follow at once: no general iteration in between, it would break the trips' alignment)
+        if (t < nt && !(t + 4 <= nt && (t & 3) == 0 && classify(t, side) && classify(t + 3, side3) && side3 == side)) {
+          generic_iter(t);
+          ++t;
+        }
+      } else {
+        if (t < nt) {
+          generic_iter(t);
+          ++t;
+        }
       }
     }
+    FAT5_STAMP(3);
     product_step((uint32_t)(((nt - 1) & 3) * SLOT));
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
+  FAT5_STAMP(4);
 
   const float scale = a.scale;
 #pragma unroll
@@ -1147,6 +1220,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         }
     }
   }
+  FAT5_STAMP(6);
 }
 
 template <int D, bool BF16, int BIAS>

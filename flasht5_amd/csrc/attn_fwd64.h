@@ -34,11 +34,6 @@
 
 namespace fat5 {
 
-template <int N, typename F>
-FAT5_DEV void static_for(F&& f) {
-  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
-}
-
 template <int D, bool KSPLIT = false>
 struct Fwd64Cfg {
   static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = 4;  // NS ring slots per operand

@@ -3,7 +3,9 @@
     python tools/attn_time.py [--S 512,2048,8192] [--modes none,rpe,dense] [--what fwd,bwd,dq,dkdv,red] [--variant BITS]
                            [--B 4 --H 12 --D 64] [--dtype bf16|fp16] [--causal] [--radius 128] [--no-dbias] [--iters 20] [--reps 5]
 
-Per (S, mode, stage): min / median / max over --reps event-timed batches of --iters launches (us) and TFLOP/s of the median by the
+Per (S, mode, stage): min / median / max over --reps event-timed batches of --iters launches (us; the batch is captured in a HIP graph
+and replayed -- kernel-side time, launch gaps included, no Python / ctypes / hipFuncSetAttribute time: a Python loop is host-bound
+below ~25 us per launch; --eager times the Python loop instead) and TFLOP/s of the median by the
 reference's FLOP model (benchmarks/bench_fa2_bias.py:10-13: fwd 4BHMND, bwd 2.5x; dq 0.5x, dkdv 2x of the forward).
 --variant: fat5_variant bits (include/fat5.h), e.g. 1 = FWD64_ON, 2 = FWD64_OFF, 4 / 8 = KV64 on / off, 16 / 32 = Q64 on / off."""
 import argparse, os, statistics, sys, time
@@ -19,7 +21,7 @@ ap.add_argument("--S", default="512,2048,8192"); ap.add_argument("--modes", defa
 ap.add_argument("--variant", type=int, default=0); ap.add_argument("--B", type=int, default=4); ap.add_argument("--H", type=int, default=12)
 ap.add_argument("--D", type=int, default=64); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--causal", action="store_true")
 ap.add_argument("--radius", type=int, default=128); ap.add_argument("--no-dbias", action="store_true")
-ap.add_argument("--iters", type=int, default=20); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--iters", type=int, default=20); ap.add_argument("--reps", type=int, default=5); ap.add_argument("--eager", action="store_true")
 a = ap.parse_args()
 dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 STAGE = {"bwd": 7, "dq": 1, "dkdv": 2, "red": 4, "dq+dkdv": 3}
@@ -49,13 +51,26 @@ for S in (int(x) for x in a.S.split(",")):
         cells = []
         for what in a.what.split(","):
             fn = plan.forward if what == "fwd" else (lambda st=STAGE[what]: plan.backward(st))
-            prewarm(fn)
+            batch = fn
+            if not a.eager:
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.cuda.graph(g, stream=side):
+                    for _ in range(a.iters):
+                        fn()
+                torch.cuda.current_stream().wait_stream(side)
+                batch = g.replay
+            prewarm(batch if not a.eager else fn)
             ts = []
             for _ in range(a.reps):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                for _ in range(a.iters):
-                    fn()
+                if a.eager:
+                    for _ in range(a.iters):
+                        fn()
+                else:
+                    batch()
                 e.record(); torch.cuda.synchronize()
                 ts.append(s.elapsed_time(e) / a.iters * 1e3)
             med = statistics.median(ts)
