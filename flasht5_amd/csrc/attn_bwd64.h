@@ -44,20 +44,34 @@ namespace fat5 {
 // half of the query steps through a ring of its own, then the second pair hands its dK^T / dV^T over through LDS.  With 256-key
 // workgroups at one per CU (one wave per SIMD), (4,12,2048,64) is 384 workgroups on 256 CUs: two rounds, the second half empty.
 // 768 half-length workgroups are three full rounds of half the length.
-template <int D, bool HALF = false>
+// SELF (round 4: the dK/dV half of a launch shared with the dQ body, attn_bwd_fused64_kernel): the body forms its row statistics
+// itself instead of reading the dQ kernel's (AttnArgs::stat2) -- the only dependency between the two kernels.  Every step brings its
+// O rows and its 32 raw log-sum-exp values along; two steps ahead of their use every wave turns 8 of the step's rows into
+// -L/scale and -delta = -rowsum(o * do) (reference _bwd_preprocess, flash_attention_v2_bias.py:516-556) in the slot's statistics area.
+template <int D, bool HALF = false, bool SELF = false>
 struct Bwd64Cfg {
+  static_assert(!(HALF && SELF), "the self-sufficient variant exists for 256-key workgroups only");
   static constexpr int NW = 4, BNK = HALF ? 128 : 64 * NW, QT = 32, NT = 64 * NW, NS = 4;
   static constexpr int IMG = rm_bytes<D, QT>();  // one 32-row image (Q or dO)
-  static constexpr int STATB = NW * 1024;        // one private 1 KiB DMA piece of row statistics per wave (256 B used)
-  static constexpr int SLOT = 2 * IMG + STATB;
+  static constexpr int IMGS = SELF ? 3 : 2;      // Q | dO (| O)
+  // statistics of a step: one private 1 KiB DMA piece per wave (256 B used: [32] -L/scale, [32] -delta); SELF: one shared 1 KiB DMA
+  // piece of raw L (its first 128 bytes become -L/scale in place) + [32] -delta behind it
+  static constexpr int STATB = SELF ? 1024 + 256 : NW * 1024;
+  static constexpr int DLOFF = SELF ? 1024 : 128;  // byte offset of -delta inside the statistics area
+  static constexpr int SLOT = IMGS * IMG + STATB;
   static constexpr int RING = NS * SLOT;
   static constexpr int RINGS = HALF ? 2 : 1;     // one ring of query steps per wave pair
-  static constexpr int RPE0 = RINGS * RING;      // the RPE state sits behind the ring(s)
-  static_assert(!HALF || 2 * 128 * 64 * 4 <= RPE0, "the hand-over of dK^T / dV^T (128 registers x 64 lanes per wave) reuses the rings");
+  static constexpr int RINGB = RINGS * RING;
+  static_assert(!HALF || 2 * 128 * 64 * 4 <= RINGB, "the hand-over of dK^T / dV^T (128 registers x 64 lanes per wave) reuses the rings");
+  // staging (round 4, see BwdQ64Cfg): the 64 keys of a wave arrive as whole rows of K | V by LDS-DMA and dK | dV leave as whole rows
+  // through the same images (HALF: the two pairs share the images of their common keys)
+  static constexpr int STG_T = 64 * 2 * D;       // one tensor's 64 rows
+  static constexpr int STG = (HALF ? 2 : NW) * 2 * STG_T;
+  static __host__ __device__ constexpr int rpe0(bool stage) { return RINGB + (stage ? STG : 0); }  // the RPE state sits behind the ring(s) and the staging images
   // rpe: four aligned table copies + one private diagonal accumulator per (wave, key block)
   // (+ one scratch word per thread: the target of the lanes that have no near diagonal to store)
   static __host__ __device__ size_t rpe_off(int R) { return (rpe_table_bytes(R) + (size_t)(2 * R + 1) * 4 * 2 * NW + NT * 4 + 63) / 64 * 64; }
-  static size_t smem(int R, int bias_mode) { return RPE0 + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) : 0); }
+  static size_t smem(int R, int bias_mode, bool stage = false) { return rpe0(stage) + (bias_mode == FAT5_BIAS_RPE1D ? rpe_off(R) : 0); }
 };
 
 FAT5_DEV float asm_mul(float a, float b) {
@@ -83,11 +97,11 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 // (b, h, nblk): the key block of this workgroup; part_row: its row among the a.part_stride partial diagonal-sum rows of (b, h);
 // part_zero_next: the row behind it is nobody's and has to read zero (a 256-key workgroup of a launch that counts rows in
 // 128-key units: attn_bwd_kv64_mixed_kernel)
-template <int D, bool BF16, int BIAS, bool HALF>
+template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
   FAT5_STAMP(0);
-  using Cfg = Bwd64Cfg<D, HALF>;
+  using Cfg = Bwd64Cfg<D, HALF, SELF>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,20 +121,45 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   const int P = N - M;
   const int kw0 = n0 + 64 * wp;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
 
-  // K and V fragments (B operands) of this lane's two keys
+  // K and V fragments (B operands) of this lane's two keys: staged (whole rows by LDS-DMA into the images of this wave's keys, read
+  // back after the prologue's wait; keys past N arrive as zeros -- their scores are masked) or straight from global
+  const bool stg = a.lds_stage != 0;
+  const uint32_t stg_k = (uint32_t)(uintptr_t)smem + (uint32_t)(Cfg::RINGB + wp * 2 * Cfg::STG_T);  // K image | V image of keys kw0 .. kw0 + 63
   u32x4 kf[2][KK], vf[2][KK];
+  if (stg) {
+    using SDma = DmaStage<D, 64, 64>;
+    static_assert(SDma::PER == 8 && SDma::NV == 2, "eight 1-KiB pieces of 8 rows per tensor");
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)stg_k);
+    if (!HALF || pr == 0) {
+      SDma sk;
+      sk.init(a.ks[2], l);
+      const __amdgpu_buffer_rsrc_t rs = make_rows_rsrc(kb_, a.ks[2], N, D);
+      const uint32_t r0 = (uint32_t)kw0 * (uint32_t)a.ks[2] * 2u;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int kr = min(kw0 + 32 * kb + lq, N - 1);
+      for (int i = 0; i < SDma::PER; ++i) dma16_asm(rs, dst + (uint32_t)(i * 1024), sk.voff[i % 2], r0 + sk.piece_step * (i / 2));
+    }
+    if (!HALF || pr == 1) {
+      SDma sv;
+      sv.init(a.vs[2], l);
+      const __amdgpu_buffer_rsrc_t rs = make_rows_rsrc(vb, a.vs[2], N, D);
+      const uint32_t r0 = (uint32_t)kw0 * (uint32_t)a.vs[2] * 2u;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      kf[kb][kk] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)kr * a.ks[2] + 16 * kk + 8 * hi);
-      vf[kb][kk] = *reinterpret_cast<const u32x4*>(vb + (int64_t)kr * a.vs[2] + 16 * kk + 8 * hi);
+      for (int i = 0; i < SDma::PER; ++i) dma16_asm(rs, dst + (uint32_t)(Cfg::STG_T + i * 1024), sv.voff[i % 2], r0 + sv.piece_step * (i / 2));
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int kr = min(kw0 + 32 * kb + lq, N - 1);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        kf[kb][kk] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)kr * a.ks[2] + 16 * kk + 8 * hi);
+        vf[kb][kk] = *reinterpret_cast<const u32x4*>(vb + (int64_t)kr * a.vs[2] + 16 * kk + 8 * hi);
+      }
     }
   }
 
   // ---- RPE state in LDS (see attn_bwd.h: table copies, private diagonal accumulators) ----
-  float* sT = reinterpret_cast<float*>(smem + Cfg::RPE0) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
+  float* sT = reinterpret_cast<float*>(smem + Cfg::rpe0(stg)) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int n1 = 2 * a.R + 1;
   float* sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);
   const uint32_t one2s = pack2<BF16>(1.f, 1.f);
@@ -208,11 +247,17 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   dost.init(a.dos[2], HALF ? (tid & 127) : tid);
   const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
   const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
-  // statistics: 64 floats per step ([32] -L/scale, [32] -delta), whole steps (the dQ kernel pads the last one)
+  // statistics: 64 floats per step ([32] -L/scale, [32] -delta), whole steps (the dQ kernel pads the last one); SELF: the step's 32 raw
+  // log-sum-exp values (rows past M read as zeros through the descriptor) and its O rows
   const __amdgpu_buffer_rsrc_t strs =
-      make_rows_rsrc(reinterpret_cast<const uint16_t*>(a.stat2 + (int64_t)bh * nst_all * 64), 128, nst_all, 128);
-  const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
-  const uint32_t svoff = (uint32_t)(l & 15) * 16u;  // (lanes 16.. re-read the same 256 bytes: no out-of-range reliance)
+      SELF ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lse + (int64_t)bh * M), 0, __builtin_amdgcn_readfirstlane(M * 4), 0x00020000)
+           : make_rows_rsrc(reinterpret_cast<const uint16_t*>(a.stat2 + (int64_t)bh * nst_all * 64), 128, nst_all, 128);
+  const uint16_t* ob = SELF ? a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1] : dob;
+  Dma ost;
+  ost.init(SELF ? a.os[2] : a.dos[2], tid);
+  const __amdgpu_buffer_rsrc_t ors = make_rows_rsrc(ob, SELF ? a.os[2] : a.dos[2], M, D);
+  const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u, ostride_b = (uint32_t)(SELF ? a.os[2] : a.dos[2]) * 2u;
+  const uint32_t svoff = (uint32_t)(l & (SELF ? 7 : 15)) * 16u;  // (the other lanes re-read the same 128 / 256 bytes: no out-of-range reliance)
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ring0 = (uint32_t)(pr * Cfg::RING);  // this pair's ring
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wp * 1024u);
@@ -223,12 +268,45 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     for (int i = 0; i < Dma::PER; ++i) {
       dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
       dma16_asm(dors, wave_lds + slot_off + (uint32_t)(IMG + i * 2048), dost.voff[0], mt * 32u * dostride_b + dost.piece_step * i);
+      if constexpr (SELF) dma16_asm(ors, wave_lds + slot_off + (uint32_t)(2 * IMG + i * 2048), ost.voff[0], mt * 32u * ostride_b + ost.piece_step * i);
     }
-    dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
+    if constexpr (SELF) dma16_asm(strs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + ring0)) + slot_off + (uint32_t)(3 * IMG), svoff, mt * 128u);  // (every wave the same 128 bytes into the shared piece)
+    else dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
   };
-  // E(j): step j+1 has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
+  // SELF: this wave's 8 rows of the step in the slot at `so` -> -L/scale (in place of the raw L) and -delta.  Eight lanes per row, each
+  // one 16-byte piece of the O and dO images (same slot of both: the images share the swizzle), a butterfly over the eight.
+  const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY, nis_c = -1.f / a.scale;
+  struct StatIn { u32x4 dov, ov; float Lr; };
+  const int prow = 8 * w + (l >> 3);
+  auto stats_read = [&](const uint32_t so) {  // (three LDS reads; their values are needed several gaps later)
+    const uint32_t pa = lds0 + ring0 + so + (uint32_t)(prow * 2 * D + (l & 7) * 16);
+    StatIn x;
+    x.dov = lds_rd128(pa + (uint32_t)IMG);
+    x.ov = lds_rd128(pa + (uint32_t)(2 * IMG));
+    x.Lr = reinterpret_cast<const float*>(smem + pr * Cfg::RING + so + 3 * IMG)[prow];
+    return x;
+  };
+  auto stats_value = [&](const StatIn& x, const int j) {  // even lanes: -delta of the lane's row, odd lanes: -L/scale
+    float pd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pd = fmaf(cvt_lo<BF16>(x.ov[i]), cvt_lo<BF16>(x.dov[i]), pd);
+      pd = fmaf(cvt_hi<BF16>(x.ov[i]), cvt_hi<BF16>(x.dov[i]), pd);
+    }
+    pd = dpp_add<0xB1>(pd);   // lane ^ 1
+    pd = dpp_add<0x4E>(pd);   // lane ^ 2
+    pd = dpp_add<0x141>(pd);  // the other quad of each 8
+    const bool live = (mt0 + j) * 32 + prow < M && !(x.Lr < kDeadRowLse);
+    const float nl = live ? x.Lr * nis_c : ninf_c;
+    return (l & 1) ? nl : -pd;
+  };
+  auto stats_write = [&](const float v, const uint32_t so) {
+    reinterpret_cast<float*>(smem + pr * Cfg::RING + so + 3 * IMG)[(l & 1) ? prow : Cfg::DLOFF / 4 + prow] = v;
+  };
+  auto produce_stats = [&](const int j, const uint32_t so) { stats_write(stats_value(stats_read(so), j), so); };
+  // E(j): step j+1 (SELF: j+2) has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
   auto sync_step = [&](int j, uint32_t slot3_off) {
-    if (j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER + 1) : "memory");
+    if (!SELF && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER + 1) : "memory");
     else wait_dma_all();
     __syncthreads();
     if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
@@ -249,6 +327,18 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   }
   wait_dma_all();
   __syncthreads();
+  FragAddr<D> fa;
+  fa.init(l);
+  if (stg) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const uint32_t ad = stg_k + (uint32_t)(fa.rm[kk] + kb * 32 * 2 * D);
+        kf[kb][kk] = lds_rd128(ad);
+        vf[kb][kk] = lds_rd128(ad + (uint32_t)Cfg::STG_T);
+      }
+  }
   FAT5_STAMP(1);
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -256,8 +346,6 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+a"(kf[kb][kk]), "+a"(vf[kb][kk]));  // MFMA-only operands: AGPRs
 
   // per-lane LDS addresses (ring base folded in; slot / image / step offsets are immediates)
-  FragAddr<D> fa;
-  fa.init(l);
   uint32_t rmA[KK], trA[2][DB], stA;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
@@ -271,8 +359,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       trA[j2][db] = lds0 + ring0 + (uint32_t)fa.tr[j2][db];
       asm volatile("" : "+v"(trA[j2][db]));
     }
-  stA = lds0 + ring0 + (uint32_t)(2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +128+32g (-delta)
+  stA = lds0 + ring0 + (uint32_t)(SELF ? 3 * IMG + 16 * hi : 2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +DLOFF+32g (-delta)
   asm volatile("" : "+v"(stA));
+  if constexpr (SELF) {  // the statistics of the first two steps (step 2's follow in iteration 0)
+    produce_stats(0, 0u);
+    produce_stats(1, (uint32_t)SLOT);
+    __syncthreads();
+  }
   auto rd_f4 = [&](uint32_t addr) { return __builtin_bit_cast(f32x4, lds_rd128(addr)); };
   auto put4 = [](f32x16& x, int g, const f32x4 v) { x[4 * g] = v[0]; x[4 * g + 1] = v[1]; x[4 * g + 2] = v[2]; x[4 * g + 3] = v[3]; };
   auto rd_tr = [&](uint32_t off, int t2, int db) {
@@ -325,7 +418,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         put4(Sx[kb], g, rd_f4(stA + so + (uint32_t)(32 * g)));
-        put4(DPx[kb], g, rd_f4(stA + so + (uint32_t)(128 + 32 * g)));
+        put4(DPx[kb], g, rd_f4(stA + so + (uint32_t)(Cfg::DLOFF + 32 * g)));
       }
     u32x4 qa[KK], da[KK];
 #pragma unroll
@@ -419,6 +512,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     const uint32_t o_prev = (uint32_t)(((j + 3) & 3) * SLOT), o_cur = (uint32_t)((j & 3) * SLOT), o_next = (uint32_t)(((j + 1) & 3) * SLOT);
     product_step(o_prev);
     sync_step(j, o_prev);
+    if constexpr (SELF) produce_stats(j + 2, (uint32_t)(((j + 2) & 3) * SLOT));
     f32x16 Sn[2], DPn[2];
     score_step(o_next, Sn, DPn);
     softmax_generic((mt0 + j) * 32);
@@ -458,6 +552,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       diag_step_zero(dst[0]);
       diag_step_zero(dst[1]);
     }
+    [[maybe_unused]] StatIn sin_;
+    [[maybe_unused]] float sval_ = 0.f;
     f32x16 Sn[2], DPn[2];
     [[maybe_unused]] f32x16 NL, DL;
     u32x4 PBn[2][2], DSn[2][2], qa[KK], da[KK];
@@ -494,6 +590,11 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else DPn[kb] = mfma32<BF16>(da[kk], vf[kb][kk], DPn[kb]);  // (preloaded with -delta)
       }
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap)
+      // (SELF: the statistics of step j+2, which has landed behind E(j) and is read two iterations from now: reads, arithmetic and the
+      //  store in gaps of their own)
+      if constexpr (SELF && g == 13) sin_ = stats_read(((SL + 2) & 3) * SLOT);
+      if constexpr (SELF && g == 23) sval_ = stats_value(sin_, j + 2);
+      if constexpr (SELF && g == 27) stats_write(sval_, ((SL + 2) & 3) * SLOT);
       if constexpr (g == 19) asm volatile("" ::"v"(NL));  // (keeps NL's registers out of reach of the VALU ops of gaps 16..18)
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
       // ---- barrier + DMA ----
@@ -510,10 +611,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       } else if constexpr (g >= 13 && g <= 16) {
         qa[g - 13] = lds_rd128(rmA[g - 13] + o_next);
       } else if constexpr (g == 17) {
-        put4(DL, 0, rd_f4(stA + o_next + 128u));
-        put4(DL, 1, rd_f4(stA + o_next + 160u));
-        put4(DL, 2, rd_f4(stA + o_next + 192u));
-        put4(DL, 3, rd_f4(stA + o_next + 224u));
+        put4(DL, 0, rd_f4(stA + o_next + (uint32_t)Cfg::DLOFF));
+        put4(DL, 1, rd_f4(stA + o_next + (uint32_t)(Cfg::DLOFF + 32)));
+        put4(DL, 2, rd_f4(stA + o_next + (uint32_t)(Cfg::DLOFF + 64)));
+        put4(DL, 3, rd_f4(stA + o_next + (uint32_t)(Cfg::DLOFF + 96)));
       } else if constexpr (g >= 19 && g <= 22) {
         da[g - 19] = lds_rd128(rmA[g - 19] + o_next + (uint32_t)IMG);
       } else if constexpr (g >= 28) {
@@ -720,6 +821,39 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         }
   }
   const float scale = a.scale;
+  if (stg) {
+    // dK | dV through the images of this wave's keys (their fragments have long been read; HALF: the other pair returned above and its
+    // last LDS access is behind the hand-over's barrier): 8-byte pieces into the swizzled row-major images, out again as whole rows
+    char* img = smem + Cfg::RINGB + wp * 2 * Cfg::STG_T;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = 32 * kb + lq;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 wk, wv;
+          wk[0] = pack2<BF16>(dk[kb][db][4 * g + 0] * scale, dk[kb][db][4 * g + 1] * scale);
+          wk[1] = pack2<BF16>(dk[kb][db][4 * g + 2] * scale, dk[kb][db][4 * g + 3] * scale);
+          wv[0] = pack2<BF16>(dv[kb][db][4 * g + 0], dv[kb][db][4 * g + 1]);
+          wv[1] = pack2<BF16>(dv[kb][db][4 * g + 2], dv[kb][db][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(img + rm_off<D>(row, 4 * db + g) + 8 * hi) = wk;
+          *reinterpret_cast<u32x2*>(img + Cfg::STG_T + rm_off<D>(row, 4 * db + g) + 8 * hi) = wv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 8 * i + (l >> 3), slot = l & 7;
+      const u32x4 k4 = *reinterpret_cast<const u32x4*>(img + row * (2 * D) + slot * 16);
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(img + Cfg::STG_T + row * (2 * D) + slot * 16);
+      if (kw0 + row < N) {
+        *reinterpret_cast<u32x4*>(dkb + (int64_t)(kw0 + row) * a.dks[2] + ((slot ^ swz<D>(row)) << 3)) = k4;
+        *reinterpret_cast<u32x4*>(dvb + (int64_t)(kw0 + row) * a.dvs[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
+      }
+    }
+    FAT5_STAMP(6);
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int krow = kw0 + 32 * kb + lq;
@@ -760,7 +894,14 @@ struct BwdQ64Cfg {
   static constexpr int IMG = rm_bytes<D, KT>();  // one 32-key image (K or V)
   static constexpr int SLOT = 2 * IMG;
   static constexpr int RING = NS * SLOT;
-  static size_t smem(int R, int bias_mode) { return RING + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0); }
+  // staging (round 4): the wave's 64 rows of Q, dO and O arrive as whole rows by LDS-DMA (one 1-KiB piece = 8 rows of 128 bytes) and
+  // are read back as operand fragments; dQ leaves the same way.  A lane loading "its" row straight from global touches 64 cache
+  // lines per instruction: 13.5 k cycles of prologue measured (tools/trace64.py), a third of the kernel at 512 keys.
+  static constexpr int STG_T = 64 * 2 * D;      // one tensor's 64 rows of one wave
+  static constexpr int STG = NW * 3 * STG_T;
+  static size_t smem(int R, int bias_mode, bool stage = false) {
+    return RING + (stage ? STG : 0) + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0);
+  }
 };
 
 template <int D, bool BF16, int BIAS>
@@ -771,7 +912,8 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sT = reinterpret_cast<float*>(smem + Cfg::RING) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
+  const bool stg = a.lds_stage != 0;
+  float* sT = reinterpret_cast<float*>(smem + Cfg::RING + (stg ? Cfg::STG : 0)) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
 
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
   int b, h, mblk;
@@ -793,7 +935,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   const int qw0 = m0 + 64 * w;  // first query row of this wave; block qb covers qw0 + 32*qb .. +31
 
   // Q and dO fragments (B operands), delta = rowsum(o * do) (reference _bwd_preprocess, :516-556), row statistics
-  u32x4 qf[2][KK], dof[2][KK];
+  u32x4 qf[2][KK], dof[2][KK], off_[2][KK];
   float nL2[2];
   // dP'^T = V dO^T - delta.  The pipelined loop takes -delta as a C operand (nd16: 16 registers per query block, live for the whole
   // loop; 1077 vs 1108 us at cfg3 for the alternative); the general iteration forms it with one extra MFMA per query block, ones(32 x 16) x D3 with
@@ -801,43 +943,79 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   // block as the C operand would hold 32 VGPRs for the whole loop (C and D of an MFMA share one register file)
   u32x4 d3[2];
   [[maybe_unused]] f32x16 nd16[2];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  float Lq_[2];  // (in flight beside the operand loads: one memory round trip for the whole prologue)
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = qw0 + 32 * qb + lq, qrow_c = min(qrow, M - 1);
-    float dsum = 0.f;
+  for (int qb = 0; qb < 2; ++qb) Lq_[qb] = a.lse[stat_off + min(qw0 + 32 * qb + lq, M - 1)];
+  // staged: this wave's rows qw0 .. qw0 + 63 of Q | dO | O as three swizzled row-major images (rows past M arrive as zeros)
+  const uint32_t stg_w = lds0 + (uint32_t)(Cfg::RING + w * 3 * Cfg::STG_T);
+  using SDma = DmaStage<D, 64, 64>;
+  static_assert(SDma::PER == 8 && SDma::NV == 2, "eight 1-KiB pieces of 8 rows per tensor");
+  if (stg) {
+    SDma sq, sdo, so;
+    sq.init(a.qs[2], l);
+    sdo.init(a.dos[2], l);
+    so.init(a.os[2], l);
+    const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb_, a.qs[2], M, D), dors = make_rows_rsrc(dob_, a.dos[2], M, D), ors = make_rows_rsrc(ob_, a.os[2], M, D);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)stg_w);
+    const uint32_t q0 = (uint32_t)qw0 * (uint32_t)a.qs[2] * 2u, do0 = (uint32_t)qw0 * (uint32_t)a.dos[2] * 2u, o0 = (uint32_t)qw0 * (uint32_t)a.os[2] * 2u;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
-      dof[qb][kk] = *reinterpret_cast<const u32x4*>(dob_ + (int64_t)qrow_c * a.dos[2] + 16 * kk + 8 * hi);
-      const u32x4 of = *reinterpret_cast<const u32x4*>(ob_ + (int64_t)qrow_c * a.os[2] + 16 * kk + 8 * hi);
+    for (int i = 0; i < SDma::PER; ++i) {
+      dma16_asm(qrs, dst + (uint32_t)(i * 1024), sq.voff[i % 2], q0 + sq.piece_step * (i / 2));
+      dma16_asm(dors, dst + (uint32_t)(Cfg::STG_T + i * 1024), sdo.voff[i % 2], do0 + sdo.piece_step * (i / 2));
+      dma16_asm(ors, dst + (uint32_t)(2 * Cfg::STG_T + i * 1024), so.voff[i % 2], o0 + so.piece_step * (i / 2));
+    }
+  } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dsum = fmaf(cvt_lo<BF16>(of[j]), cvt_lo<BF16>(dof[qb][kk][j]), dsum);
-        dsum = fmaf(cvt_hi<BF16>(of[j]), cvt_hi<BF16>(dof[qb][kk][j]), dsum);
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow_c = min(qw0 + 32 * qb + lq, M - 1);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
+        dof[qb][kk] = *reinterpret_cast<const u32x4*>(dob_ + (int64_t)qrow_c * a.dos[2] + 16 * kk + 8 * hi);
+        off_[qb][kk] = *reinterpret_cast<const u32x4*>(ob_ + (int64_t)qrow_c * a.os[2] + 16 * kk + 8 * hi);
       }
     }
-    const float delta = pair_sum(dsum);
-    if (!FAT5_TRACE && a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
-    const float Lq = a.lse[stat_off + qrow_c];
-    nL2[qb] = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;  // (dead rows: see attn_bwd.h)
-    if (a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
-      float* st = a.stat2 + (((int64_t)b * a.H + h) * ((M + 31) / 32) + (qrow >> 5)) * 64 + (qrow & 31);
-      const bool live = qrow < M && !(Lq < kDeadRowLse);
-      st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
-      st[32] = qrow < M ? -delta : 0.f;
-    }
-    {
-      const float nd = -delta;
-      const uint32_t p0 = to16<BF16>(nd);
-      const float r1 = nd - cvt16<BF16>((uint16_t)p0);
-      const uint32_t p1 = to16<BF16>(r1);
-      const float r2 = r1 - cvt16<BF16>((uint16_t)p1);
-      const uint32_t p2 = to16<BF16>(r2);
-      d3[qb] = hi == 0 ? u32x4{p0 | (p1 << 16), p2, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};  // (k-index 8*hi + j of the B operand)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) nd16[qb][r] = nd;
-    }
   }
+  // (the fragments of the staged form are read after the prologue's wait; everything derived from them follows below)
+  auto derive_rows = [&]() {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qw0 + 32 * qb + lq;
+      float dsum = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const u32x4 of = off_[qb][kk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dsum = fmaf(cvt_lo<BF16>(of[j]), cvt_lo<BF16>(dof[qb][kk][j]), dsum);
+          dsum = fmaf(cvt_hi<BF16>(of[j]), cvt_hi<BF16>(dof[qb][kk][j]), dsum);
+        }
+      }
+      const float delta = pair_sum(dsum);
+      if (!FAT5_TRACE && a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
+      const float Lq = Lq_[qb];
+      nL2[qb] = (Lq < kDeadRowLse) ? -INFINITY : -Lq * kLog2e;  // (dead rows: see attn_bwd.h)
+      if (a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
+        float* st = a.stat2 + (((int64_t)b * a.H + h) * ((M + 31) / 32) + (qrow >> 5)) * 64 + (qrow & 31);
+        const bool live = qrow < M && !(Lq < kDeadRowLse);
+        st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
+        st[32] = qrow < M ? -delta : 0.f;
+      }
+      {
+        const float nd = -delta;
+        const uint32_t p0 = to16<BF16>(nd);
+        const float r1 = nd - cvt16<BF16>((uint16_t)p0);
+        const uint32_t p1 = to16<BF16>(r1);
+        const float r2 = r1 - cvt16<BF16>((uint16_t)p1);
+        const uint32_t p2 = to16<BF16>(r2);
+        d3[qb] = hi == 0 ? u32x4{p0 | (p1 << 16), p2, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};  // (k-index 8*hi + j of the B operand)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nd16[qb][r] = nd;
+      }
+    }
+  };
+  if (!stg) derive_rows();
   const uint32_t one2 = pack2<BF16>(1.f, 1.f);
   u32x4 ones4 = {one2, one2, one2, one2};
   const float* sTa[2] = {sT, sT};
@@ -863,7 +1041,6 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
   const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb_, a.vs[2], N, D);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
   auto dma_step = [&](int t, uint32_t slot_off) {
     const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane(t);
@@ -882,9 +1059,26 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   for (int i = 0; i < 3; ++i)
     if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
+  FAT5_STAMP(7);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  FAT5_STAMP(8);
   wait_dma_all();
   __syncthreads();
+  FAT5_STAMP(9);
+  FragAddr<D> fa;
+  fa.init(l);
+  if (stg) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const uint32_t ad = stg_w + (uint32_t)(fa.rm[kk] + qb * 32 * 2 * D);
+        qf[qb][kk] = lds_rd128(ad);
+        dof[qb][kk] = lds_rd128(ad + (uint32_t)Cfg::STG_T);
+        off_[qb][kk] = lds_rd128(ad + (uint32_t)(2 * Cfg::STG_T));
+      }
+    derive_rows();
+  }
   FAT5_STAMP(1);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -892,8 +1086,6 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+a"(qf[qb][kk]), "+a"(dof[qb][kk]));  // MFMA-only operands: AGPRs
   asm volatile("" : "+a"(d3[0]), "+a"(d3[1]), "+a"(ones4));
 
-  FragAddr<D> fa;
-  fa.init(l);
   uint32_t rmA[KK], trA[2][DB];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) rmA[kk] = lds0 + (uint32_t)fa.rm[kk];
@@ -1204,11 +1396,13 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   FAT5_STAMP(4);
 
   const float scale = a.scale;
+  if (stg) {
+    // dQ through the wave's (free) Q image: 8-byte pieces into the swizzled row-major image, out again as whole rows -- eight stores
+    // of eight full 128-byte rows each instead of sixteen that touch 64 rows
+    char* img = smem + Cfg::RING + w * 3 * Cfg::STG_T;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = qw0 + 32 * qb + lq;
-    if (qrow < M) {
-      uint16_t* drow = dqb_ + (int64_t)qrow * a.dqs[2];
+    for (int qb = 0; qb < 2; ++qb) {
+      const int row = 32 * qb + lq;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -1216,8 +1410,31 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
           u32x2 wv;
           wv[0] = pack2<BF16>(dq[qb][db][4 * g + 0] * scale, dq[qb][db][4 * g + 1] * scale);
           wv[1] = pack2<BF16>(dq[qb][db][4 * g + 2] * scale, dq[qb][db][4 * g + 3] * scale);
-          *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
+          *reinterpret_cast<u32x2*>(img + rm_off<D>(row, 4 * db + g) + 8 * hi) = wv;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 8 * i + (l >> 3), slot = l & 7;
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(img + row * (2 * D) + slot * 16);
+      if (qw0 + row < M) *reinterpret_cast<u32x4*>(dqb_ + (int64_t)(qw0 + row) * a.dqs[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
+    }
+  } else {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qw0 + 32 * qb + lq;
+      if (qrow < M) {
+        uint16_t* drow = dqb_ + (int64_t)qrow * a.dqs[2];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2 wv;
+            wv[0] = pack2<BF16>(dq[qb][db][4 * g + 0] * scale, dq[qb][db][4 * g + 1] * scale);
+            wv[1] = pack2<BF16>(dq[qb][db][4 * g + 2] * scale, dq[qb][db][4 * g + 3] * scale);
+            *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
+          }
+      }
     }
   }
   FAT5_STAMP(6);
@@ -1227,6 +1444,21 @@ template <int D, bool BF16, int BIAS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_q64_kernel(const AttnArgs a) {
   attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x);
+}
+
+// Both backward kernels in ONE launch for problems whose grids leave the chip's last round mostly empty (mid sequence lengths) or
+// do not fill it at all (cfg2: 96 + 96 workgroups): workgroups [0, n_kv_blocks) run the dK/dV body in its self-sufficient form,
+// the others the dQ body; one workgroup per CU either way (512 registers per lane), the longer ones first.
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_fused64_kernel(const AttnArgs a) {
+  if ((int)blockIdx.x < a.n_kv_blocks) {
+    int b, h, nblk;
+    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+    attn_bwd_kv64_body<D, BF16, BIAS, false, true>(a, b, h, nblk, nblk, false);
+  } else {
+    attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x - a.n_kv_blocks);
+  }
 }
 
 template <int D, bool BF16, int BIAS, bool HALF>

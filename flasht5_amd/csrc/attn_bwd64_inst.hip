@@ -13,25 +13,31 @@ namespace fat5 {
 
 template <int D, bool BF16, int BIAS, bool HALF>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = Bwd64Cfg<D, HALF>::smem(a.R, BIAS);
+  // (operands / outputs through LDS images whenever the workgroup's LDS allows: see BwdQ64Cfg)
+  AttnArgs as = a;
+  as.lds_stage = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, true) <= 160 * 1024;
+  const size_t smem = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, as.lds_stage != 0);
   auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as);
   return hipGetLastError();
 }
 
 template <int D, bool BF16, int BIAS>
 static hipError_t launch_q64(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = BwdQ64Cfg<D>::smem(a.R, BIAS);
+  // (operands / outputs through wave-private LDS images whenever the workgroup's LDS allows: a radius beyond ~500 does not)
+  AttnArgs as = a;
+  as.lds_stage = BwdQ64Cfg<D>::smem(a.R, BIAS, true) <= 160 * 1024;
+  const size_t smem = BwdQ64Cfg<D>::smem(a.R, BIAS, as.lds_stage != 0);
   auto kern = attn_bwd_q64_kernel<D, BF16, BIAS>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as);
   return hipGetLastError();
 }
 hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
@@ -48,13 +54,16 @@ static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int gr
 }
 template <int D, bool BF16, int BIAS>
 static hipError_t launch_kv64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS), Bwd64Cfg<D, true>::smem(a.R, BIAS));
+  AttnArgs as = a;
+  as.lds_stage = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS, true), Bwd64Cfg<D, true>::smem(a.R, BIAS, true)) <= 160 * 1024;
+  const bool st = as.lds_stage != 0;
+  const size_t smem = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS, st), Bwd64Cfg<D, true>::smem(a.R, BIAS, st));
   auto kern = attn_bwd_kv64_mixed_kernel<D, BF16, BIAS>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as);
   return hipGetLastError();
 }
 // nw == 2: the half-length variant (128-key workgroups, two wave pairs each walking half of the query steps); nw == 3: both in one
@@ -66,6 +75,29 @@ hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int 
     return bf16 ? launch_kv64_mixed<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_kv64_mixed<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
   }
   return nw == 2 ? launch_kv64_bias<true>(a, bf16, bias, grid, s) : launch_kv64_bias<false>(a, bf16, bias, grid, s);
+}
+// dK/dV (self-sufficient 256-key form) and dQ in one launch: a.n_kv_blocks workgroups of the former, then the dQ workgroups
+template <int D, bool BF16, int BIAS>
+static hipError_t launch_fused64(const AttnArgs& a, int grid, hipStream_t s) {
+  AttnArgs as = a;
+  as.lds_stage = std::max(Bwd64Cfg<D, false, true>::smem(a.R, BIAS, true), BwdQ64Cfg<D>::smem(a.R, BIAS, true)) <= 160 * 1024;
+  const bool st = as.lds_stage != 0;
+  const size_t smem = std::max(Bwd64Cfg<D, false, true>::smem(a.R, BIAS, st), BwdQ64Cfg<D>::smem(a.R, BIAS, st));
+  auto kern = attn_bwd_fused64_kernel<D, BF16, BIAS>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as);
+  return hipGetLastError();
+}
+hipError_t CAT(launch_bwd_fused64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int /*nw*/, int grid, hipStream_t s) {
+  if (bias == FAT5_BIAS_RPE1D)
+    return bf16 ? launch_fused64<FAT5_INST_D, true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_fused64<FAT5_INST_D, false, FAT5_BIAS_RPE1D>(a, grid, s);
+  return bf16 ? launch_fused64<FAT5_INST_D, true, FAT5_BIAS_NONE>(a, grid, s) : launch_fused64<FAT5_INST_D, false, FAT5_BIAS_NONE>(a, grid, s);
+}
+size_t CAT(smem_bwd_fused64_d, FAT5_INST_D)(int R, int bias) {
+  return std::max(Bwd64Cfg<FAT5_INST_D, false, true>::smem(R, bias), BwdQ64Cfg<FAT5_INST_D>::smem(R, bias));
 }
 size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }
 size_t CAT(smem_bwd_kv64h_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D, true>::smem(R, bias); }

@@ -27,4 +27,7 @@ size_t smem_bwd_kv64_d64(int R, int bias);
 size_t smem_bwd_kv64h_d64(int R, int bias);  // (nw == 2: 128-key workgroups, half the query steps per wave pair)
 // 64 query rows per wave, software-pipelined dQ body (attn_bwd64.h): same conditions
 hipError_t launch_bwd_q64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
+// dK/dV (256-key workgroups, row statistics formed in the body) + dQ in one launch: a.n_kv_blocks workgroups of the former first
+hipError_t launch_bwd_fused64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
+size_t smem_bwd_fused64_d64(int R, int bias);
 }  // namespace fat5

@@ -51,6 +51,7 @@ struct BwdLayout {
   bool kv64_half;   // ... in its half-length variant (128-key workgroups: two wave pairs, each half of the query steps)
   int kv64_mix_pf;  // > 0: both variants in one launch, this many (b, h) pairs per XCD as 256-key workgroups (attn_bwd_kv64_mixed_kernel)
   bool q64;         // dQ by the 64-rows-per-wave pipelined body (attn_bwd64.h)
+  bool fused64;     // both 64-wide bodies in one launch when a call asks for both stages (attn_bwd_fused64_kernel); implies kv64 (256-key) and q64
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
   int n_nblk;
@@ -317,8 +318,31 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
           (q64_env == 1 || ((bh * ((p->M + 255) / 256) >= 512 || (bh * ((p->M + 255) / 256) >= 160 && p->N >= 8192)) &&  // ((4,12,1024x8192): 153 vs 166 us)
-                            p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 8192 : 2048) && (!p->causal || p->M >= 16384)));  // (T5 bias: its band steps are unpipelined here -- (8,12,2048) 170 vs 154 us,
-                                                              //  (16,12,2048) 345 vs 321, (4,12,4096) 291 vs 288, (4,12,8192) 1098 vs 1110)
+                            p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 4096 : 2048) && (!p->causal || p->M >= 16384)));  // (T5 bias, band steps in the pipelined iteration since round 4:
+                                                              //  (4,12,4096) 284-295 vs 298 us, (4,12,8192) 1089 vs 1107; (4,12,2048), 1.5 rounds: 97 vs 83 -> from 4096 keys on)
+  // Both 64-wide bodies in ONE launch (attn_bwd_fused64_kernel; the dK/dV half forms its row statistics itself): one workgroup per CU
+  // either way, so the two grids fill each other's empty last rounds -- and at cfg2 (96 + 96 workgroups) run side by side.
+  const int f64_env = vsel(p->variant, FAT5_V_FUSED64_ON, FAT5_V_FUSED64_OFF);
+  L.fused64 = false;
+  if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
+      smem_bwd_fused64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024) {
+    // Measured, backward incl. the reduction launch, fused 64-wide against the library's previous choice (tools/attn_time.py, us):
+    //   (4,12,512) T5 bias 30.4 vs 35.6, none 19.5 vs 23.2; (4,12,1024) 72.2 vs 76.9, 56.5 vs 60.0; (8,12,512) 49.2 vs 53.3, 35.4 vs 37.1;
+    //   (2,12,512) 29.3 vs 40.8; (2,12,1024) 43.7 vs 51.8; (2,12,2048) 118.8 vs 128.6, 100.8 vs 111.2   -> up to 1.5 rounds of the chip;
+    //   (4,12,2048): 3 rounds, 194.6 vs 196.4 -- even: the last round is still two workgroup lengths long;
+    //   causal (4,12,512) 39.0 vs 33.7, (4,12,1024) 83.6 vs 61.7: the diagonal steps of the 64-wide bodies are unpipelined -> never.
+    const long wq = bh * ((p->M + 255) / 256), tot = wg256 + wq;
+    // (a call that forces or forbids one of the 64-wide bodies / launch forms keeps that choice)
+    const bool rule = !p->causal && tot <= 384 && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    L.fused64 = f64_env == 1 || rule;
+  }
+  if (L.fused64) {
+    L.kv64 = L.q64 = true;
+    L.kv64_half = false;
+    L.kv64_mix_pf = -1;
+    L.nw_kv = 4;
+    L.n_nblk = (p->N + 255) / 256;
+  }
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;
@@ -377,7 +401,7 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  return bwd_fusable(L, grid_q, grid_kv, p->D, p->variant) ? 1 : 2;
+  return (bwd_fusable(L, grid_q, grid_kv, p->D, p->variant) || L.fused64) ? 1 : 2;
 }
 
 // Which kernel bodies a problem runs, as text (tests pin the dispatch rules with it; no device needed, no pointer of `p` is followed)
@@ -395,7 +419,7 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
   snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.ksplit ? "64row-ksplit" : "64row") : (fc.nw == -4 ? "32row-split" : "32row"),
-           L.q64 ? "64row" : "32row", kv, fused ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
+           L.q64 ? "64row" : "32row", kv, (fused || L.fused64) ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
   return FAT5_OK;
 }
 
@@ -498,6 +522,13 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
     hipError_t e = fn(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused launch");
+  } else if (L.fused64 && (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV)) {
+    // (a call for one stage only runs the same two bodies as separate launches, the row statistics through the workspace)
+    a.n_kv_blocks = (int)grid_kv;
+    a.part_stride = a.n_nblk;
+    a.stat2 = nullptr;
+    hipError_t e = launch_bwd_fused64_d64(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
+    if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused64 launch");
   } else {
     // 1) dQ (+ delta)
     if (stages & FAT5_BWD_DQ) {

@@ -255,3 +255,46 @@ def test_bwd64_mixed_launch_matches_the_256_key_launch(B, H, M, N, causal, mode)
     ref = oracle_all(q, k, v, pe.compute_bias(table, M, N).to(torch.bfloat16) if mode == "rpe" else None, do, 0.125, causal)
     for key, got in zip(("dq", "dk", "dv"), b[:3]):
         assert maxdiff(got, ref[key]) <= gbound(ref[key], torch.bfloat16), key
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,mode,md", [
+    (4, 12, 512, 512, False, "rpe", 128),     # cfg2: 96 + 96 workgroups side by side
+    (2, 3, 1024, 1024, False, "none", 128),
+    (1, 2, 2048, 2048, True, "rpe", 128),     # causal: masked (general) steps produce their statistics the same way
+    (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: the last step's rows past M (raw L reads as zero there), a key tail
+    (1, 2, 300, 2500, True, "rpe", 32),       # M << N
+    (1, 2, 2500, 300, True, "none", 128),     # M >> N: dead rows
+    (1, 2, 90, 70, False, "rpe", 128),        # fewer steps than ring slots
+    (1, 1, 40, 600, False, "rpe", 64),        # two steps only: everything from the prologue
+])
+def test_bwd64_fused_launch(B, H, M, N, causal, mode, md):
+    """attn_bwd_fused64_kernel (variant bit FAT5_V_FUSED64_ON): the 256-key dK/dV body in its self-sufficient form (row statistics
+    -L/scale, -delta formed from the step's own O / dO rows two steps ahead of their use) and the dQ body in ONE launch, against the
+    oracle and against the two-launch form of the same bodies (dq identical; dk / dv to the last bits of delta's summation order)."""
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    dtype = torch.bfloat16
+    q, k, v, _, do = make_inputs(B, H, M, N, 64, dtype, None, seed=3 * M + N, strided=True)
+    table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    kw = dict(causal=causal, sm_scale=0.125)
+    bias = None
+    if mode == "rpe":
+        kw.update(rpe1d=pe.rpe1d_from_table(table, True, 32, md), radius=md, rpe_bucket=pe.bucket_index32(md, True, 32, md, "cuda"), num_buckets=32)
+        bias = pe.compute_bias(table, M, N, True, 32, md).to(dtype)
+    outs = []
+    for bits in (_lib.V_KV64_ON | _lib.V_Q64_ON | _lib.V_KV64_HALF_OFF | _lib.V_KV64_MIX_OFF | _lib.V_FUSED64_OFF, _lib.V_FUSED64_ON):
+        plan = AttentionPlan(q, k, v, do, variant=bits, **kw)
+        assert plan.bwd_launches() == (1 if bits == _lib.V_FUSED64_ON else 2)
+        plan.forward(); plan.backward(); torch.cuda.synchronize()
+        outs.append([t.clone() for t in (plan.dq, plan.dk, plan.dv)] + ([plan.dbias.clone()] if plan.dbias is not None else []))
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:3], b[1:3]):
+        assert torch.isfinite(y.float()).all()
+        assert maxdiff(x, y) <= 2.0 ** -7 * max(1e-6, float(x.float().abs().max()))
+    if mode == "rpe":
+        assert maxdiff(a[3], b[3]) <= 1e-3 * max(1.0, float(a[3].abs().max()))
+    ref = oracle_all(q, k, v, bias, do, 0.125, causal)
+    for key, got in zip(("dq", "dk", "dv"), b[:3]):
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key

@@ -290,13 +290,16 @@ def test_dispatch_rules_are_pinned():
     rpe = dict(bias_mode=L.BIAS_RPE1D, radius=128, need_dbias=True)
     dense = dict(bias_mode=L.BIAS_DENSE, need_dbias=True)
     cases = [
-        # the three headline shapes (T5 bias): one fused backward launch at S = 512; mixed dK/dV launch at 2048; 64-wide everywhere at 8192
-        (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="32row", dkdv="32key", fused="1")),
+        # the three headline shapes (T5 bias): one launch of both 64-wide backward bodies at S = 512 (round 4); mixed dK/dV launch at 2048; 64-wide everywhere at 8192
+        (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
+        (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1")),
+        (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
+        (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(dq="32row", dkdv="32key", fused="1")),   # causal: the 32-wide bodies side by side
         (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4", fused="0")),
         (dict(B=4, H=12, M=8192, N=8192, **rpe), dict(fwd="64row", dq="64row", dkdv="64key")),
         (dict(B=4, H=12, M=8192, N=8192), dict(fwd="64row", dq="64row", dkdv="64key")),
         (dict(B=4, H=12, M=4096, N=4096), dict(fwd="64row", dq="64row", dkdv="64key")),
-        (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="32row", dkdv="64key")),            # T5 bias: the 64-row dQ body waits for 8192 keys
+        (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="64row", dkdv="64key")),            # T5 bias: band steps pipelined since round 4
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
         (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="32key")),

@@ -30,11 +30,27 @@ if a.stage != 1:
     plan.backward(a.stage); torch.cuda.synchronize()
 nwg = plan.delta_bytes // 128 if hasattr(plan, "delta_bytes") else (4 * 12 * a.S * 4) // 128   # the delta scratch holds 16 int64 per workgroup
 raw = plan.ws[: nwg * 16 * 8].view(torch.int64).cpu().numpy().reshape(-1, 16)
-raw = raw[(raw[:, 0] > 0) & (raw[:, 6] > raw[:, 0]) & (raw[:, 6] - raw[:, 0] < 10 ** 9)]
-names = ["entry", "prologue", "first scores", "loop", "drain", "partials", "stored"]
-d = np.diff(raw[:, :7].astype(np.float64), axis=1)   # (s_memtime counters of different XCDs are not synchronised: per-workgroup differences only)
-print(f"S={a.S} {a.mode} variant={a.variant} stage={a.stage}: {len(raw)} workgroups; per-workgroup phase lengths in shader-clock ticks, median (max):")
-for n_, col in zip(names[1:], d.T):
-    print(f"   -> {n_:13s} {np.median(col):8.0f} ({col.max():8.0f})")
-tot = (raw[:, 6] - raw[:, 0]).astype(np.float64)
-print(f"   workgroup duration: median {np.median(tot):.0f}  max {tot.max():.0f}")
+def show(rows, title):
+    rows = rows[(rows[:, 0] > 0) & (rows[:, 6] > rows[:, 0]) & (rows[:, 6] - rows[:, 0] < 10 ** 9)]
+    if len(rows) == 0:
+        return
+    names = ["entry", "prologue", "first scores", "loop", "drain", "partials", "stored"]
+    cols = [0, 1, 2, 3, 4, 5, 6] if rows[:, 5].min() > 0 else [0, 1, 2, 3, 4, 6]
+    d = np.diff(rows[:, cols].astype(np.float64), axis=1)   # (s_memtime counters of different XCDs are not synchronised: per-workgroup differences only)
+    print(f"{title}: {len(rows)} workgroups; per-workgroup phase lengths in shader-clock ticks, median (max):")
+    for c_, col in zip(cols[1:], d.T):
+        print(f"   -> {names[c_]:13s} {np.median(col):8.0f} ({col.max():8.0f})")
+    if rows[:, 9].min() > 0:
+        for n_, k_ in (("DMAs issued", 7), ("table filled", 8), ("landed + barrier", 9)):
+            print(f"   prologue detail: entry -> {n_:18s} {np.median(rows[:, k_] - rows[:, 0]):8.0f}")
+    tot = (rows[:, 6] - rows[:, 0]).astype(np.float64)
+    print(f"   workgroup duration: median {np.median(tot):.0f}  max {tot.max():.0f}")
+
+
+head = f"S={a.S} {a.mode} variant={a.variant} stage={a.stage}"
+if a.stage == 3 and plan.bwd_launches() == 1:
+    nkv = 4 * 12 * ((a.S + 255) // 256)
+    show(raw[:nkv], head + " fused launch, dK/dV workgroups")
+    show(raw[nkv:], head + " fused launch, dQ workgroups")
+else:
+    show(raw, head)
