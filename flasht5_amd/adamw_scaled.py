@@ -76,9 +76,13 @@ class AdamWScale(Optimizer):
         lib = _lib.load()
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         if capturing:  # (a step recorded into a HIP graph: see graph_advance)
+            # ONE captured step per optimizer: the graph bakes raw pointers to the arena's descriptor table and step scalars into its
+            # launches, and graph_advance() writes the scalars of exactly one capture -- a second capture would hand the same arena
+            # bytes out again (the first graph would then replay over another table) and leave the first graph's scalars stale
+            if getattr(self, "_graph_jobs", None):
+                raise RuntimeError("AdamWScale: this optimizer already holds a captured step; destroy that graph and call "
+                                   "release_captured_step() before capturing another one")
             self._graph_jobs, self._graph_keep = [], []
-            for a in getattr(self, "_graph_arena", {}).values():
-                a[1] = 0
         jobs = []  # one per (group, device, dtype, kahan) bucket: descriptor table on the device, launched below
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -209,15 +213,27 @@ class AdamWScale(Optimizer):
                 state["exp_avg_sq"] = torch.zeros_like(p, dtype=sd, memory_format=torch.preserve_format)
                 kah = group["kahan_sum"] and p.dtype in (torch.float16, torch.bfloat16)
                 state["kahan_comp"] = torch.zeros_like(p, memory_format=torch.preserve_format) if kah else None
-        # descriptor tables + step scalars of a captured step (see step()): one arena per device, [tensor, bytes handed out]
+        # descriptor tables + step scalars of a captured step (see step()): one arena per device, [tensor, bytes handed out].  An arena
+        # a captured graph may be reading is never replaced or resized: it is allocated once and only while no step is captured.
         if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             count = {}
             for group in self.param_groups:
                 for p in group["params"]:
                     if p.is_cuda:
                         count[p.device] = count.get(p.device, 0) + 1
-            self._graph_arena = {dev: [torch.empty((2 * n + 8 * len(self.param_groups) + 8) * 128, dtype=torch.uint8, device=dev), 0]
-                                 for dev, n in count.items()}
+            need = {dev: (2 * n + 8 * len(self.param_groups) + 8) * 128 for dev, n in count.items()}
+            have = getattr(self, "_graph_arena", None)
+            if have is None or any(dev not in have or have[dev][0].numel() < nb for dev, nb in need.items()):
+                if getattr(self, "_graph_jobs", None):
+                    raise RuntimeError("AdamWScale.init_state: parameters were added while a captured step exists; destroy that graph "
+                                       "and call release_captured_step() first")
+                self._graph_arena = {dev: [torch.empty(nb, dtype=torch.uint8, device=dev), 0] for dev, nb in need.items()}
+
+    def release_captured_step(self):
+        """Forget the captured step (the caller has destroyed every graph that holds it): its arena bytes may be handed out again."""
+        self._graph_jobs, self._graph_keep = [], []
+        for a in getattr(self, "_graph_arena", {}).values():
+            a[1] = 0
 
     def _upload(self, device, table):
         """descriptor table -> device, ASYNCHRONOUSLY: through one of eight rotating pinned staging buffers (a copy from pageable memory

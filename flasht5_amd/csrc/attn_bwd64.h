@@ -25,7 +25,7 @@
 #include "diag_sum.h"    // per-diagonal sums of dS on the VALU (DPP row rotations)
 
 #ifndef FAT5_ABL
-#define FAT5_ABL 0  // developer ablations of the dK/dV body (timing only, wrong results): 1 no diagonal ops, 2 no finish / hand-over, 4 no table reads, 8 no table fill / zeroing in the prologue, 16 no partial sums in the epilogue, 32 no far-bin MFMAs
+#define FAT5_ABL 0  // developer ablations of the dK/dV body (timing only, wrong results): 1 no diagonal ops, 2 no finish / hand-over, 4 no table reads, 8 no table fill / zeroing in the prologue, 16 no partial sums in the epilogue, 32 no far-bin MFMAs, 64 SELF: no statistics production in the pipelined iteration, 128 SELF: counted vmcnt (step j+1 landed) instead of vmcnt(0)
 #endif
 
 #ifndef FAT5_TRACE
@@ -306,7 +306,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   auto produce_stats = [&](const int j, const uint32_t so) { stats_write(stats_value(stats_read(so), j), so); };
   // E(j): step j+1 (SELF: j+2) has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
   auto sync_step = [&](int j, uint32_t slot3_off) {
-    if (!SELF && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER + 1) : "memory");
+    if ((!SELF || (FAT5_ABL & 128)) && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SELF ? 3 : 2) * Dma::PER + 1) : "memory");
     else wait_dma_all();
     __syncthreads();
     if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
@@ -592,9 +592,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap)
       // (SELF: the statistics of step j+2, which has landed behind E(j) and is read two iterations from now: reads, arithmetic and the
       //  store in gaps of their own)
-      if constexpr (SELF && g == 13) sin_ = stats_read(((SL + 2) & 3) * SLOT);
-      if constexpr (SELF && g == 23) sval_ = stats_value(sin_, j + 2);
-      if constexpr (SELF && g == 27) stats_write(sval_, ((SL + 2) & 3) * SLOT);
+      if constexpr (SELF && g == 13 && !(FAT5_ABL & 64)) sin_ = stats_read(((SL + 2) & 3) * SLOT);
+      if constexpr (SELF && g == 23 && !(FAT5_ABL & 64)) sval_ = stats_value(sin_, j + 2);
+      if constexpr (SELF && g == 27 && !(FAT5_ABL & 64)) stats_write(sval_, ((SL + 2) & 3) * SLOT);
       if constexpr (g == 19) asm volatile("" ::"v"(NL));  // (keeps NL's registers out of reach of the VALU ops of gaps 16..18)
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
       // ---- barrier + DMA ----

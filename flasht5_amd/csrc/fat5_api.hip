@@ -515,7 +515,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const long grid_q = n_units(p) * a.n_mblk, grid_kv = n_units(p) * a.n_nblk;
   const long full_q = bh * a.n_mblk, full_kv = bh * a.n_nblk;  // (variant choice: see fat5_attn_fwd)
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
-  // side by side (attn_bwd_fused_kernel).  FAT5_BWD_FUSE=0 disables (developer A/B).
+  // side by side (attn_bwd_fused_kernel).  fat5_attn_params.variant & FAT5_V_NO_FUSE forbids it (tests / profiling: _lib.variant()).
   const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, p->D, p->variant);
   if (fuse) {
     a.n_kv_blocks = (int)grid_kv;

@@ -335,7 +335,14 @@ class GraphedTrainStep:
     Gradients stay allocated between steps (the graph owns them): `p.grad` holds the last step's unclipped gradients.
 
     Data parallel (`group` with more than one rank; `split=True` forces this form): two graphs -- forward + backward, then the
-    optimizer step -- with the flat gradient all-reduce (RCCL, `allreduce_gradients`) between them, outside any graph."""
+    optimizer step -- with the flat gradient all-reduce (RCCL, `allreduce_gradients`) between them, outside any graph.
+
+    What a captured step fixes (checked before every replay where it can be): `betas` and `eps` of every parameter group are launch
+    arguments of the captured kernels -- changing them afterwards raises; the gradient tensors belong to the graph -- a
+    `zero_grad(set_to_none=True)` / re-assignment of `p.grad` between replays raises (the graph would keep writing the old buffers
+    while `allreduce_gradients` skipped the parameter); clipping happens only if the optimizer was built with `max_grad_norm`
+    (the eager warm-up steps behave the same: `train_step(..., max_grad_norm=None)`); one captured step per optimizer
+    (`AdamWScale.release_captured_step()` after destroying this object to capture again)."""
 
     def __init__(self, model, optimizer, group=None, warmup=2, split=None):
         from .adamw_scaled import AdamWScale
@@ -372,6 +379,19 @@ class GraphedTrainStep:
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self.optimizer.step()
             self.graphs.append(g2)
+        # what the capture baked in (see the class docstring)
+        self._baked = [(tuple(g["betas"]), float(g["eps"])) for g in self.optimizer.param_groups]
+        self._grads = [(p, p.grad) for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+
+    def _check_baked(self):
+        for g, (betas, eps) in zip(self.optimizer.param_groups, self._baked):
+            if tuple(g["betas"]) != betas or float(g["eps"]) != eps:
+                raise RuntimeError("GraphedTrainStep: betas / eps are launch arguments of the captured optimizer step and cannot change "
+                                   "after capture (lr and weight_decay can: they travel through device memory)")
+        for p, gr in self._grads:
+            if p.grad is not gr:
+                raise RuntimeError("GraphedTrainStep: p.grad was reset or replaced between replays; the captured graph owns the gradient "
+                                   "tensors (use zero_grad(set_to_none=False) if they have to be cleared)")
 
     def __call__(self, input_ids, labels):
         self.calls += 1
@@ -384,6 +404,7 @@ class GraphedTrainStep:
                 raise ValueError(f"GraphedTrainStep was captured for batches {tuple(self.ids.shape)} / {tuple(self.labels.shape)}")
             self.ids.copy_(input_ids, non_blocking=True)
             self.labels.copy_(labels, non_blocking=True)
+        self._check_baked()
         self.optimizer.graph_advance()
         self.graphs[0].replay()
         if self.split:

@@ -195,3 +195,43 @@ def test_rpe_table_forward_sees_fused_optimizer_updates(path):
     assert (ta.detach() - t0.cuda()).abs().max().item() > 0.2
     assert (o1.detach().float() - first.float()).abs().max().item() > 0.02
     assert (ta.detach() - tb.detach()).abs().max().item() <= 0.05 * max(1.0, tb.detach().abs().max().item())
+
+
+def test_captured_step_keeps_its_arena_and_refuses_a_second_capture():
+    """a captured step bakes raw pointers to the optimizer's arena (descriptor table, step scalars) into its launches.
+    init_state() must not replace that arena, a second capture must not hand the same bytes out again (and graph_advance() feeds
+    one capture only): refused until release_captured_step()."""
+    from flasht5_amd.adamw_scaled import AdamWScale
+    p = torch.nn.Parameter(torch.randn(4096, device="cuda", dtype=torch.bfloat16))
+    opt = AdamWScale([p], lr=1e-2)
+    p.grad = torch.randn_like(p)
+    opt.step()
+    opt.init_state()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        opt.step()
+    arena = opt._graph_arena[p.device][0]
+    opt.init_state()
+    assert opt._graph_arena[p.device][0] is arena
+    before = p.detach().clone()
+    opt.graph_advance()
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(before, p.detach())
+    with pytest.raises(RuntimeError, match="already holds a captured step"):
+        _capture_again(opt)
+    opt.release_captured_step()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        opt.step()
+    opt.graph_advance()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(p.detach().float()).all()
+
+
+def _capture_again(opt):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        opt.step()
