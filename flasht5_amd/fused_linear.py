@@ -10,11 +10,19 @@ way through LDS and whose epilogue applies them / adds the residual).
         reference: `hidden_states + self.o(...)` / `hidden_states + self.wo(...)` (:316, :162-163), rounded twice like the two ops.
 
 Both differentiable in every tensor argument.  The backward GEMMs are library GEMMs (torch.matmul -> hipBLASLt)."""
+from typing import List, Optional, Tuple
+
 import torch
 
 from . import _lib
 
 __all__ = ["rmsnorm_linear", "linear_residual", "fold_weights", "RMSNormLinear", "LinearResidual", "fused_linear_supported"]
+
+
+def _python_path(t):
+    """the Python autograd functions (custom ops with fakes) instead of the C++ ones: under torch.compile and for FakeTensors"""
+    from torch._subclasses.fake_tensor import FakeTensor
+    return torch.compiler.is_compiling() or isinstance(t, FakeTensor)
 
 
 def fused_linear_supported(x, weight):
@@ -28,25 +36,46 @@ def _rows(t):
     return t2 if (t2.stride(-1) == 1 and t2.data_ptr() % 16 == 0 and t2.stride(0) % 8 == 0) else t2.contiguous()
 
 
-def _launch(a, w, res, norm, eps, want_rstd):
+# The four kernels below are registered as `fat5::` custom ops with fake (shape-only) implementations, like every other kernel of
+# the library (the reference registers each of its kernels with a fake, flash_attention_v2_bias.py:83-89, :219-226): the Python
+# autograd functions of this file trace under FakeTensor / torch.compile (tests/test_fused_linear_gpu.py::test_fused_block_traces).
+@torch.library.custom_op("fat5::linear_fused", mutates_args=(), device_types="cuda")
+def linear_fused_op(a: torch.Tensor, w: torch.Tensor, res: Optional[torch.Tensor], norm: bool, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """out = [rstd(a) *] a w^T [+ res]; (out, rstd) -- rstd (M,) fp32 when `norm`, else an empty tensor.  a (M, K), w (N, K) rows."""
+    a, w = _rows(a), _wrows(w)
+    res = _rows(res) if res is not None else None
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    rstd = torch.empty((M,), dtype=torch.float32, device=a.device) if want_rstd else None
+    rstd = torch.empty((M if norm else 0,), dtype=torch.float32, device=a.device)
     if M == 0:
         return out, rstd
     with _lib.on_device(a.device):
         _lib.check(_lib.load().fat5_linear_fused(
             a.data_ptr(), w.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
-            rstd.data_ptr() if rstd is not None else None, M, N, K, a.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
+            rstd.data_ptr() if norm else None, M, N, K, a.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
             out.stride(0), int(bool(norm)), float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device)), "fat5_linear_fused")
     return out, rstd
 
 
-def fold_weights(weights, norm_weight):
-    """[w0; w1; ...] (up to three (n_i, K) weights stacked along n) times diag(norm_weight), ONE launch (fat5_fold_weights):
-    the projection weight `rmsnorm_linear`'s kernel takes.  norm_weight None: the plain stack."""
-    ws = [w if (w.stride(-1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 8 == 0) else w.contiguous() for w in weights]
+@torch.library.register_fake("fat5::linear_fused")
+def _linear_fused_fake(a, w, res, norm, eps):
+    return (torch.empty((a.shape[0], w.shape[0]), dtype=a.dtype, device=a.device),
+            torch.empty((a.shape[0] if norm else 0,), dtype=torch.float32, device=a.device))
+
+
+def _launch(a, w, res, norm, eps, want_rstd):
+    out, rstd = linear_fused_op(a, w, res, bool(norm), float(eps))
+    return out, (rstd if want_rstd else None)
+
+
+def _wrows(w):
+    return w if (w.stride(-1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 8 == 0) else w.contiguous()
+
+
+@torch.library.custom_op("fat5::fold_weights", mutates_args=(), device_types="cuda")
+def fold_weights_op(weights: List[torch.Tensor], norm_weight: Optional[torch.Tensor]) -> torch.Tensor:
+    ws = [_wrows(w) for w in weights]
     assert 1 <= len(ws) <= 3
     K = ws[0].shape[1]
     out = torch.empty((sum(w.shape[0] for w in ws), K), dtype=ws[0].dtype, device=ws[0].device)
@@ -61,6 +90,69 @@ def fold_weights(weights, norm_weight):
     return out
 
 
+@torch.library.register_fake("fat5::fold_weights")
+def _fold_weights_fake(weights, norm_weight):
+    return torch.empty((sum(w.shape[0] for w in weights), weights[0].shape[1]), dtype=weights[0].dtype, device=weights[0].device)
+
+
+def fold_weights(weights, norm_weight):
+    """[w0; w1; ...] (up to three (n_i, K) weights stacked along n) times diag(norm_weight), ONE launch (fat5_fold_weights):
+    the projection weight `rmsnorm_linear`'s kernel takes.  norm_weight None: the plain stack."""
+    return fold_weights_op(list(weights), norm_weight)
+
+
+@torch.library.custom_op("fat5::rmsnorm_unit_bwd", mutates_args=(), device_types="cuda")
+def rmsnorm_unit_bwd_op(gy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, dres: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dx, xhat): the gradient of x -> x * rstd given dL/dxhat = gy (+ the residual path's gradient `dres`, fp32 sum, one
+    rounding) and xhat = x * rstd itself, in one pass (fat5_rmsnorm_unit_bwd)."""
+    gy, x = _rows(gy), _rows(x)
+    dres = _rows(dres) if dres is not None else None
+    M, K = x.shape
+    dx = torch.empty((M, K), dtype=x.dtype, device=x.device)
+    xhat = torch.empty((M, K), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return dx, xhat
+    with _lib.on_device(x.device):
+        _lib.check(_lib.load().fat5_rmsnorm_unit_bwd(gy.data_ptr(), x.data_ptr(), rstd.data_ptr(), dx.data_ptr(), xhat.data_ptr(), M, K,
+                                                     gy.stride(0), x.stride(0), K, K, dres.data_ptr() if dres is not None else None,
+                                                     dres.stride(0) if dres is not None else 0, _lib.dtype_code(x.dtype),
+                                                     _lib.stream_ptr(x.device)), "fat5_rmsnorm_unit_bwd")
+    return dx, xhat
+
+
+@torch.library.register_fake("fat5::rmsnorm_unit_bwd")
+def _rmsnorm_unit_bwd_fake(gy, x, rstd, dres):
+    return torch.empty(x.shape, dtype=x.dtype, device=x.device), torch.empty(x.shape, dtype=x.dtype, device=x.device)
+
+
+@torch.library.custom_op("fat5::fold_weights_bwd", mutates_args=(), device_types="cuda")
+def fold_weights_bwd_op(dwg: torch.Tensor, weights: List[torch.Tensor], g: torch.Tensor) -> List[torch.Tensor]:
+    """[dW_0, .., dg]: dW_i = dWg_i diag(g), dg = sum_n dWg W (column sums over the stacked rows), one launch + the in-order slab sum."""
+    lib = _lib.load()
+    dwg = _rows(dwg)
+    K = dwg.shape[1]
+    ws = [_wrows(w) for w in weights]
+    gq = g.to(dwg.dtype).contiguous()
+    dWs = [torch.empty((w.shape[0], K), dtype=dwg.dtype, device=dwg.device) for w in ws]
+    dgq = torch.empty((K,), dtype=dwg.dtype, device=dwg.device)
+    ptr = [w.data_ptr() for w in ws] + [None] * (3 - len(ws))
+    n = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
+    ld = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
+    dptr = [t.data_ptr() for t in dWs] + [None] * (3 - len(ws))
+    scratch = torch.empty((max(int(lib.fat5_fold_weights_bwd_scratch_bytes(sum(n), K)), 4) // 4,), dtype=torch.float32, device=dwg.device)
+    with _lib.on_device(dwg.device):
+        _lib.check(lib.fat5_fold_weights_bwd(dwg.data_ptr(), ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2],
+                                             gq.data_ptr(), dptr[0], dptr[1], dptr[2], dgq.data_ptr(), K, _lib.dtype_code(dwg.dtype),
+                                             scratch.data_ptr(), scratch.numel() * 4, _lib.stream_ptr(dwg.device)), "fat5_fold_weights_bwd")
+    return dWs + [dgq]
+
+
+@torch.library.register_fake("fat5::fold_weights_bwd")
+def _fold_weights_bwd_fake(dwg, weights, g):
+    K = dwg.shape[1]
+    return [torch.empty((w.shape[0], K), dtype=dwg.dtype, device=dwg.device) for w in weights] + [torch.empty((K,), dtype=dwg.dtype, device=dwg.device)]
+
+
 class RMSNormLinear(torch.autograd.Function):
     """`weights`: one to three (n_i, K) projection weights applied to the SAME normalised input (Wq, Wk, Wv / wi_0, wi_1): the
     outputs come back concatenated along the last dim, the gradients per weight.
@@ -73,7 +165,7 @@ class RMSNormLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, norm_weight, eps, with_residual, *weights):
         shape = x.shape
-        x2 = _rows(x)
+        x2 = x.reshape(-1, shape[-1])
         # the norm weight rides in the projection: (x rstd g) W^T = rstd (x (W diag g)^T)
         wg = fold_weights(weights, norm_weight)
         out, rstd = _launch(x2, wg, None, True, eps, True)
@@ -94,39 +186,19 @@ class RMSNormLinear(torch.autograd.Function):
         if dout is None:  # only the residual alias was used
             return (dres, None, None, None, *([None] * len(weights)))
         if dres is not None:
-            dres = _rows(dres if dres.dtype == x2.dtype else dres.to(x2.dtype))
-        d2 = _rows(dout)
+            dres = (dres if dres.dtype == x2.dtype else dres.to(x2.dtype)).reshape(-1, dres.shape[-1])
+        d2 = dout.reshape(-1, dout.shape[-1])
         if d2.dtype != x2.dtype:
             d2 = d2.to(x2.dtype)
-        lib = _lib.load()
-        M, K = x2.shape
         gy = d2 @ wg                                                     # dL/dxhat: (M, K)
-        dx = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-        xhat = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-        with _lib.on_device(x2.device):
-            _lib.check(lib.fat5_rmsnorm_unit_bwd(gy.data_ptr(), x2.data_ptr(), rstd.data_ptr(), dx.data_ptr(), xhat.data_ptr(), M, K,
-                                                 gy.stride(0), x2.stride(0), K, K, dres.data_ptr() if dres is not None else None,
-                                                 dres.stride(0) if dres is not None else 0, _lib.dtype_code(x2.dtype),
-                                                 _lib.stream_ptr(x2.device)), "fat5_rmsnorm_unit_bwd")
+        dx, xhat = rmsnorm_unit_bwd_op(gy, x2, rstd, dres)
         dg = None
         dWs = [None] * len(weights)
         if ctx.needs_input_grad[1] or any(ctx.needs_input_grad[4:]):
             dwg = d2.t() @ xhat                                          # gradient of the folded weight [W_i] diag(g): (N, K)
-            ws = [w if (w.stride(-1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0) else w.contiguous() for w in weights]
-            gq = g.to(x2.dtype).contiguous()
-            dWs = [torch.empty((w.shape[0], K), dtype=x2.dtype, device=x2.device) for w in ws]
-            dgq = torch.empty((K,), dtype=x2.dtype, device=x2.device)
-            ptr = [w.data_ptr() for w in ws] + [None] * (3 - len(ws))
-            n = [w.shape[0] for w in ws] + [0] * (3 - len(ws))
-            ld = [w.stride(0) for w in ws] + [0] * (3 - len(ws))
-            dptr = [t.data_ptr() for t in dWs] + [None] * (3 - len(ws))
-            scratch = torch.empty((max(int(lib.fat5_fold_weights_bwd_scratch_bytes(sum(n), K)), 4) // 4,), dtype=torch.float32, device=x2.device)
-            with _lib.on_device(x2.device):
-                _lib.check(lib.fat5_fold_weights_bwd(dwg.data_ptr(), ptr[0], ptr[1], ptr[2], n[0], n[1], n[2], ld[0], ld[1], ld[2],
-                                                     gq.data_ptr(), dptr[0], dptr[1], dptr[2], dgq.data_ptr(), K, _lib.dtype_code(x2.dtype),
-                                                     scratch.data_ptr(), scratch.numel() * 4, _lib.stream_ptr(x2.device)), "fat5_fold_weights_bwd")
+            *dWq, dgq = fold_weights_bwd_op(dwg, list(weights), g)
             dg = dgq.to(g.dtype) if ctx.needs_input_grad[1] else None
-            dWs = [(t.to(w.dtype) if ctx.needs_input_grad[4 + i] else None) for i, (t, w) in enumerate(zip(dWs, weights))]
+            dWs = [(t.to(w.dtype) if ctx.needs_input_grad[4 + i] else None) for i, (t, w) in enumerate(zip(dWq, weights))]
         return (dx.reshape(ctx.shape) if ctx.needs_input_grad[0] else None, dg, None, None, *dWs)
 
 
@@ -134,8 +206,8 @@ class LinearResidual(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, weight, residual):
         shape = residual.shape
-        a2, r2 = _rows(a), _rows(residual)
-        out, _ = _launch(a2, _rows(weight), r2, False, 0.0, False)
+        a2, r2 = a.reshape(-1, a.shape[-1]), residual.reshape(-1, shape[-1])
+        out, _ = _launch(a2, weight, r2, False, 0.0, False)
         ctx.save_for_backward(a2, weight)
         ctx.ashape = a.shape
         return out.reshape(shape)
@@ -165,7 +237,7 @@ def rmsnorm_linear(x, norm_weight, weight, eps=1e-6, return_residual=False):
         y = fast_rms_layernorm(x, norm_weight, eps)
         out = torch.cat([torch.nn.functional.linear(y, w) for w in weights], -1) if len(weights) > 1 else torch.nn.functional.linear(y, weights[0])
         return (out, x) if return_residual else out
-    nat = None if torch.compiler.is_compiling() else _lib.native()
+    nat = None if _python_path(x) else _lib.native()
     if nat is not None:  # (C++ autograd function: same host logic, a fraction of the per-call cost -- above all in the backward)
         r = nat.rmsnorm_linear_apply(x, norm_weight, float(eps), bool(return_residual), list(weights))
         return (r[0], r[1]) if return_residual else r[0]
@@ -178,7 +250,7 @@ def linear_residual(a, weight, residual):
         raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
     if not fused_linear_supported(a, weight) or residual.dtype != a.dtype or residual.shape[-1] != weight.shape[0]:
         return residual + torch.nn.functional.linear(a, weight)
-    nat = None if torch.compiler.is_compiling() else _lib.native()
+    nat = None if _python_path(a) else _lib.native()
     if nat is not None:
         return nat.linear_residual_apply(a, weight, residual)
     return LinearResidual.apply(a, weight, residual)
