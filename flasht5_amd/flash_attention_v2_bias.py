@@ -748,6 +748,12 @@ class AttentionPlan:
         _lib.check(self.lib.fat5_attn_fwd(ctypes.byref(self.p), _lib.stream_ptr(self.device)), "fat5_attn_fwd")
         return self.o
 
+    def describe(self):
+        """the kernel bodies this plan's calls run, e.g. {"fwd": "64row-ksplit", "dq": "64row", "dkdv": "64key", "fused": "1", ...} (fat5_attn_describe)"""
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(self.lib.fat5_attn_describe(ctypes.byref(self.p), buf, 256), "fat5_attn_describe")
+        return dict(kv.split("=") for kv in buf.value.decode().split())
+
     def bwd_launches(self):
         """1: dQ and dK/dV halves share one launch (short sequences); 2: two kernels (fat5_attn_bwd_launches)."""
         return int(self.lib.fat5_attn_bwd_launches(ctypes.byref(self.p)))

@@ -456,6 +456,47 @@ def gen_gated_act():
     save("gated_act", **out)
 
 
+def gen_norm_linear():
+    """The reference's own `normed = layer_norm(hidden)` -> Wq / Wk / Wv sequence (FlashT5LayerNorm eager branch followed by three
+    bias-free nn.Linear, modeling_flash_t5.py:95-112, :226-231, :304-318) and `hidden + o(attn)` (:316), fp32 and bf16, with
+    autograd's gradients: pins oracle/fused_linear.py as a unit (parity iii)."""
+    out = {}
+    for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        torch.manual_seed(77)
+        rows, K, n = 24, 128, 64
+        ln = FlashT5LayerNorm(K, eps=1e-6, use_triton_layernorm=False).to(dt)
+        with torch.no_grad():
+            ln.weight.copy_((1.0 + 0.1 * torch.randn(K)).to(dt))
+        lins = [torch.nn.Linear(K, n, bias=False).to(dt) for _ in range(3)]
+        wo = torch.nn.Linear(n, K, bias=False).to(dt)
+        x = torch.randn(rows, K).to(dt).requires_grad_()
+        normed = ln(x).type_as(x)
+        qkv = torch.cat([l(normed) for l in lins], -1)
+        dqkv = torch.randn(qkv.shape).to(dt)
+        qkv.backward(dqkv)
+        a = torch.randn(rows, n).to(dt).requires_grad_()
+        res = torch.randn(rows, K).to(dt).requires_grad_()
+        y = res + wo(a)
+        dy = torch.randn(y.shape).to(dt)
+        y.backward(dy)
+        W = torch.cat([l.weight for l in lins], 0).detach()
+        ref_o, _ = oracle.rmsnorm_linear_oracle(x.detach(), ln.weight.detach(), W, 1e-6)
+        ref_r = oracle.rmsnorm_linear_reference_rounding(x.detach(), ln.weight.detach(), W, 1e-6)
+        print(f"norm_linear {tag}: |oracle - reference| = {maxdiff(ref_o, qkv.detach()):.3e}, with the reference's rounding {maxdiff(ref_r, qkv.detach()):.3e};"
+              f" residual {maxdiff(oracle.linear_residual_oracle(a.detach(), wo.weight.detach(), res.detach()), y.detach()):.3e}")
+        if dt == torch.float32:
+            assert maxdiff(ref_o, qkv.detach()) < 1e-4 and maxdiff(oracle.linear_residual_oracle(a.detach(), wo.weight.detach(), res.detach()), y.detach()) < 1e-5
+        else:
+            assert maxdiff(ref_r, qkv.detach()) <= 2.0 ** -7 * float(qkv.detach().float().abs().max())  # (one output rounding)
+        k = tag + "_"
+        f = lambda t: t.detach().float().numpy()   # (bf16 values are exact in fp32)
+        out.update({k + "x": f(x), k + "g": f(ln.weight), k + "W": f(W), k + "qkv": f(qkv), k + "dqkv": f(dqkv), k + "dx": f(x.grad),
+                    k + "dg": f(ln.weight.grad), k + "dW": f(torch.cat([l.weight.grad for l in lins], 0)),
+                    k + "a": f(a), k + "wo": f(wo.weight), k + "res": f(res), k + "y": f(y), k + "dy": f(dy), k + "da": f(a.grad),
+                    k + "dwo": f(wo.weight.grad), k + "dres": f(res.grad)})
+    save("norm_linear", **out)
+
+
 def main():
     torch.set_num_threads(8)
     only = set(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else None
@@ -469,6 +510,8 @@ def main():
             gen_triton_round3()
         if "gated" in only:
             gen_gated_act()
+        if "normlin" in only:
+            gen_norm_linear()
         return
     gen_rpe()
     f32, f16, bf16 = torch.float32, torch.float16, torch.bfloat16
@@ -494,6 +537,7 @@ def main():
     gen_ce()
     gen_adamw()
     gen_gated_act()
+    gen_norm_linear()
 
 
 if __name__ == "__main__":

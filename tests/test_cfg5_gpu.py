@@ -216,3 +216,31 @@ def test_graphed_train_step_argument_checks():
     step(ids, labels)
     with pytest.raises(ValueError):
         step(ids[:, :64], labels)
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_cfg5_two_layer_model_every_parameter(fuse):
+    """VERDICT r3 (parity iv): the full-depth test accepts 8e-2 of the largest entry on six tensors -- loose enough to hide a wrong
+    layer.  A 2 + 2 layer model (everything else FAT5-base) against the fp32 twin, EVERY parameter's gradient at 2e-2 of its largest
+    entry; with the separate operators and with the fused projections (fuse_norm_linear)."""
+    from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
+    cfg = FAT5Config(num_layers=2, num_decoder_layers=2)
+    cfg.fuse_norm_linear = fuse
+    B, S, T = 2, 512, 256
+    torch.manual_seed(11)
+    model = FAT5ForConditionalGeneration(cfg).cuda().bfloat16()
+    g = torch.Generator().manual_seed(6)
+    input_ids = torch.randint(0, cfg.vocab_size, (B, S), generator=g).cuda()
+    labels = torch.randint(0, cfg.vocab_size, (B, T), generator=g)
+    labels[1, -19:] = -100
+    labels = labels.cuda()
+    loss = model(input_ids, labels)
+    loss.backward()
+    sd = {n: p.detach().float().requires_grad_() for n, p in model.named_parameters()}
+    rloss = _twin_loss(sd, cfg, input_ids, labels, model._shift_right(labels))
+    names = [n for n, _ in model.named_parameters()]
+    rgrads = dict(zip(names, torch.autograd.grad(rloss, [sd[n] for n in names])))
+    assert abs(loss.item() - rloss.item()) <= 5e-3 * abs(rloss.item()), (loss.item(), rloss.item())
+    got = dict(model.named_parameters())
+    worst = max(((maxdiff(got[n].grad, rgrads[n]) / (rgrads[n].abs().max().item() + 1e-12), n) for n in names))
+    assert worst[0] <= 2e-2, worst

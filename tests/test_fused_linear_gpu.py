@@ -291,3 +291,23 @@ def test_fused_block_traces_under_fake_tensors():
         fx = torch.empty(4, 64, 256, device=dev, dtype=dt)
         out = rmsnorm_linear(fx, torch.empty(256, device=dev, dtype=dt), torch.empty(512, 256, device=dev, dtype=dt), 1e-6)
         assert out.shape == (4, 64, 512)
+
+
+def test_fused_projections_match_the_reference_fixture():
+    """fat5_linear_fused against tests/golden/norm_linear.npz -- the reference's own FlashT5LayerNorm -> three nn.Linear and
+    `hidden + o(attn)` in bf16 with autograd's gradients: forward within the reference's two intermediate roundings + ours,
+    gradients within 2e-2 of their largest entry (bf16 operands in every gradient GEMM)."""
+    from golden_io import load
+    from flasht5_amd import rmsnorm_linear, linear_residual
+    z = load("norm_linear")
+    g = {k[5:]: torch.from_numpy(z[k]) for k in z if k.startswith("bf16_")}
+    x, gw, W = (g[k].cuda().bfloat16().requires_grad_() for k in ("x", "g", "W"))
+    out = rmsnorm_linear(x, gw, tuple(W.split(W.shape[0] // 3, 0)), 1e-6)
+    dx, dg, dW = torch.autograd.grad(out, (x, gw, W), g["dqkv"].cuda().bfloat16())
+    a, wo, res = (g[k].cuda().bfloat16().requires_grad_() for k in ("a", "wo", "res"))
+    y = linear_residual(a, wo, res)
+    da, dwo, dres = torch.autograd.grad(y, (a, wo, res), g["dy"].cuda().bfloat16())
+    for got, key, rel in ((out, "qkv", 3 * 2.0 ** -8), (y, "y", 3 * 2.0 ** -8), (dx, "dx", 2e-2), (dg, "dg", 2e-2), (dW, "dW", 2e-2),
+                          (da, "da", 2e-2), (dwo, "dwo", 2e-2), (dres, "dres", 2.0 ** -8)):
+        ref = g[key].cuda()
+        assert (got.float() - ref).abs().max().item() <= rel * max(1.0, ref.abs().max().item()), key

@@ -222,3 +222,26 @@ def test_gated_act_golden(act, tag):
         x = torch.linspace(-12, 12, 4001, dtype=torch.float64)
         a = oracle.gated_act_oracle(x, torch.ones_like(x), act)
         assert float((a - torch.nn.functional.gelu(x, approximate="tanh")).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_norm_linear_golden(tag):
+    """oracle/fused_linear.py as a unit against the reference's own `layer_norm -> Wq / Wk / Wv` and `hidden + o(attn)` sequences
+    (fixture: tests/golden/make_golden.py::gen_norm_linear: FlashT5LayerNorm + nn.Linear modules, gradients by autograd).
+    fp32: the restatement and its autograd gradients to fp32 rounding; bf16: within the reference's own intermediate roundings
+    (normed activation, GEMM output: the oracle keeps fp32 in between, which is what the GPU comparison's tolerance covers)."""
+    z = load("norm_linear")
+    g = {k[len(tag) + 1:]: torch.from_numpy(z[k]) for k in z if k.startswith(tag + "_")}
+    x, gw, W = (g[k].clone().requires_grad_() for k in ("x", "g", "W"))
+    out, _ = oracle.rmsnorm_linear_oracle(x, gw, W, 1e-6)
+    dx, dg, dW = torch.autograd.grad(out, (x, gw, W), g["dqkv"])
+    a, wo, res = (g[k].clone().requires_grad_() for k in ("a", "wo", "res"))
+    y = oracle.linear_residual_oracle(a, wo, res)
+    da, dwo, dres = torch.autograd.grad(y, (a, wo, res), g["dy"])
+    rel = 2e-5 if tag == "fp32" else 3.0 * 2.0 ** -8   # bf16: normed rounded, GEMM output rounded (+ the gradient GEMMs' operands)
+    for got, key in ((out, "qkv"), (dx, "dx"), (dg, "dg"), (dW, "dW"), (y, "y"), (da, "da"), (dwo, "dwo"), (dres, "dres")):
+        ref = g[key]
+        assert (got - ref).abs().max().item() <= rel * max(1.0, ref.abs().max().item()), key
+    if tag == "bf16":  # with the reference's intermediate rounding restated: one output rounding
+        r2 = oracle.rmsnorm_linear_reference_rounding(g["x"].bfloat16(), g["g"].bfloat16(), g["W"].bfloat16(), 1e-6)
+        assert (r2 - g["qkv"]).abs().max().item() <= 2.0 ** -7 * g["qkv"].abs().max().item()

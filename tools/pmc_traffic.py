@@ -5,7 +5,7 @@ coalesced reads; WRITE_SIZE is taken as reported (uncalibrated).  Both counters 
 Writes gpurun_out/pmc_traffic.json: {"<kernel>:S<seq>:<mode>": {"fetch_bytes":…, "write_bytes":…, "bytes":…}}"""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"attn_fwd_kernel": "attn_fwd", "attn_fwd64_kernel": "attn_fwd", "attn_fwd_split_kernel": "attn_fwd", "attn_bwd_fused_kernel": "attn_bwd_fused", "attn_bwd_q_kernel": "attn_bwd_dq",
+NAMES = {"attn_fwd_kernel": "attn_fwd", "attn_fwd64_kernel": "attn_fwd", "attn_fwd_split_kernel": "attn_fwd", "attn_bwd_fused_kernel": "attn_bwd_fused", "attn_bwd_fused64_kernel": "attn_bwd_fused", "attn_bwd_kv64_mixed_kernel": "attn_bwd_dkdv", "attn_bwd_q_kernel": "attn_bwd_dq",
          "attn_bwd_kv_kernel": "attn_bwd_dkdv", "attn_bwd_kv64_kernel": "attn_bwd_dkdv", "attn_bwd_q64_kernel": "attn_bwd_dq", "drpe_reduce_kernel": "bias_grad_reduce", "attn_bwd_dbias_kernel": "attn_bwd_dbias", "dbias_reduce_kernel": "dbias_reduce"}
 out = {}
 for S, mode in ((512, "rpe"), (2048, "rpe"), (8192, "rpe"), (8192, "none"), (8192, "dense")):
