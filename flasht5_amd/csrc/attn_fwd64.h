@@ -41,13 +41,22 @@ struct Fwd64Cfg {
   static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + 16;
   static constexpr int MERGE = 32 * 64 * 4 + 1024;  // KSPLIT: per wave, one query block's O^T (32 registers x 64 lanes) + (m, l) -- inside the rings
   static_assert(NW * MERGE <= 2 * NS * TILE, "merge area lives in the K / V rings");
-  static size_t smem(int R, int bias_mode) { return TAB + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0); }
+  // dense bias (round 4): the workgroup's (BM rows x 64 keys) 16-bit bias tile of every key tile travels global -> LDS like K / V,
+  // into a ring of two tiles behind the K / V rings (source-swizzled like a D = 64 image: BiasTileReader)
+  static constexpr int BIASB = BM * BN * 2, NSB = 2;
+  static size_t smem(int R, int bias_mode) {
+    return TAB + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) + (bias_mode == FAT5_BIAS_DENSE ? (size_t)NSB * BIASB : 0);
+  }
 };
 
 // LDS access by integer address (base VGPR + compile-time constant -> the constant lands in the instruction's offset field;
 // pointer arithmetic on the dynamic-LDS symbol costs a v_add per access instead)
 FAT5_DEV u32x4 lds_rd128(uint32_t addr) {
   typedef const u32x4 __attribute__((address_space(3))) * p_t;
+  return *(p_t)(uintptr_t)addr;
+}
+FAT5_DEV u32x2 lds_rd64(uint32_t addr) {
+  typedef const u32x2 __attribute__((address_space(3))) * p_t;
   return *(p_t)(uintptr_t)addr;
 }
 FAT5_DEV u32x4 lds_rd_tr(uint32_t a0, uint32_t a1) {  // two ds_read_b64_tr_b16 -> one transposed operand fragment
@@ -78,6 +87,21 @@ FAT5_DEV float asm_exp2(float x) {
   return r;
 }
 FAT5_DEV void asm_add(float& l, float p) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(l) : "v"(p)); }
+FAT5_DEV float asm_mulf(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+FAT5_DEV float asm_shl16(uint32_t w) {  // low bf16 of a packed pair -> fp32
+  float r;
+  asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(w));
+  return r;
+}
+FAT5_DEV float asm_and_hi(uint32_t w) {  // high bf16 of a packed pair -> fp32
+  float r;
+  asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(w));
+  return r;
+}
 template <bool BF16>
 FAT5_DEV uint32_t asm_cvt_pk(float a, float b) {
   uint32_t r;
@@ -96,7 +120,8 @@ FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); 
 
 template <int D, bool BF16, int BIAS, bool KSPLIT>
 FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
-  static_assert(BIAS != FAT5_BIAS_DENSE, "dense bias runs the 32-row body");
+  static_assert(BIAS != FAT5_BIAS_DENSE || !KSPLIT, "dense bias: 256-row workgroups only");
+  constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
   using Cfg = Fwd64Cfg<D, KSPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
@@ -176,12 +201,36 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   };
   auto dma_k = [&](int t, int slot) { dma_tile(kst, krs, (uint32_t)(t * BN) * kstride_b, (uint32_t)(Cfg::KOFF + slot * TILE)); };
   auto dma_v = [&](int t, int slot) { dma_tile(vst, vrs, (uint32_t)(t * BN) * vstride_b, (uint32_t)(Cfg::VOFF + slot * TILE)); };
+  // dense bias: tile t (rows m0 .. m0 + BM - 1, keys 64 t ..) into bias slot t & 1.  Every wave fetches the rows IT reads (its 64 query
+  // rows: eight 1-KiB pieces of 8 rows), so its own counted vmcnt covers them -- the first groups of the next tile are read before
+  // the iteration's closing barrier.  Rows past M and bytes past the last row's N keys read as zeros; key columns past N inside earlier
+  // rows read the next row's values (finite): tiles with such keys run the masked, unpipelined pass.
+  using BDma = DmaStage<BN, 64, 64, true>;
+  BDma bst;
+  constexpr int BOFF = Cfg::TAB;  // (the table region: unused in dense mode)
+  __amdgpu_buffer_rsrc_t brs = krs;
+  if constexpr (DENSE) {
+    static_assert(BDma::NV == 2 && BDma::PER == 8, "eight pieces of 8 rows, two swizzle phases");
+    bst.init(a.bs[2], l);
+    brs = make_rows_rsrc(a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)(m0 + 64 * rg) * a.bs[2], a.bs[2], M - m0 - 64 * rg, N);
+  }
+  const uint32_t bias_lds = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(Cfg::TAB + rg * 64 * BN * 2));
+  auto dma_b = [&](int t) {
+    if constexpr (DENSE) {
+      const uint32_t base = bias_lds + (uint32_t)((t & 1) * Cfg::BIASB);
+#pragma unroll
+      for (int i = 0; i < BDma::PER; ++i) dma16_asm(brs, base + (uint32_t)(1024 * i), bst.voff[i % 2], (uint32_t)(t * BN) * 2u + bst.piece_step * (i / 2));
+    }
+  };
   // Ring protocol.  Tile t lives in slot t % NS of both rings.  Iteration t (between two barriers) may read K(t), K(t+1) and
   // V(t); it starts by issuing K(t+NS-1) and V(t+NS-2) into the slots of K(t-1) / V(t-2), whose last readers are behind the
   // barrier that ended iteration t-1.  Before its closing barrier every wave waits for its own pieces of K(t+2) and V(t+1)
   // -- everything but the requests issued in THIS iteration (counted vmcnt: LDS-DMA requests retire in order), so a
   // request has a full iteration more than it needs to land.
+  // Dense: the bias tile of t + 1 is requested FIRST in iteration t (into the slot of tile t - 1), so that the counted wait at the end
+  // of the iteration -- everything but this iteration's K / V requests -- covers it: it is read from the first block of iteration t + 1.
   auto stage_first = [&]() {
+    if (nt > 0) dma_b(0);
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
       if (i < nt) dma_k(i, i);
@@ -192,6 +241,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   auto begin_iter = [&](int t, int slot) {
     const int sk = slot == 0 ? NS - 1 : slot - 1;                    // (t + NS - 1) % NS
     const int sv = slot <= 1 ? slot + NS - 2 : slot - 2;             // (t + NS - 2) % NS
+    if (t + 1 < nt) dma_b(t + 1);
     if (t + NS - 1 < nt) dma_k(t + NS - 1, sk);
     if (t + NS - 2 < nt) dma_v(t + NS - 2, sv);
   };
@@ -252,6 +302,20 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   auto tab_addr = [&](int qb, int nb) {  // LDS address of the lane's 28-entry window of block nb (clamped into the padded copy)
     return tabA + 4u * (uint32_t)min(max(posb[qb] + nb, -kRpePad), clamp_hi);
   };
+  // dense bias: LDS byte address of this lane's 8 bytes of (key block kb, key group gg) of query block 0 in bias slot 0 -- keys
+  // 32 kb + 8 gg + 4 hi + (0..3) of row 64 rg + lq; query block 1 sits 32 rows = 4096 bytes further, slot 1 Cfg::BIASB further
+  uint32_t bA[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  if constexpr (DENSE) {
+    BiasTileReader brd;
+    brd.init(64 * rg + lq, hi);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        bA[kb][gg] = lds0 + (uint32_t)(BOFF + brd.base[kb] + brd.goff[gg]);
+        asm volatile("" : "+v"(bA[kb][gg]));
+      }
+  }
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
@@ -294,7 +358,20 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
           if constexpr (!NOMAX) mcand = fmaf(max16(sq), c2, cst);
         } else {
           bool folded = fold_ok;
-          if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+          if constexpr (DENSE) {
+            // (unpipelined: masked tiles and the exact second pass) this lane's 16 bias values of the block from the staged tile
+            folded = false;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              u32x2 wv = lds_rd64(bA[kb][g] + (uint32_t)((t & 1) * Cfg::BIASB + qb * 4096));
+              wv[0] = bias_clamp2<BF16>(wv[0]);
+              wv[1] = bias_clamp2<BF16>(wv[1]);
+              sq[4 * g + 0] = fmaf(sq[4 * g + 0], c2, bias_log2(cvt_lo<BF16>(wv[0])));
+              sq[4 * g + 1] = fmaf(sq[4 * g + 1], c2, bias_log2(cvt_hi<BF16>(wv[0])));
+              sq[4 * g + 2] = fmaf(sq[4 * g + 2], c2, bias_log2(cvt_lo<BF16>(wv[1])));
+              sq[4 * g + 3] = fmaf(sq[4 * g + 3], c2, bias_log2(cvt_hi<BF16>(wv[1])));
+            }
+          } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
             // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
             const int R = a.R;
             folded = false;
@@ -377,6 +454,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   float xc[2], pc[2];
   u32x4 TN[2];
   uint32_t tadr0 = 0;
+  [[maybe_unused]] u32x2 BN0 = {0u, 0u}, BN1 = {0u, 0u};  // dense: the first two bias groups of the block whose softmax is due
 
   // One pipelined 32-key block i = 16 MFMA gaps.  Gap g holds, all mutually independent:
   //   MFMA g          g < 8: O^T += VF . PB (block i-1; VF was fetched during the previous block)   g >= 8: S' = K(KS, KB) . Q^T (block i+1)
@@ -403,6 +481,16 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       T[0][0] = TN[0];
       T[0][1] = TN[1];
     }
+    // DENSE: the bias words of this block (= (VS, VB)), [query block][4-key group] = two 2-element words each; the first two groups were
+    // fetched during the previous block (BN0, BN1).  The values enter in log2 units: one shift / mask and one multiply per element on
+    // top of the FMA (no clamp: a finfo.min bias overflows to -inf here, p = 0; a row of nothing but such entries has l = 0 and sends
+    // its workgroup through the exact pass, which clamps like the 32-row body)
+    [[maybe_unused]] u32x2 Bw[2][4];
+    if constexpr (DENSE) {
+      Bw[0][0] = BN0;
+      Bw[0][1] = BN1;
+    }
+    constexpr uint32_t bcur = (uint32_t)((VS & 1) * Cfg::BIASB), bnxt = (uint32_t)((KS & 1) * Cfg::BIASB);
     static_for<16>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       // ---- MFMA ----
@@ -421,6 +509,17 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         constexpr int v = g - 8, t2 = v >> 2, db = (v >> 1) & 1, j2 = v & 1;
         typedef s16x4_t __attribute__((address_space(3))) * p_t;
         vh[t2][db][j2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)(trA[j2][db] + voff + (uint32_t)(16 * t2 * 2 * D))));
+      }
+      if constexpr (DENSE) {  // chunk pair (2p, 2p + 1) = query block p >> 2, key group p & 3: fetched three gaps ahead
+        if constexpr (g == 1) Bw[0][2] = lds_rd64(bA[VB][2] + bcur);
+        else if constexpr (g == 3) Bw[0][3] = lds_rd64(bA[VB][3] + bcur);
+        else if constexpr (g == 5) Bw[1][0] = lds_rd64(bA[VB][0] + bcur + 4096u);
+        else if constexpr (g == 7) Bw[1][1] = lds_rd64(bA[VB][1] + bcur + 4096u);
+        else if constexpr (g == 9) Bw[1][2] = lds_rd64(bA[VB][2] + bcur + 4096u);
+        else if constexpr (g == 11) Bw[1][3] = lds_rd64(bA[VB][3] + bcur + 4096u);
+        else if constexpr (g == 12 && VB == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER) : "memory");  // (the next block opens tile t + 1: this wave's pieces of its bias tile, requested ahead of this iteration's K / V)
+        else if constexpr (g == 13) BN0 = lds_rd64(bA[KB][0] + bnxt);  // the next block = (KS, KB)
+        else if constexpr (g == 15) BN1 = lds_rd64(bA[KB][1] + bnxt);
       }
       if constexpr (BAND) {
         if constexpr (g == 1) T[0][2] = lds_rd128(tadr0 + 64u);
@@ -457,7 +556,20 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       // ---- VALU: exponent arguments of chunk g ----
       {
         constexpr int cq = g >> 3, cr = 2 * (g & 7);
-        if constexpr (BAND) {
+        if constexpr (DENSE) {
+          const uint32_t wd = Bw[cq][cr >> 2][(cr & 3) >> 1];
+          float b0, b1;
+          if constexpr (BF16) {
+            b0 = asm_mulf(asm_shl16(wd), kLog2e);
+            b1 = asm_mulf(asm_and_hi(wd), kLog2e);
+          } else {
+            const f16x2_t hv = __builtin_bit_cast(f16x2_t, wd);
+            b0 = (float)hv[0] * kLog2e;
+            b1 = (float)hv[1] * kLog2e;
+          }
+          X[g][0] = asm_fma(S[cq][cr], c2, b0);
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, b1);
+        } else if constexpr (BAND) {
           X[g][0] = asm_fma(S[cq][cr], c2, __uint_as_float(T[cq][cr >> 2][cr & 3]));
           X[g][1] = asm_fma(S[cq][cr + 1], c2, __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]));
         } else {
@@ -581,6 +693,9 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     cst_b = cst_pos;
     tbA = ta / NS * NS;
     tbB = min(t_full, (tb0 + NS - 1) / NS * NS);
+  } else if constexpr (DENSE) {
+    ta = 0;              // (exact pass: every tile generic; optimistic sweep: every unmasked tile in the pipelined dense mode)
+    tbA = tbB = t_full;
   } else {
     ta = t_full;
     tbA = tbB = t_full;  // (no band: one constant range, bias 0)
@@ -629,6 +744,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
             pipe_run.template operator()<true>(t, tbB, slot, 0.f);
             pipe_run.template operator()<false>(t, t_full, slot, cst_b);
           } else {
+            if constexpr (DENSE) {  // the first block's first two bias groups (later blocks prefetch their successor's)
+              BN0 = lds_rd64(bA[0][0]);
+              BN1 = lds_rd64(bA[0][1]);
+            }
             pipe_run.template operator()<false>(t, t_full, slot, 0.f);
           }
           pipe_drain();
@@ -725,6 +844,12 @@ template <int D, bool BF16, int BIAS, bool KSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  // (two waves per SIMD: <= 256 registers)
 void attn_fwd64_kernel(const AttnArgs a) {
   attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, blockIdx.x);
+}
+// dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_fwd64_dense_kernel(const AttnArgs a) {
+  attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, false>(a, blockIdx.x);
 }
 
 }  // namespace fat5

@@ -25,8 +25,21 @@ static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int D, bool BF16>
+static hipError_t launch64_dense(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = Fwd64Cfg<D, false>::smem(a.R, FAT5_BIAS_DENSE);
+  auto kern = attn_fwd64_dense_kernel<D, BF16>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
 template <bool KSPLIT>
 static hipError_t launch64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
+  if constexpr (!KSPLIT) {
+    if (bias == FAT5_BIAS_DENSE) return bf16 ? launch64_dense<FAT5_INST_D, true>(a, grid, s) : launch64_dense<FAT5_INST_D, false>(a, grid, s);
+  }
   if (bias == FAT5_BIAS_RPE1D)
     return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s);
   return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE, KSPLIT>(a, grid, s);

@@ -163,6 +163,19 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   // the chip (fat5_attn_params.variant: FAT5_V_FWD64_OFF disables, FAT5_V_FWD64_ON forces wherever the body applies)
   const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
   const long waves64 = bh * ((p->M + 63) / 64);  // waves of 64 query rows x all keys
+  // Dense bias (round 4): the 64-row body with a two-tile bias ring in LDS -- one workgroup per CU, one wave per SIMD, so it needs
+  // the chip full of 64-row waves; bf16 (the sweep without a running maximum), bias rows 16-byte aligned (LDS-DMA)
+  const bool dense64 = p->D == 64 && p->bias_mode == FAT5_BIAS_DENSE && p->dtype == FAT5_BF16 && !p->cu_seqlens_q && f64_env != 0 &&
+                       ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) && (p->bias_stride[1] % 8 == 0) &&
+                       (p->bias_stride[2] % 8 == 0) && smem_fwd64_d64(0, FAT5_BIAS_DENSE) <= 160 * 1024 &&
+                       (f64_env == 1 || (waves64 >= 3072 && p->N >= 4096 && !p->causal));  // (measured, us, 64-row vs 32-row body: (4,12,8192) 1217 vs 1371; (4,12,2048) 102 vs 95; (16,12,1024) causal 95 vs 77)
+  if (dense64) {
+    c.fwd64 = true;
+    c.ksplit = false;
+    c.nw = 4;
+    c.n_mblk = (p->M + 255) / 256;
+    return c;
+  }
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
       // (fp16: P would overflow at 2^16 without the running maximum, so its 64-row body is the exact, unpipelined pass -- still
       //  ahead of the 32-row body once the chip is full: 953 vs 987 us at (4,12,8192,64))

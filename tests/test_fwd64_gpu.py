@@ -146,3 +146,58 @@ def test_fwd64_deterministic():
     a = _run(q, k, v, do, False, 0.125)
     b = _run(q, k, v, do, False, 0.125)
     assert torch.equal(a["o"], b["o"])
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,kind", [
+    (2, 3, 1024, 1024, False, "1h"),     # the model's bias: one tile ring shared by the batch
+    (2, 2, 512, 768, False, "bh"),       # per-batch bias
+    (1, 2, 1280, 1280, True, "1h"),      # causal: diagonal tiles masked (exact, unpipelined), the rest pipelined
+    (2, 2, 1000, 1096, False, "11"),     # ragged M (rows past M read as zeros), N a multiple of 8 but not of 64: a masked tail tile
+    (1, 2, 300, 2048, True, "b1"),       # M << N, bottom-right causal, head-broadcast bias
+    (1, 2, 2048, 256, True, "1h"),       # M >> N: fully masked rows
+    (1, 1, 3072, 3072, False, "1h"),     # several trips of the 4-tile loop: the two-tile bias ring turns over many times
+])
+def test_fwd64_dense_bias_matches_oracle(B, H, M, N, causal, kind, force_fwd64):
+    """Round 4: the dense-bias instantiation of the 64-row body (bias tiles by LDS-DMA into a two-tile ring, the bias words as the
+    addend of the exponent FMA inside the pipelined stream; reference kernel bias path flash_attention_v2_bias.py:440-443) forced on
+    shapes the oracle finishes in seconds: o, lse and -- through the backward that consumes this lse -- all four gradients."""
+    if force_fwd64 == "ksplit":
+        pytest.skip("dense bias: 256-row workgroups only")
+    from flasht5_amd import _lib
+    assert _lib.describe(B=B, H=H, M=M, N=N, bias_mode=_lib.BIAS_DENSE, variant=_lib.V_FWD64_ON)["fwd"] == "64row"
+    dtype = torch.bfloat16
+    q, k, v, bias, do = make_inputs(B, H, M, N, 64, dtype, kind, seed=7 * M + N, strided=True)
+    from attn_helpers import run_dense
+    ref = oracle_all(q, k, v, bias, do, 0.125, causal)
+    got = run_dense(q, k, v, bias, do, 0.125, causal)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], dtype)
+    fin = torch.isfinite(ref["L"])
+    assert torch.equal(torch.isfinite(got["L"]), fin)
+    assert maxdiff(got["L"][fin], ref["L"][fin]) <= 2e-3 * max(1.0, float(ref["L"][fin].abs().max()))
+    for key in ("dq", "dk", "dv", "db"):
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= gbound(ref[key], dtype), key
+
+
+def test_fwd64_dense_bias_masking_values_and_edge_rows(force_fwd64):
+    """a bias holding finfo.min (the reference's `use_masking`, modeling_flash_t5.py:266-270) on half of the keys of every row and on ALL
+    keys of some rows: masked keys get p = 0 inside the pipelined sweep (the product overflows to -inf), a fully masked row has
+    l = 0 there and sends its workgroup through the exact pass, which clamps like the 32-row body: same results as that body"""
+    if force_fwd64 == "ksplit":
+        pytest.skip("dense bias: 256-row workgroups only")
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import _attn_fwd
+    B, H, S = 1, 2, 1024
+    q, k, v, bias, _ = make_inputs(B, H, S, S, 64, torch.bfloat16, "1h", seed=5, strided=True)
+    bias = bias.clone()
+    bias[..., S // 2:] = torch.finfo(torch.bfloat16).min
+    bias[:, :, 7::64, :] = torch.finfo(torch.bfloat16).min
+    outs = []
+    for bits in (_lib.V_FWD64_ON | _lib.V_FWD64_KSPLIT_OFF, _lib.V_FWD64_OFF):
+        with _lib.variant(bits):
+            o, L = _attn_fwd(q, k, v, bias, None, 0, False, 0.125)
+        outs.append((o.float(), L))
+    assert torch.isfinite(outs[0][0]).all()
+    assert maxdiff(outs[0][0], outs[1][0]) <= 2.0 ** -7 * max(1.0, float(outs[1][0].abs().max()))
+    assert maxdiff(outs[0][1], outs[1][1]) <= 1e-3 * max(1.0, float(outs[1][1].abs().max()))

@@ -316,8 +316,10 @@ def test_dispatch_rules_are_pinned():
         # under-filled grids with long streams
         (dict(B=4, H=12, M=4096, N=1024), dict(dq="32row", dkdv="64key")),
         (dict(B=4, H=12, M=1024, N=8192), dict(dq="64row")),
-        # dense bias never runs the 64-wide bodies; the batch-shared gradient is formed in-kernel once the staging tensor would be large
-        (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="32row", dq="32row", dkdv="32key", dbias="inkernel")),
+        # dense bias: the 64-row forward (two-tile bias ring, one wave per SIMD) from 4096 keys on (round 4), the 32-wide backward bodies;
+        # the batch-shared gradient is formed in-kernel once the staging tensor would be large
+        (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="64row", dq="32row", dkdv="32key", dbias="inkernel")),
+        (dict(B=4, H=12, M=2048, N=2048, **dense), dict(fwd="32row")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dbias="staged")),
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="32row", dq="32row", dkdv="32key")),
