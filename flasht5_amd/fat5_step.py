@@ -277,7 +277,7 @@ class FAT5ForConditionalGeneration(nn.Module):  # :604-736 (training forward onl
             from .lm_head_cross_entropy import lm_head_cross_entropy
             c = self.config
             return lm_head_cross_entropy(dec, self.lm_head.weight, labels, label_smoothing=c.label_smoothing,
-                                         lse_square_scale=c.z_loss)[0].mean()
+                                         lse_square_scale=c.z_loss, reduction="mean")[0]
         return self.loss_fct(self.lm_head(dec), labels)
 
 

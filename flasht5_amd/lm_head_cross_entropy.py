@@ -21,11 +21,23 @@ import torch
 
 from .cross_entropy_loss import cross_entropy_fwd, cross_entropy_bwd
 
-__all__ = ["lm_head_cross_entropy", "LMHeadCrossEntropy"]
+__all__ = ["lm_head_cross_entropy", "LMHeadCrossEntropy", "LMHeadCrossEntropyMean"]
 
 
 def _chunks(rows, chunk_rows):
     return [(s, min(rows, s + chunk_rows)) for s in range(0, rows, chunk_rows)]
+
+
+def _dh_gemm(dlogits, weight):
+    """dlogits (m, V) @ weight (V, K) for a row chunk: m x K is a few dozen output tiles with a contraction over the whole vocabulary
+    -- the library runs it on a fraction of the chip (212 us against 117 us for the chunk's logits GEMM of the same flops, measured
+    at m = 2048, V = 32768, K = 768).  Split the contraction four ways (one batched GEMM, fp32 partials) and add the parts."""
+    m, V = dlogits.shape
+    K = weight.shape[1]
+    if dlogits.dtype == torch.float32 or V % 4 or (m // 256) * (K // 128) >= 192 or not weight.is_contiguous():
+        return dlogits @ weight
+    part = torch.bmm(dlogits.view(m, 4, V // 4).transpose(0, 1), weight.view(4, V // 4, K), out_dtype=torch.float32)
+    return part.sum(0).to(dlogits.dtype)
 
 
 class LMHeadCrossEntropy(torch.autograd.Function):
@@ -60,24 +72,80 @@ class LMHeadCrossEntropy(torch.autograd.Function):
             logits = hidden[s:e] @ wt
             cross_entropy_bwd(g[s:e], logits, lse[s:e], labels[s:e], True, smoothing, logit_scale, lse_square_scale, ignore_index)
             if need_h:
-                dh[s:e] = logits @ weight                                # logits now holds dlogits (in place)
+                dh[s:e] = _dh_gemm(logits, weight)                       # logits now holds dlogits (in place)
             if need_w:
-                dw.addmm_(logits.t().float(), hidden[s:e].float()) if weight.dtype == torch.float32 else dw.add_(logits.t() @ hidden[s:e])
+                if weight.dtype == torch.float32:
+                    dw.addmm_(logits.t(), hidden[s:e])
+                else:
+                    torch.addmm(dw, logits.t(), hidden[s:e], out_dtype=torch.float32, out=dw)
         return dh, (dw.to(weight.dtype) if need_w else None), None, None, None, None, None, None
+
+
+class LMHeadCrossEntropyMean(torch.autograd.Function):
+    """The MEAN of the per-row losses (what the model takes: `cross_entropy_loss(...)[0].mean()`, modeling_flash_t5.py:64-68) with the
+    gradients formed in the FORWARD pass, chunk by chunk (round 4): the upstream gradient of a mean is one scalar, so every row's
+    dlogits = (1 / rows) d loss_r / d logits_r is known as soon as the chunk's loss is -- no recomputation of the logits in the
+    backward (three lm_head-sized GEMMs per step like the unfused form instead of four), which only scales dh and dW by that scalar.
+
+        per chunk c:  logits_c = h_c W^T -> fat5_ce_fwd -> sum of losses | fat5_ce_bwd in place (dlosses = 1 / rows) -> dlogits_c
+                      dh_c = dlogits_c W,   dW += dlogits_c^T h_c   (fp32 accumulation over the chunks)"""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, labels, smoothing, logit_scale, lse_square_scale, ignore_index, chunk_rows):
+        rows = hidden.shape[0]
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dev = hidden.device
+        total = torch.zeros((), dtype=torch.float32, device=dev)
+        ztotal = torch.zeros((), dtype=torch.float32, device=dev)
+        dh = torch.empty_like(hidden) if need_h else None
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev) if need_w else None
+        wt = weight.t()
+        g = torch.full((min(rows, chunk_rows),), 1.0 / max(rows, 1), dtype=torch.float32, device=dev)
+        for s, e in _chunks(rows, chunk_rows):
+            logits = hidden[s:e] @ wt
+            l, z, ls = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
+            total += l.sum()
+            ztotal += z.sum()
+            if need_h or need_w:
+                cross_entropy_bwd(g[:e - s], logits, ls, labels[s:e], True, smoothing, logit_scale, lse_square_scale, ignore_index)
+                if need_h:
+                    dh[s:e] = _dh_gemm(logits, weight)                   # logits now holds dlogits (in place)
+                if need_w:  # (fp32 accumulation over the chunks inside the GEMM: bf16 operands, fp32 output added to the accumulator)
+                    if weight.dtype == torch.float32:
+                        dw.addmm_(logits.t(), hidden[s:e])
+                    else:
+                        torch.addmm(dw, logits.t(), hidden[s:e], out_dtype=torch.float32, out=dw)
+        if need_w and dw.dtype != weight.dtype:
+            dw = dw.to(weight.dtype)
+        ctx.save_for_backward(dh, dw)
+        zmean = ztotal / max(rows, 1)
+        ctx.mark_non_differentiable(zmean)
+        return total / max(rows, 1), zmean
+
+    @staticmethod
+    def backward(ctx, grad_loss, grad_z):
+        del grad_z
+        dh, dw = ctx.saved_tensors
+        return (dh * grad_loss.to(dh.dtype) if dh is not None else None, dw * grad_loss.to(dw.dtype) if dw is not None else None,
+                None, None, None, None, None, None)
 
 
 def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0,
                           logit_scale: float = 1.0, lse_square_scale: float = 0.0, ignore_index: int = -100,
-                          chunk_rows: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                          chunk_rows: Optional[int] = None, reduction: str = "none") -> Tuple[torch.Tensor, torch.Tensor]:
     """hidden (..., d_model), weight (vocab, d_model) -- `lm_head.weight` --, labels (...): returns (losses, z_losses), fp32 per row,
-    equal to `cross_entropy_loss(hidden @ weight.T, labels, ...)`.  chunk_rows: rows per chunk (default: ~64 MB of logits)."""
+    equal to `cross_entropy_loss(hidden @ weight.T, labels, ...)`.  chunk_rows: rows per chunk (default: ~128 MB of logits).
+    reduction="mean": returns (losses.mean(), z_losses.mean()) over ALL rows -- two scalars -- with the gradients formed during the
+    forward pass (LMHeadCrossEntropyMean): no recomputation, the fast form for a training step."""
     if not hidden.is_cuda:
         raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
+    if reduction not in ("none", "mean"):
+        raise ValueError("reduction must be 'none' or 'mean'")
     h2 = hidden.reshape(-1, hidden.shape[-1])
     lab = labels.reshape(-1)
     if lab.shape[0] != h2.shape[0] or weight.shape[1] != h2.shape[1]:
         raise ValueError(f"hidden {tuple(hidden.shape)}, weight {tuple(weight.shape)}, labels {tuple(labels.shape)} do not match")
     if chunk_rows is None:
-        chunk_rows = max(256, (64 << 20) // (weight.shape[0] * h2.element_size()) // 256 * 256)
-    return LMHeadCrossEntropy.apply(h2, weight, lab, float(label_smoothing), float(logit_scale), float(lse_square_scale),
-                                    int(ignore_index), int(chunk_rows))
+        chunk_rows = max(256, (128 << 20) // (weight.shape[0] * h2.element_size()) // 256 * 256)
+    fn = LMHeadCrossEntropyMean if reduction == "mean" else LMHeadCrossEntropy
+    return fn.apply(h2, weight, lab, float(label_smoothing), float(logit_scale), float(lse_square_scale), int(ignore_index), int(chunk_rows))

@@ -113,8 +113,9 @@ def test_cfg5_train_step_updates_and_repeats():
 
 
 def test_cfg5_fused_lm_head_ce_matches_unfused():
-    """the step with lm_head + loss fused in row chunks (the (B*T, vocab) logits never exist): same loss to the
-    last bit (same GEMM rows, same kernels), same gradients up to the fp32 accumulation order of d lm_head.weight"""
+    """the step with lm_head + loss fused in row chunks (the (B*T, vocab) logits never exist): same per-row losses
+    (same GEMM rows, same kernels) -- their mean to fp32 summation order (round 4: the fused form sums chunk by chunk and forms its
+    gradients in the forward pass) --, same gradients up to the fp32 accumulation order of d lm_head.weight"""
     from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
     import copy
     cfg = FAT5Config(num_layers=2, num_decoder_layers=2)
@@ -129,7 +130,7 @@ def test_cfg5_fused_lm_head_ce_matches_unfused():
     labels[0, -9:] = -100
     labels = labels.cuda()
     l0, l1 = m0(ids, labels), m1(ids, labels)
-    assert l0.item() == l1.item()
+    assert abs(l0.item() - l1.item()) <= 2e-6 * abs(l0.item())
     l0.backward()
     l1.backward()
     for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
@@ -156,7 +157,7 @@ def test_cfg5_fused_add_norm_is_bit_identical():
     ids = torch.randint(0, cfg.vocab_size, (2, 512), generator=g).cuda()
     labels = torch.randint(0, cfg.vocab_size, (2, 256), generator=g).cuda()
     l0, l1 = m0(ids, labels), m1(ids, labels)
-    assert l0.item() == l1.item()
+    assert abs(l0.item() - l1.item()) <= 2e-6 * abs(l0.item())
     l0.backward()
     l1.backward()
     # (gradients: the model's backward is not run-to-run deterministic -- torch's embedding backward and some library GEMMs
@@ -242,5 +243,10 @@ def test_cfg5_two_layer_model_every_parameter(fuse):
     rgrads = dict(zip(names, torch.autograd.grad(rloss, [sd[n] for n in names])))
     assert abs(loss.item() - rloss.item()) <= 5e-3 * abs(rloss.item()), (loss.item(), rloss.item())
     got = dict(model.named_parameters())
-    worst = max(((maxdiff(got[n].grad, rgrads[n]) / (rgrads[n].abs().max().item() + 1e-12), n) for n in names))
+    # (the two bias tables sum ~1e7 dS values each rounded to bf16 -- like the reference's own `ds.to(dtype)` before `sum(0)`,
+    #  flash_attention_v2_bias.py:720 / :214 -- over two layers: 5e-2; every other tensor 2e-2)
+    rel = {n: maxdiff(got[n].grad, rgrads[n]) / (rgrads[n].abs().max().item() + 1e-12) for n in names}
+    worst = max((v, n) for n, v in rel.items() if "relative_attention_bias" not in n)
     assert worst[0] <= 2e-2, worst
+    worst_t = max((v, n) for n, v in rel.items() if "relative_attention_bias" in n)
+    assert worst_t[0] <= 5e-2, worst_t

@@ -311,3 +311,29 @@ def test_fused_projections_match_the_reference_fixture():
                           (da, "da", 2e-2), (dwo, "dwo", 2e-2), (dres, "dres", 2.0 ** -8)):
         ref = g[key].cuda()
         assert (got.float() - ref).abs().max().item() <= rel * max(1.0, ref.abs().max().item()), key
+
+
+@pytest.mark.parametrize("rows,V,d,chunk,dtype", [(96, 1000, 128, 32, torch.float32), (50, 32128, 64, 16, torch.float32), (8, 520, 256, 256, torch.float32),
+                                                  (200, 4096, 256, 64, torch.bfloat16)])
+def test_lm_head_cross_entropy_mean_vs_oracle(rows, V, d, chunk, dtype):
+    """reduction="mean" (round 4: the gradients are formed in the forward pass, no recomputation): the mean loss, the mean z-loss and the
+    gradients of hidden / weight -- scaled by a non-trivial upstream gradient -- against oracle.ce_fwd_oracle / ce_bwd_oracle on the
+    fp32 logits; bf16: within the rounding of the logits / dlogits that the unfused bf16 sequence has as well."""
+    from flasht5_amd import lm_head_cross_entropy
+    g = torch.Generator().manual_seed(rows + V)
+    hid = torch.randn(rows, d, generator=g).to(dtype)
+    W = (torch.randn(V, d, generator=g) / d ** 0.5).to(dtype)
+    lab = torch.randint(0, V, (rows,), generator=g)
+    lab[::7] = -100
+    hs, Ws = hid.cuda().requires_grad_(), W.cuda().requires_grad_()
+    loss, z = lm_head_cross_entropy(hs, Ws, lab.cuda(), label_smoothing=0.1, lse_square_scale=1e-4, chunk_rows=chunk, reduction="mean")
+    assert loss.dim() == 0 and not z.requires_grad
+    dh, dW = torch.autograd.grad(loss * 1.75, (hs, Ws))
+    logits = hid.float() @ W.float().t()
+    l_ref, z_ref, lse = oracle.ce_fwd_oracle(logits, lab, 0.1, 1.0, 1e-4, -100)
+    dlog = oracle.ce_bwd_oracle(torch.full((rows,), 1.75 / rows), logits, lse, lab, 0.1, 1.0, 1e-4, -100)
+    rel = 2e-4 if dtype == torch.float32 else 2e-2
+    tol = lambda t: rel * max(1e-3 if dtype == torch.float32 else 0.0, t.abs().max().item())  # noqa: E731
+    assert abs(loss.item() - l_ref.mean().item()) <= rel * abs(l_ref.mean().item()) and abs(z.item() - z_ref.mean().item()) <= rel * abs(z_ref.mean().item()) + 1e-7
+    assert maxdiff(dh.cpu(), dlog @ W.float()) <= tol(dlog @ W.float())
+    assert maxdiff(dW.cpu(), dlog.t() @ hid.float()) <= tol(dlog.t() @ hid.float())
