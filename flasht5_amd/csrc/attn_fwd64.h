@@ -22,7 +22,7 @@
 //    (second pass, unpipelined).  Band tiles read their per-element bias from the padded table copies in LDS (attn_common.h)
 //    inside the pipelined stream: the value is the FMA's addend (no extra VALU op), fetched three MFMA gaps ahead.
 //    Tiles with masked keys (N tail, causal diagonal) run unpipelined with the same reference point.  fp16 P overflows at
-//    2^16: fp16 runs the exact pass only.
+//    2^16: its sweep uses the row maxima of the first tile as reference point (round 4; see OPT below).
 //  * KSPLIT (mid sequence lengths): the waves of a workgroup pair up on 64 query rows, each taking ONE 32-key block of every
 //    staged tile, and merge (m, l, O) through LDS at the end: 128-row workgroups of half-length waves.  With 64 rows x N keys
 //    per wave (4,12,2048,64) is 1536 waves on 1024 SIMDs at two waves per SIMD: half the SIMDs carry two waves for the whole
@@ -165,7 +165,11 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   FragAddr<D> fa;
   fa.init(l);
 
-  constexpr bool OPT = FAT5_OPTIMISTIC && BF16;
+  // fp16 (round 4): the same sweep with a per-row reference point -- the row maxima of the first tile (a scores-only pre-pass) --
+  // instead of 0: fp16 probabilities overflow at 2^16, so a later score more than ~11 nats above the first tile's maximum of its
+  // row sends the workgroup through the exact pass (the check the bf16 sweep has for 2^100); what lies far BELOW that maximum
+  // is flushed, as negligible beside the row's own first tile as it is in the exact algorithm.  (dense bias: bf16 only)
+  constexpr bool OPT = FAT5_OPTIMISTIC && (BF16 || !DENSE);
   if (OPT && tid == 0) *sFlag = 0;
 
   f32x16 oacc[2][DB];
@@ -324,7 +328,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // Both query blocks per 32-key block: K / V fragments are read once and used twice.
   // NOMAX: reference point 0 for every row (the optimistic sweep's masked tiles); otherwise the exact running maximum.
   // ------------------------------------------------------------------------------------------------------------------
-  auto tile_exact = [&]<int MODE, bool NOMAX>(int t, int slot, float cst) {
+  auto tile_exact = [&]<int MODE, bool NOMAX, bool MAXONLY = false>(int t, int slot, float cst) {
     const int n0 = t * BN;
     const uint32_t soff = (uint32_t)(slot * TILE);
 #pragma unroll
@@ -343,10 +347,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
           for (int qb = 0; qb < 2; ++qb) s[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], kk == 0 ? zero16 : s[qb]);
       }
       u32x4 vf[2][DB];
+      if constexpr (!MAXONLY) {
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int db = 0; db < DB; ++db) vf[t2][db] = rd_v(soff, kbo, t2, db);
+          for (int db = 0; db < DB; ++db) vf[t2][db] = rd_v(soff, kbo, t2, db);
+      }
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qr0 = qrow0 + 32 * qb, qrow = qr0 + lq;
@@ -405,7 +411,11 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
             mcand = folded ? m16 * c2 : m16;
           }
         }
-        float ad = add;
+        if constexpr (MAXONLY) {  // (the fp16 sweep's reference point: row maxima only)
+          m_run[qb] = fmaxf(m_run[qb], pair_max(mcand));
+          continue;
+        }
+        float ad = add - ((m_run[qb] == -INFINITY) ? 0.f : m_run[qb]);  // (NOMAX: the sweep's fixed reference point -- 0 in bf16)
         if constexpr (!NOMAX) {
           mcand = pair_max(mcand);
           if (__any(mcand > m_run[qb] + FAT5_DEFER_THR)) {
@@ -467,7 +477,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // and pads no hazards for them -- the youngest MFMA result they read (S'[0], finished by MFMA 14) is two MFMA issue
   // periods old when chunk 0 of the next block reads it.
   constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
-  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float adc, const int nbS) {
+  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS) {
     static_assert(D == 64, "gap schedule written for D = 64 (16 MFMAs, 16 two-element chunks per block)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
     u32x4 kf[KK];
@@ -570,11 +580,16 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
           X[g][0] = asm_fma(S[cq][cr], c2, b0);
           X[g][1] = asm_fma(S[cq][cr + 1], c2, b1);
         } else if constexpr (BAND) {
-          X[g][0] = asm_fma(S[cq][cr], c2, __uint_as_float(T[cq][cr >> 2][cr & 3]));
-          X[g][1] = asm_fma(S[cq][cr + 1], c2, __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]));
+          float t0 = __uint_as_float(T[cq][cr >> 2][cr & 3]), t1 = __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]);
+          if constexpr (!BF16) {  // (fp16: table entry minus the row's reference point -- in bf16 the reference point is 0)
+            asm_add(t0, cq == 0 ? ad0 : ad1);
+            asm_add(t1, cq == 0 ? ad0 : ad1);
+          }
+          X[g][0] = asm_fma(S[cq][cr], c2, t0);
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, t1);
         } else {
-          X[g][0] = asm_fma(S[cq][cr], c2, adc);
-          X[g][1] = asm_fma(S[cq][cr + 1], c2, adc);
+          X[g][0] = asm_fma(S[cq][cr], c2, cq == 0 ? ad0 : ad1);
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, cq == 0 ? ad0 : ad1);
         }
       }
       // chunk c is packed in gap c + 2: a group of four words is summed two gaps after its last one (the previous block's last group,
@@ -642,14 +657,16 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // slots 0 .. NS-1) per trip, straight-line -- a slot switch inside the loop makes the register allocator reconcile the bodies at
   // every merge (tuple copies, spilled accumulators).
   auto pipe_run = [&]<bool BAND>(int& t, const int te, int& slot, const float cst) {
+    // the exponent's addend per query block: the tile-constant bias minus the row's reference point (bf16: 0; fp16: m_run, fixed during the sweep)
+    const float ad0 = BF16 ? cst : cst - m_run[0], ad1 = BF16 ? cst : cst - m_run[1];
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
       begin_iter(tt, SL);
       if constexpr (KSPLIT) {
-        pipe_block.template operator()<S1, 0, SL, 0, BAND>(cst, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
+        pipe_block.template operator()<S1, 0, SL, 0, BAND>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
       } else {
-        pipe_block.template operator()<SL, 1, SL, 0, BAND>(cst, tt * BN);
-        pipe_block.template operator()<S1, 0, SL, 1, BAND>(cst, tt * BN + 32);
+        pipe_block.template operator()<SL, 1, SL, 0, BAND>(ad0, ad1, tt * BN);
+        pipe_block.template operator()<S1, 0, SL, 1, BAND>(ad0, ad1, tt * BN + 32);
       }
       end_iter(tt);
     };
@@ -710,7 +727,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
-      m_run[qb] = nomax ? 0.f : -INFINITY;
+      m_run[qb] = (nomax && BF16) ? 0.f : -INFINITY;
       l_run[qb][0] = l_run[qb][1] = 0.f;
     }
     if (pass > 0) {
@@ -722,6 +739,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     int t = 0, slot = 0;
     if constexpr (OPT) {
       if (nomax) {
+        if constexpr (!BF16) {
+          // fp16: the reference point of every row = its maximum over the first tile (scores only); a row that sees none of its keys: 0
+          if (nt > 0) tile_exact.template operator()<0, false, true>(0, 0, 0.f);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            if (m_run[qb] == -INFINITY) m_run[qb] = 0.f;
+        }
         if (t_full > 0) {
           // fill: scores of the wave's first block, nothing pending
           {

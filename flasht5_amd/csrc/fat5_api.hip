@@ -177,9 +177,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     return c;
   }
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
-      // (fp16: P would overflow at 2^16 without the running maximum, so its 64-row body is the exact, unpipelined pass -- still
-      //  ahead of the 32-row body once the chip is full: 953 vs 987 us at (4,12,8192,64))
-      (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 2048) &&
+      // (fp16, round 4: the pipelined sweep with the first tile's row maxima as reference point -- (4,12,8192) 739 us against 913 for the
+      //  32-row body, (4,12,2048) 64.3 vs 69.4)
+      (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 1536) &&
                         // (512 keys are 8 tiles: too few for the pipeline's prologue to pay when half of them sit on the causal diagonal --
                         //  tools/dispatch_audit.py: (4,12,512) causal 10.0 vs 11.2 us, (8,12,512) causal 15.7 vs 17.5 -- or in the 1.5-waves-per-SIMD
                         //  range where the 64-row waves fill the chip unevenly: (16,12,512) 22.2 vs 24.8; (16,12,1024x512) and (16,12,2048x512),

@@ -134,7 +134,7 @@ def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, labels: to
                           logit_scale: float = 1.0, lse_square_scale: float = 0.0, ignore_index: int = -100,
                           chunk_rows: Optional[int] = None, reduction: str = "none") -> Tuple[torch.Tensor, torch.Tensor]:
     """hidden (..., d_model), weight (vocab, d_model) -- `lm_head.weight` --, labels (...): returns (losses, z_losses), fp32 per row,
-    equal to `cross_entropy_loss(hidden @ weight.T, labels, ...)`.  chunk_rows: rows per chunk (default: ~128 MB of logits).
+    equal to `cross_entropy_loss(hidden @ weight.T, labels, ...)`.  chunk_rows: rows per chunk (default: ~64 MB of logits, ~128 MB in the mean form).
     reduction="mean": returns (losses.mean(), z_losses.mean()) over ALL rows -- two scalars -- with the gradients formed during the
     forward pass (LMHeadCrossEntropyMean): no recomputation, the fast form for a training step."""
     if not hidden.is_cuda:
@@ -145,7 +145,7 @@ def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, labels: to
     lab = labels.reshape(-1)
     if lab.shape[0] != h2.shape[0] or weight.shape[1] != h2.shape[1]:
         raise ValueError(f"hidden {tuple(hidden.shape)}, weight {tuple(weight.shape)}, labels {tuple(labels.shape)} do not match")
-    if chunk_rows is None:
-        chunk_rows = max(256, (128 << 20) // (weight.shape[0] * h2.element_size()) // 256 * 256)
+    if chunk_rows is None:  # ~64 MB of logits per chunk; the mean form (three GEMMs per chunk, no recomputation) takes chunks twice as long
+        chunk_rows = max(256, ((128 if reduction == "mean" else 64) << 20) // (weight.shape[0] * h2.element_size()) // 256 * 256)
     fn = LMHeadCrossEntropyMean if reduction == "mean" else LMHeadCrossEntropy
     return fn.apply(h2, weight, lab, float(label_smoothing), float(logit_scale), float(lse_square_scale), int(ignore_index), int(chunk_rows))

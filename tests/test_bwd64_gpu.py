@@ -82,8 +82,6 @@ def _table_truth(q, k, v, bias, o, L, do, scale, causal, table, M, N, bidir, md)
 ])
 def test_bwd64_matches_oracle(B, H, M, N, causal, mode, md, dtype):
     scale = 0.125
-    if dtype == torch.float16 and ((M, N) not in ((1024, 1024), (1000, 1100), (2048, 2048)) or md == 512):
-        pytest.skip("fp16: a subset of the shapes")
     if mode == "rpe":
         q, k, v, do, table, bias = _rpe_case(B, H, M, N, dtype, causal, True, md, seed=M + 5 * N)
     else:

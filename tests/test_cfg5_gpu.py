@@ -136,7 +136,9 @@ def test_cfg5_fused_lm_head_ce_matches_unfused():
     for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
         # (the relative-position tables: a sum of ~1e6 signed terms whose inputs already differ in the last bf16 bit between
         #  the two runs -- run to run, too: torch's embedding backward accumulates with atomics -- so the bound is wider)
-        rel = 2.0 ** -4 if "relative_attention_bias" in n else 2.0 ** -7
+        # (round 4: the fused form's dh GEMM sums the vocabulary in four parts -- another fp32 order, the odd last bf16 bit of dh differs,
+        #  and everything below the decoder inherits it: 2^-6 of the largest entry instead of 2^-7)
+        rel = 2.0 ** -4 if "relative_attention_bias" in n else 2.0 ** -6
         tol = rel * max(p0.grad.float().abs().max().item(), 1e-6)
         assert maxdiff(p1.grad, p0.grad) <= tol, (n, maxdiff(p1.grad, p0.grad), tol)
 

@@ -42,7 +42,11 @@ def _run(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
     (1, 2, 1000, 1100, False, "rpe", torch.bfloat16),     # ragged M and N (row clamp, N tail)
     (1, 2, 300, 2500, True, "rpe", torch.bfloat16),       # M << N, bottom-right causal
     (1, 2, 2500, 300, True, "none", torch.bfloat16),      # M >> N: fully masked rows (o = 0, lse = -inf)
-    (1, 2, 1536, 1536, False, "rpe", torch.float16),      # fp16: exact body only (no optimistic loop)
+    (1, 2, 1536, 1536, False, "rpe", torch.float16),      # fp16 (round 4): the pipelined sweep with the first tile's row maxima as reference point
+    (2, 3, 1024, 1024, False, "none", torch.float16),
+    (1, 2, 2048, 2048, True, "rpe", torch.float16),       # fp16 causal: rows whose first tile is partly masked
+    (1, 2, 1000, 1100, False, "rpe", torch.float16),
+    (1, 2, 2500, 300, True, "none", torch.float16),       # fp16, M >> N: rows without any visible key (reference point 0, l = 0)
     (1, 1, 3072, 3072, False, "none", torch.bfloat16),    # several trips of the 4-tile steady-state loop
 ])
 def test_fwd64_matches_oracle(B, H, M, N, causal, mode, dtype):
@@ -201,3 +205,28 @@ def test_fwd64_dense_bias_masking_values_and_edge_rows(force_fwd64):
     assert torch.isfinite(outs[0][0]).all()
     assert maxdiff(outs[0][0], outs[1][0]) <= 2.0 ** -7 * max(1.0, float(outs[1][0].abs().max()))
     assert maxdiff(outs[0][1], outs[1][1]) <= 1e-3 * max(1.0, float(outs[1][1].abs().max()))
+
+
+@pytest.mark.parametrize("boost,at", [(0.0, 512), (6.0, 512), (9.0, 1111), (14.0, 512), (30.0, 768), (200.0, 320), (-20.0, 64), (-60.0, 64)])
+def test_fwd64_fp16_reference_point_edge_cases(boost, at):
+    """fp16 sweep (round 4): reference point = the row's maximum over its first tile.  Scores shifted by `boost` nats from key `at`
+    on: within fp16's range above the reference (6, 9 nats), beyond it (14 nats ~ 2^20, 30, 200: probabilities overflow -> the
+    workgroup's exact second pass), far below it (-20, -60 nats from the second tile on: flushed, negligible beside the first tile)."""
+    B, H, S, D = 1, 2, 2048, 64
+    g = torch.Generator().manual_seed(13)
+    q = torch.randn(B, H, S, D, generator=g).half()
+    k = torch.randn(B, H, S, D, generator=g).half()
+    v = torch.randn(B, H, S, D, generator=g).half()
+    q[..., 0] = 4.0
+    k[..., at:, 0] = boost / 4.0
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B, H, S, D, generator=g).half().cuda()
+    got = _run(q, k, v, do, False, 1.0)
+    ref = oracle_all(q, k, v, None, do, 1.0, False)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], torch.float16)
+    lp = eager_lowprec_errors(q, k, v, None, do, 1.0, False, ref)
+    for key in ("dq", "dk", "dv"):  # (the reference's rule for the gradients: keys of size 50 in fp16 -- the eager low-precision path is the yardstick)
+        assert torch.isfinite(got[key].float()).all(), key
+        e = maxdiff(got[key], ref[key])
+        assert e <= max(gbound(ref[key], torch.float16), 3 * lp[key]), (key, e, lp[key])
