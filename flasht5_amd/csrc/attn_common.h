@@ -229,21 +229,25 @@ FAT5_DEV int rpe_clamp_desc(int pos, int R) { return min(max(pos, -kRpePad + 24)
 // `sT_raw`: the table's raw LDS base (16-byte aligned)
 FAT5_DEV void rpe_table_fill(float* sT_raw, const float* rpe1d_h, int R, int tid, int nthreads) {
   const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
-  // eight global loads in flight per round (a prologue that waits for each load before the next costs a memory round
-  // trip per iteration: +4.6 k cycles measured at cfg2)
-  for (int i0 = tid; i0 < 4 * n1p; i0 += 8 * nthreads) {
+  // Copy by copy (no division by the run-time copy length: ~40 instructions per entry in the first version), two entries of each of
+  // the four copies per round: eight global loads in flight (a prologue that waits for each load before the next costs a memory
+  // round trip per iteration: +4.6 k cycles measured at cfg2)
+  for (int m0 = tid; m0 < n1p; m0 += 2 * nthreads) {
     float vv[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = min(i0 + u * nthreads, 4 * n1p - 1);
-      const int c = i / n1p, m = i - c * n1p;
-      vv[u] = rpe1d_h[min(max(m + c - kRpePad, 0), n1 - 1)];
-    }
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * nthreads;
-      if (i < 4 * n1p) sT_raw[i] = vv[u] * kLog2e;
-    }
+      for (int u = 0; u < 2; ++u) {
+        const int m = m0 + u * nthreads;
+        vv[2 * c + u] = rpe1d_h[min(max(m + c - kRpePad, 0), n1 - 1)];
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int m = m0 + u * nthreads;
+        if (m < n1p) sT_raw[c * n1p + m] = vv[2 * c + u] * kLog2e;
+      }
   }
 }
 

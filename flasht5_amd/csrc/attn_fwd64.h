@@ -150,14 +150,34 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   const int nt = n_end > 0 ? (n_end + BN - 1) / BN : 0;
 
   const int qrow0 = m0 + 64 * rg;  // first query row of this wave; block qb covers rows qrow0 + 32*qb ..+31
-  // Q fragments (B operand of S^T = K Q^T): Q[q][16kk + 8hi + j]
+  // Q fragments (B operand of S^T = K Q^T): Q[q][16kk + 8hi + j].  KSPLIT (short sequences, round 4): the pair's 64 query rows arrive
+  // as whole rows by LDS-DMA -- each wave of the pair four of the eight 1-KiB pieces -- in V ring slots 2, 3 (free until the first
+  // iteration requests V tile 2) and are read back as fragments after the prologue's wait (rows past M arrive as zeros); the
+  // 256-row form loads them straight from global (its prologue is < 1 % of a long sweep).
   u32x4 qf[2][KK];
+  const uint32_t qimg = (uint32_t)(uintptr_t)smem + (uint32_t)(Cfg::VOFF + 2 * TILE + rg * 64 * 2 * D);
+  if constexpr (KSPLIT) {
+    static_assert(2 * TILE >= (Cfg::NW / 2) * 64 * 2 * D, "the Q images of the workgroup's 64-row groups fit V slots 2 and 3");
+    using SDma = DmaStage<D, 64, 64>;
+    static_assert(SDma::PER == 8 && SDma::NV == 2, "eight 1-KiB pieces of 8 rows");
+    SDma sq;
+    sq.init(a.qs[2], l);
+    const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb_, a.qs[2], M, D);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)qimg);
+    const uint32_t r0 = (uint32_t)qrow0 * (uint32_t)a.qs[2] * 2u;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qr = min(qrow0 + 32 * qb + lq, M - 1);
+    for (int i = 0; i < 4; ++i) {
+      const int pi = 4 * kh + i;  // (wave-uniform)
+      dma16_asm(qrs, dst + (uint32_t)(pi * 1024), sq.voff[i % 2], r0 + sq.piece_step * (uint32_t)(pi / 2));
+    }
+  } else {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-      qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qr * a.qs[2] + 16 * kk + 8 * hi);
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qr = min(qrow0 + 32 * qb + lq, M - 1);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qr * a.qs[2] + 16 * kk + 8 * hi);
+    }
   }
   const float* sTa = sT;  // this lane's aligned copy of the RPE table (rows 32 apart share the alignment)
   if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - (qrow0 + lq)) & 3) * rpe_n1p(a.R);
@@ -260,6 +280,14 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   wait_dma_all();
   __syncthreads();
+  if constexpr (KSPLIT) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) qf[qb][kk] = lds_rd128(qimg + (uint32_t)(fa.rm[kk] + qb * 32 * 2 * D));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // (the first iteration requests V tile 2 into the slot the Q images sit in)
+  }
   // per-lane LDS addresses of the fragment reads (ring base folded in; slot / block / step offsets are immediates;
   // KSPLIT: the wave's own 32-key block of every tile is folded in as well)
   const uint32_t khoff = (uint32_t)(kh * 32 * 2 * D);
@@ -842,24 +870,59 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   }
 
   // ---- epilogue: o = acc / l, L = m + ln(l) ----
+  if constexpr (KSPLIT) {
+    // Short sequences (round 4): O leaves through an LDS image of the wave's 32 rows -- 8-byte pieces into the swizzled row-major image,
+    // out again as whole 128-byte rows; a lane storing "its" row straight to global touches 64 cache lines per instruction, and at
+    // 512 keys the store tail is a visible part of the kernel.  The image sits behind the merge area (which the partner wave may
+    // still be reading); every wave is behind the sweep's last barrier.  (The 256-row form keeps the direct stores: its instantiations
+    // sit at the register cap of two waves per SIMD and the tail is < 1 % of a long sweep.)
+    static_assert(Cfg::NW * Cfg::MERGE + Cfg::NW * 32 * 2 * D <= 2 * NS * TILE, "the O images fit behind the merge area");
+    char* oimg = smem + Cfg::NW * Cfg::MERGE + w * (32 * 2 * D);
+    {
+      const int qb = kh;
+      const float l_tot = pair_sum((kh == 0 ? l_run[0][0] + l_run[0][1] : l_run[1][0] + l_run[1][1]));
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+      const int qrow = qrow0 + 32 * qb + lq;
+      auto put = [&]<int QB>() {
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    if (KSPLIT && qb != kh) continue;
-    const int qrow = qrow0 + 32 * qb + lq;
-    const float l_tot = pair_sum(l_run[qb][0] + l_run[qb][1]);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    if (qrow < M) {
-      uint16_t* orow = ob_ + (int64_t)qrow * a.os[2];
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
+          for (int g = 0; g < 4; ++g) {
+            u32x2 wv;
+            wv[0] = pack2<BF16>(oacc[QB][db][4 * g + 0] * inv, oacc[QB][db][4 * g + 1] * inv);
+            wv[1] = pack2<BF16>(oacc[QB][db][4 * g + 2] * inv, oacc[QB][db][4 * g + 3] * inv);
+            *reinterpret_cast<u32x2*>(oimg + rm_off<D>(lq, 4 * db + g) + 8 * hi) = wv;
+          }
+      };
+      if (kh == 0) put.template operator()<0>(); else put.template operator()<1>();
+      if (qrow < M && hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? ((kh == 0 ? m_run[0] : m_run[1]) + fast_log2(l_tot)) * kLn2 : -INFINITY;
+    }
+    const int orow0 = qrow0 + 32 * kh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 wv;
-          wv[0] = pack2<BF16>(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
-          wv[1] = pack2<BF16>(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
-          *reinterpret_cast<u32x2*>(orow + 32 * db + 8 * g + 4 * hi) = wv;
-        }
-      if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run[qb] + fast_log2(l_tot)) * kLn2 : -INFINITY;
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (l >> 3), slot = l & 7;
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(oimg + row * (2 * D) + slot * 16);
+      if (orow0 + row < M) *reinterpret_cast<u32x4*>(ob_ + (int64_t)(orow0 + row) * a.os[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
+    }
+  } else {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qrow0 + 32 * qb + lq;
+      const float l_tot = pair_sum(l_run[qb][0] + l_run[qb][1]);
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+      if (qrow < M) {
+        uint16_t* orow = ob_ + (int64_t)qrow * a.os[2];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2 wv;
+            wv[0] = pack2<BF16>(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
+            wv[1] = pack2<BF16>(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
+            *reinterpret_cast<u32x2*>(orow + 32 * db + 8 * g + 4 * hi) = wv;
+          }
+        if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run[qb] + fast_log2(l_tot)) * kLn2 : -INFINITY;
+      }
     }
   }
 }
