@@ -32,6 +32,9 @@
 #include <utility>
 #include "attn_fwd.h"
 
+#ifndef FAT5_FWD_ABL
+#define FAT5_FWD_ABL 0  // developer ablations of the pipelined block (timing / counters only, wrong results unless noted): 1 no row sums, 2 row sums by v_add_f32 (correct results), 4 v_mov for v_exp, 8 no conversion to 16 bit (the words stay zero)
+#endif
 namespace fat5 {
 
 template <int D, bool KSPLIT = false>
@@ -200,6 +203,16 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // n, n+16, n+32, n+48 form column n; SEL row 4G has ones for the k-groups of parity G%2, every other row is zero, so register 0 of
   // lane l ends up with the sum over both key halves (lanes l%32 and l%32 + 32) of ITS query column; registers 1..3 stay zero.
   f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  [[maybe_unused]] float lv[2] = {0.f, 0.f};  // (FAT5_FWD_ABL & 2)
+  auto abl_exp2 = [](float x) {
+    if constexpr ((FAT5_FWD_ABL & 4) != 0) {
+      float r;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
+      return r;
+    } else {
+      return asm_exp2(x);
+    }
+  };
   u32x4 sel;
   {
     const int i16 = l & 15;
@@ -579,17 +592,23 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         if constexpr (c == -2) { p0 = pc[0]; p1 = pc[1]; }
         else if constexpr (c == -1) { p0 = Pr[15][0]; p1 = Pr[15][1]; }  // (slot 15 of this block's array is free until gap 15)
         else { p0 = Pr[c][0]; p1 = Pr[c][1]; }
-        const uint32_t wd = asm_cvt_pk<BF16>(p0, p1);
+        uint32_t wd = 0u;
+        if constexpr ((FAT5_FWD_ABL & 8) == 0) wd = asm_cvt_pk<BF16>(p0, p1);
         if constexpr (c < 0) PB[1][1][(cr & 7) >> 1] = wd;
         else PBn[cq][cr >> 3][(cr & 7) >> 1] = wd;
       }
       // ---- VALU: exp of chunk g-1 ----
       if constexpr (g == 0) {
-        Pr[15][0] = asm_exp2(xc[0]);
-        Pr[15][1] = asm_exp2(xc[1]);
+        Pr[15][0] = abl_exp2(xc[0]);
+        Pr[15][1] = abl_exp2(xc[1]);
       } else {
-        Pr[g - 1][0] = asm_exp2(X[g - 1][0]);
-        Pr[g - 1][1] = asm_exp2(X[g - 1][1]);
+        Pr[g - 1][0] = abl_exp2(X[g - 1][0]);
+        Pr[g - 1][1] = abl_exp2(X[g - 1][1]);
+      }
+      if constexpr ((FAT5_FWD_ABL & 2) != 0) {  // (sums of the unrounded probabilities, the round-2 form)
+        constexpr int e = g == 0 ? 15 : g - 1;
+        asm_add(lv[g == 0 ? 1 : (e >> 3)], Pr[e][0]);
+        asm_add(lv[g == 0 ? 1 : (e >> 3)], Pr[e][1]);
       }
       // ---- VALU: exponent arguments of chunk g ----
       {
@@ -622,7 +641,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       }
       // chunk c is packed in gap c + 2: a group of four words is summed two gaps after its last one (the previous block's last group,
       // whose words 2, 3 were packed in gaps 0, 1, in gap 3); nothing reads lacc before the end of the sweep
-      if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+      if constexpr ((FAT5_FWD_ABL & 3) != 0) {
+      } else if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
       else if constexpr (g == 7) mfma16_acc<BF16>(lacc[0], sel, PBn[0][0]);
       else if constexpr (g == 11) mfma16_acc<BF16>(lacc[0], sel, PBn[0][1]);
       else if constexpr (g == 14) mfma16_acc<BF16>(lacc[1], sel, PBn[1][0]);
@@ -661,7 +681,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     PB[1][1][2] = pack2<BF16>(pc[0], pc[1]);
     PB[1][1][3] = pack2<BF16>(q0, q1);
     asm volatile("s_nop 1" : "+v"(PB[1][1]));  // (VALU write -> asm MFMA read: two wait states by hand)
-    mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+    if constexpr ((FAT5_FWD_ABL & 3) == 0) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+    if constexpr ((FAT5_FWD_ABL & 2) != 0) lv[1] += q0 + q1;
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -677,6 +698,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     for (int qb = 0; qb < 2; ++qb) {
       l_run[qb][0] += 0.5f * lacc[qb][0];
       lacc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr ((FAT5_FWD_ABL & 2) != 0) {  // (per-lane sums over the lane's own key half: pair_sum adds the halves)
+        l_run[qb][0] += lv[qb];
+        lv[qb] = 0.f;
+      }
     }
   };
 
@@ -863,7 +888,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
         const bool visible = !(a.causal && qrow0 + 32 * qb + lq + P < 0);  // (a row without any visible key has l = 0 exactly)
         bad = bad || !(lt < 0x1p100f) || (visible && lt < 0x1p-40f);
       }
-      if (bad) *sFlag = 1;
+      if (bad && (FAT5_FWD_ABL & 13) == 0) *sFlag = 1;  // (ablations with wrong sums must not take the exact pass)
       __syncthreads();
       if (*sFlag == 0) break;
     }
