@@ -342,11 +342,16 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     // Measured, backward incl. the reduction launch, fused 64-wide against the library's previous choice (tools/attn_time.py, us):
     //   (4,12,512) T5 bias 30.4 vs 35.6, none 19.5 vs 23.2; (4,12,1024) 72.2 vs 76.9, 56.5 vs 60.0; (8,12,512) 49.2 vs 53.3, 35.4 vs 37.1;
     //   (2,12,512) 29.3 vs 40.8; (2,12,1024) 43.7 vs 51.8; (2,12,2048) 118.8 vs 128.6, 100.8 vs 111.2   -> up to 1.5 rounds of the chip;
-    //   (4,12,2048): 3 rounds, 194.6 vs 196.4 -- even: the last round is still two workgroup lengths long;
+    //   second sweep, fused vs not (T5 bias / none): (4,12,1280) 87.6 vs 102.1 / 76.5 vs 86.7; (4,12,1536) 136 vs 176 / 120 vs 150; (4,12,2048) 192.9-194.8 vs 196.0-199.4 / 171 vs 177;
+    //   (4,12,2560) 291 vs 327 / 265 vs 289; (4,12,3072) 414 vs 424 / 376 vs 403; (4,12,3584) 548 vs 555 / 511 vs 501; (4,12,4096) 671 vs 650 / 625 vs 619;
+    //   (16,12,512) 79.9 vs 89.1 / 62.3 vs 71.2; (16,12,1024) 223 vs 217 / 194 vs 189; (8,12,1024) 117 vs 125 / 98 vs 104; (2,12,4096) 351 vs 350; (1,12,8192) 670 vs 752;
+    //   (1,12,4096) 214 vs 202 (the one miss inside the rule) -> up to 1152 workgroups (4.5 rounds) on roughly square problems;
     //   causal (4,12,512) 39.0 vs 33.7, (4,12,1024) 83.6 vs 61.7: the diagonal steps of the 64-wide bodies are unpipelined -> never.
     const long wq = bh * ((p->M + 255) / 256), tot = wg256 + wq;
+    constexpr long FUSED64_MAX_WG = 1152;
     // (a call that forces or forbids one of the 64-wide bodies / launch forms keeps that choice)
-    const bool rule = !p->causal && tot <= 384 && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    const bool squarish = 2 * (p->M < p->N ? p->M : p->N) >= (p->M < p->N ? p->N : p->M);
+    const bool rule = !p->causal && (tot <= 384 || (tot <= FUSED64_MAX_WG && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }
   if (L.fused64) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 111 /* 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+#define FAT5_VERSION 112 /* 0.1.2 (112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
                             AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_*, fat5_adamw_scale_step_dev */
 
 enum fat5_status {

@@ -257,6 +257,7 @@ def test_bwd64_mixed_launch_matches_the_256_key_launch(B, H, M, N, causal, mode)
 
 @pytest.mark.parametrize("B,H,M,N,causal,mode,md", [
     (4, 12, 512, 512, False, "rpe", 128),     # cfg2: 96 + 96 workgroups side by side
+    (4, 12, 1536, 1536, False, "rpe", 128),   # 576 workgroups on 256 CUs: dQ workgroups queue behind the dK/dV ones
     (2, 3, 1024, 1024, False, "none", 128),
     (1, 2, 2048, 2048, True, "rpe", 128),     # causal: masked (general) steps produce their statistics the same way
     (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: the last step's rows past M (raw L reads as zero there), a key tail

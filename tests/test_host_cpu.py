@@ -34,7 +34,7 @@ def test_exports_match_header(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fat5_version() == 111
+    assert lib.fat5_version() == 112
     assert lib.fat5_sizeof_attn_params() == ctypes.sizeof(_lib.AttnParams)
 
 
@@ -290,12 +290,16 @@ def test_dispatch_rules_are_pinned():
     rpe = dict(bias_mode=L.BIAS_RPE1D, radius=128, need_dbias=True)
     dense = dict(bias_mode=L.BIAS_DENSE, need_dbias=True)
     cases = [
-        # the three headline shapes (T5 bias): one launch of both 64-wide backward bodies at S = 512 (round 4); mixed dK/dV launch at 2048; 64-wide everywhere at 8192
+        # the three headline shapes (T5 bias): one launch of both 64-wide backward bodies at S = 512 (round 4); the same up to 1152 workgroups (S = 3072); mixed dK/dV launch above; 64-wide everywhere at 8192
         (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(dq="32row", dkdv="32key", fused="1")),   # causal: the 32-wide bodies side by side
-        (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4", fused="0")),
+        (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
+        (dict(B=4, H=12, M=3072, N=3072, **rpe), dict(dq="64row", dkdv="64key", fused="1")),     # (1152 workgroups: the last size that takes the one-launch form)
+        (dict(B=4, H=12, M=3584, N=3584, **rpe), dict(dq="32row", dkdv="64key", fused="0")),
+        (dict(B=16, H=12, M=512, N=512, **rpe), dict(dq="64row", dkdv="64key", fused="1")),
+        (dict(B=4, H=12, M=2048, N=512, **rpe), dict(dq="32row", dkdv="32key")),                 # (480 workgroups, not roughly square: not the 64-wide one-launch form)
         (dict(B=4, H=12, M=8192, N=8192, **rpe), dict(fwd="64row", dq="64row", dkdv="64key")),
         (dict(B=4, H=12, M=8192, N=8192), dict(fwd="64row", dq="64row", dkdv="64key")),
         (dict(B=4, H=12, M=4096, N=4096), dict(fwd="64row", dq="64row", dkdv="64key")),
