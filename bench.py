@@ -544,6 +544,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one (4,12,S,64) batch per rank; strong = ONE batch split over the ranks by (batch, head) units")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-steps", type=int, default=1, help="steps captured per HIP graph (N = 1 only; the timed region still runs exactly --steps steps)")
     ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
     args = ap.parse_args()
 
@@ -615,6 +616,18 @@ def main():
                 step_local()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+    # several steps per replay: the same launches in the same order, one host call per U steps (single-process runs only: with
+    # more ranks every step hands its gradient to the reducer)
+    U = max(1, args.graph_steps) if (graph is not None and world == 1) else 1
+    graph_u = None
+    if U > 1:
+        graph_u = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph_u, stream=side):
+                for _ in range(U):
+                    step_local()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
 
     from flasht5_amd.sharding import OverlappedGradReduce
     reducer = OverlappedGradReduce(plan.dbias) if (world > 1 and mode != "none") else None
@@ -650,8 +663,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if graph_u is not None:
+        for _ in range(args.steps // U):
+            graph_u.replay()
+        for _ in range(args.steps % U):
+            step()
+    else:
+        for _ in range(args.steps):
+            step()
     if reducer is not None:
         reducer.drain()  # every step's all-reduce finishes inside the timed region
     torch.cuda.synchronize()
