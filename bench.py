@@ -544,7 +544,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one (4,12,S,64) batch per rank; strong = ONE batch split over the ranks by (batch, head) units")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph-steps", type=int, default=1, help="steps captured per HIP graph (N = 1 only; the timed region still runs exactly --steps steps)")
+    ap.add_argument("--graph-steps", type=int, default=16, help="steps captured per HIP graph replay (the timed region still runs exactly --steps steps, "
+                    "every one the same launches on the same batch; 1 = one replay per step: a replay boundary costs ~5 us on this stack)")
     ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
     args = ap.parse_args()
 
@@ -616,21 +617,26 @@ def main():
                 step_local()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-    # several steps per replay: the same launches in the same order, one host call per U steps (single-process runs only: with
-    # more ranks every step hands its gradient to the reducer)
-    U = max(1, args.graph_steps) if (graph is not None and world == 1) else 1
-    graph_u = None
+    from flasht5_amd.sharding import OverlappedGradReduce
+    want_reduce = world > 1 and mode != "none"
+    # several steps per replay: the same launches in the same order, one host call per U steps.  With more than one rank every step's
+    # bias(-table) gradient is kept (one stream-ordered copy per step inside the graph, what the reducer's staging copy is at U = 1) and
+    # the U of them travel in ONE all-reduce per replay: every step's gradient is reduced exactly once, in buckets of U.
+    U = max(1, args.graph_steps) if graph is not None else 1
+    graph_u, stash = None, None
     if U > 1:
+        if want_reduce:
+            stash = torch.zeros((U,) + tuple(plan.dbias.shape), dtype=torch.float32, device=device)
         graph_u = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph_u, stream=side):
-                for _ in range(U):
+                for u in range(U):
                     step_local()
+                    if stash is not None:
+                        stash[u].copy_(plan.dbias)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-
-    from flasht5_amd.sharding import OverlappedGradReduce
-    reducer = OverlappedGradReduce(plan.dbias) if (world > 1 and mode != "none") else None
+    reducer = OverlappedGradReduce(stash if stash is not None else plan.dbias) if want_reduce else None
 
     def step():
         if graph is not None:
@@ -638,9 +644,13 @@ def main():
         else:
             step_local()
         if reducer is not None:
-            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI -- one all-reduce per step,
-            # asynchronous on RCCL's stream (overlaps the next step's kernels like DDP overlaps its buckets)
-            reducer.submit(plan.dbias)
+            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI -- one all-reduce per step (U > 1: per replay of U
+            # steps), asynchronous on RCCL's stream (overlaps the next step's kernels like DDP overlaps its buckets)
+            if stash is not None:
+                stash[0].copy_(plan.dbias)
+                reducer.submit(stash)
+            else:
+                reducer.submit(plan.dbias)
 
     # Untimed pre-warm, by wall clock: a step is ~60 us, so a fixed W would end long before the GPU has left its idle
     # clock (585 MHz -> ~1.95 GHz sustained) and before the host's graph-launch path is warm.
@@ -666,6 +676,8 @@ def main():
     if graph_u is not None:
         for _ in range(args.steps // U):
             graph_u.replay()
+            if reducer is not None:
+                reducer.submit(stash)
         for _ in range(args.steps % U):
             step()
     else:
@@ -706,7 +718,7 @@ def main():
                                    f"32-bucket T5 RPE bias ({mode} mode), sm_scale 0.125, (B,S,H,D)-strided inputs",
                        "global_batch": B if strong else B * world, "seq_len": S,
                        "parallelism": (f"units{world} ({units[1]} of {B * H} (batch, head) units per GPU)" if strong else f"dp{world}"),
-                       "bias_mode": mode, "launch": "hipGraph replay" if graph is not None else "eager C-ABI calls"},
+                       "bias_mode": mode, "launch": (f"hipGraph replay, {U} step(s) per replay" if graph is not None else "eager C-ABI calls")},
             "frac_of_peak": round(value / (PEAK_BF16_TFLOPS * world), 4),
             "per_gpu_tflops": round(value / world, 2),
         }
