@@ -933,6 +933,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   if (a.causal) n_end = min(N, m0 + BM + P);
   const int nt = n_end > 0 ? (n_end + 31) / 32 : 0;
   const int qw0 = m0 + 64 * w;  // first query row of this wave; block qb covers qw0 + 32*qb .. +31
+  FAT5_STAMP(10);
 
   // Q and dO fragments (B operands), delta = rowsum(o * do) (reference _bwd_preprocess, :516-556), row statistics
   u32x4 qf[2][KK], dof[2][KK], off_[2][KK];
@@ -977,6 +978,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
     }
   }
+  FAT5_STAMP(11);
   // (the fragments of the staged form are read after the prologue's wait; everything derived from them follows below)
   auto derive_rows = [&]() {
 #pragma unroll

@@ -41,7 +41,9 @@ def show(rows, title):
     for c_, col in zip(cols[1:], d.T):
         print(f"   -> {names[c_]:13s} {np.median(col):8.0f} ({col.max():8.0f})")
     if rows[:, 9].min() > 0:
-        for n_, k_ in (("DMAs issued", 7), ("table filled", 8), ("landed + barrier", 9)):
+        for n_, k_ in (("arguments decoded", 10), ("staging DMAs issued", 11), ("DMAs issued", 7), ("table filled", 8), ("landed + barrier", 9)):
+            if rows[:, k_].min() <= 0:
+                continue
             print(f"   prologue detail: entry -> {n_:18s} {np.median(rows[:, k_] - rows[:, 0]):8.0f}")
     tot = (rows[:, 6] - rows[:, 0]).astype(np.float64)
     print(f"   workgroup duration: median {np.median(tot):.0f}  max {tot.max():.0f}")
