@@ -54,23 +54,27 @@ static hipError_t launch_fused(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-// dense bias gradient by in-kernel batch reduction (attn_bwd_dbias.h): grid = H x ceil(M / 128)
-hipError_t CAT(launch_bwd_dbias_d, FAT5_INST_D)(const AttnArgs& a, int bf16, void* dbias, float* scratch, int grid, hipStream_t s) {
-  const size_t smem = BwdDbiasCfg<FAT5_INST_D, 4>::smem();
-  static size_t configured = 0;
-  if (bf16) {
-    auto kern = attn_bwd_dbias_kernel<FAT5_INST_D, true, 4>;
-    hipError_t e = set_smem(kern, smem, configured);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, (uint16_t*)dbias, scratch);
-  } else {
-    static size_t configured16 = 0;
-    auto kern = attn_bwd_dbias_kernel<FAT5_INST_D, false, 4>;
-    hipError_t e = set_smem(kern, smem, configured16);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a, (uint16_t*)dbias, scratch);
-  }
+// dense bias gradient by in-kernel batch reduction (attn_bwd_dbias.h): grid = H x ceil(M / 128) x key splits; a.lds_stage != 0 (D <= 64) selects the form
+// with two wave groups sharing the batch (512 threads, two waves per SIMD)
+template <typename K>
+static hipError_t launch_dbias_one(K kern, size_t smem, size_t& configured, int threads, const AttnArgs& a, void* dbias, float* scratch, int grid, hipStream_t s) {
+  hipError_t e = set_smem(kern, smem, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, a, (uint16_t*)dbias, scratch);
   return hipGetLastError();
+}
+hipError_t CAT(launch_bwd_dbias_d, FAT5_INST_D)(const AttnArgs& a, int bf16, void* dbias, float* scratch, int grid, hipStream_t s) {
+  static size_t cfg[4] = {0, 0, 0, 0};
+#if FAT5_INST_D <= 64
+  if (a.lds_stage) {
+    const size_t smem2 = BwdDbiasCfg<FAT5_INST_D, 4, true>::smem();
+    if (bf16) return launch_dbias_one(attn_bwd_dbias_split_kernel<FAT5_INST_D, true, 4>, smem2, cfg[2], 512, a, dbias, scratch, grid, s);
+    return launch_dbias_one(attn_bwd_dbias_split_kernel<FAT5_INST_D, false, 4>, smem2, cfg[3], 512, a, dbias, scratch, grid, s);
+  }
+#endif
+  const size_t smem = BwdDbiasCfg<FAT5_INST_D, 4>::smem();
+  if (bf16) return launch_dbias_one(attn_bwd_dbias_kernel<FAT5_INST_D, true, 4>, smem, cfg[0], 256, a, dbias, scratch, grid, s);
+  return launch_dbias_one(attn_bwd_dbias_kernel<FAT5_INST_D, false, 4>, smem, cfg[1], 256, a, dbias, scratch, grid, s);
 }
 
 #define DISPATCH(FN, a, bf16, bias, nw, grid, s)                                                     \

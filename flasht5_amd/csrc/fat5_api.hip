@@ -592,6 +592,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     AttnArgs ab = a;
     ab.n_mblk = (p->M + 127) / 128;
     ab.batch_inner = 0;
+    ab.lds_stage = (p->D <= 64 && !(p->variant & FAT5_V_DBIAS_NOSPLIT)) ? 1 : 0;  // (two wave groups sharing the batch: two waves per SIMD)
     // key tiles of a strip are independent: split them over workgroups until the grid covers the chip about twice
     const long strips = (long)p->H * ab.n_mblk, ntile = (p->N + 63) / 64;
     long nsplit = 1;

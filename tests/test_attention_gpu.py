@@ -852,10 +852,12 @@ def test_rpe_generator_cache_follows_table_updates():
     (6, 2, 192, 256, 64, False, torch.bfloat16),   # batch beyond the kernel's 4-element register chunk: fp32 pass-through scratch
     (9, 1, 130, 70, 32, True, torch.float16), (4, 2, 128, 192, 128, False, torch.bfloat16), (5, 2, 520, 77, 64, True, torch.bfloat16),
     (3, 2, 256, 320, 64, True, torch.bfloat16), (2, 2, 384, 256, 64, True, torch.bfloat16)])   # causal, N % 8 == 0, M != N: whole-chunk skips of the reduction
-def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatch):
+@pytest.mark.parametrize("split", [True, False])
+def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, split, monkeypatch):
     """(1, H, M, N) bias shared by the batch: the bias gradient comes from the batch-inner dBias kernel (attn_bwd_dbias.h) --
     no (B, H, M, N) staging (workspace O(B*H*M)), each term rounded to the bias dtype before the sum like the reference
-    (flash_attention_v2_bias.py:720, :214).  Against the oracle, and against the staged + reduced path it replaces."""
+    (flash_attention_v2_bias.py:720, :214).  Against the oracle, and against the staged + reduced path it replaces.
+    split: two wave groups sharing the batch (round 4, D <= 64; the default) / the one-group form."""
     import ctypes
     from flasht5_amd.flash_attention_v2_bias import AttentionPlan
     from flasht5_amd import _lib
@@ -864,7 +866,7 @@ def test_dense_dbias_batch_inner_kernel(B, H, M, N, D, causal, dtype, monkeypatc
     res = {}
     for mode in ("2", "0"):  # 2: the batch-inner kernel also below its size threshold; 0: the staged path
         plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=0.25,
-                             variant=_lib.V_DBIAS_INKERNEL if mode == "2" else _lib.V_DBIAS_STAGED)
+                             variant=(_lib.V_DBIAS_INKERNEL | (0 if split else _lib.V_DBIAS_NOSPLIT)) if mode == "2" else _lib.V_DBIAS_STAGED)
         plan.forward()
         plan.dbias.fill_(float("nan"))
         plan.ws.view(torch.uint8).fill_(255)  # (NaN patterns: with a causal mask the staged path must not read what the dQ kernel never wrote)
