@@ -235,7 +235,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   return FAT5_OK;
 }
 
-static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
+static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const long bh = (long)p->B * p->H;  // workspace layout and kernel variants follow the full problem also for a unit range
   L.nw_q = pick_nw(bh * ((p->M + 127) / 128));
   L.nw_kv = pick_nw(bh * ((p->N + 127) / 128));
@@ -398,6 +398,30 @@ static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
     off = align_up(off + (size_t)bh * L.n_nblk * (2 * p->rpe_radius + 1) * sizeof(float), 256);
   L.total = off;
   return FAT5_OK;
+}
+
+// The layout is asked for two or three times per backward call (workspace size, stages, launches) and its mixed-launch model is a
+// search: the last answer is kept per thread, keyed on every argument the function reads.
+static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
+  struct Key {
+    int64_t v[20];
+    bool operator==(const Key& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+  };
+  const Key k = {{p->B, p->H, p->M, p->N, p->D, p->bias_mode, p->causal, (int64_t)p->variant, p->rpe_radius, p->dbias_batch, p->dbias_heads,
+                  p->bias_stride[0], p->bias_stride[1], p->unit_count, p->total_q, p->cu_seqlens_q != nullptr, p->dbias != nullptr,
+                  p->drpe1d != nullptr, p->drpe_table != nullptr, 0}};
+  thread_local Key last_k;
+  thread_local BwdLayout last_L;
+  thread_local int last_rc = -1;
+  if (last_rc >= 0 && last_k == k) {
+    L = last_L;
+    return last_rc;
+  }
+  const int rc = bwd_layout_compute(p, L);
+  last_k = k;
+  last_L = L;
+  last_rc = rc;
+  return rc;
 }
 
 size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
