@@ -96,9 +96,9 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   float dsum = 0.f;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    qf[kk] = *reinterpret_cast<const u32x4*>(qb + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
-    dof[kk] = *reinterpret_cast<const u32x4*>(dob + (int64_t)qrow_c * a.dos[2] + 16 * kk + 8 * hi);
-    const u32x4 of = *reinterpret_cast<const u32x4*>(ob + (int64_t)qrow_c * a.os[2] + 16 * kk + 8 * hi);
+    qf[kk] = load_frag16(qb + (int64_t)qrow_c * a.qs[2], kk, hi, a.dvalid);
+    dof[kk] = load_frag16(dob + (int64_t)qrow_c * a.dos[2], kk, hi, a.dvalid);
+    const u32x4 of = load_frag16(ob + (int64_t)qrow_c * a.os[2], kk, hi, a.dvalid);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dsum = fmaf(cvt_lo<BF16>(of[j]), cvt_lo<BF16>(dof[kk][j]), dsum);
@@ -155,10 +155,10 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
     for (int r = 0; r < 16; ++r) dqacc[i][r] = 0.f;
 
   DmaStage<D, BN, NT> kst, vst;  // K / V tiles global -> LDS directly (see the dK/dV body)
-  kst.init(a.ks[2], tid);
-  vst.init(a.vs[2], tid);
-  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
-  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
+  kst.init(a.ks[2], tid, a.dvalid);
+  vst.init(a.vs[2], tid, a.dvalid);
+  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, a.dvalid);
+  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, a.dvalid);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   if (nt > 0) {
     kst.issue(krs, 0, smem, tid);
@@ -359,7 +359,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
         u32x2 wv;
         wv[0] = pack2<BF16>(dqacc[db][4 * g + 0] * scale, dqacc[db][4 * g + 1] * scale);
         wv[1] = pack2<BF16>(dqacc[db][4 * g + 2] * scale, dqacc[db][4 * g + 3] * scale);
-        *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
+        if (32 * db + 8 * g + 4 * hi < a.dvalid) *reinterpret_cast<u32x2*>(drow + 32 * db + 8 * g + 4 * hi) = wv;
       }
   }
 }
@@ -440,8 +440,8 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   u32x4 kf[KK], vf[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
-    kf[kk] = *reinterpret_cast<const u32x4*>(kb_ + (int64_t)krow_c * a.ks[2] + 16 * kk + 8 * hi);
-    vf[kk] = *reinterpret_cast<const u32x4*>(vb + (int64_t)krow_c * a.vs[2] + 16 * kk + 8 * hi);
+    kf[kk] = load_frag16(kb_ + (int64_t)krow_c * a.ks[2], kk, hi, a.dvalid);
+    vf[kk] = load_frag16(vb + (int64_t)krow_c * a.vs[2], kk, hi, a.dvalid);
   }
 
   // RPE: table + per-wave private diagonal accumulators in LDS
@@ -516,10 +516,10 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   // waves per SIMD, and every spilled register is a scratch round trip on the critical path of a 1-2 waves/SIMD grid)
   using Dma = DmaStage<D, BMQ, NT>;
   Dma qdm, dodm;
-  qdm.init(a.qs[2], tid);
-  dodm.init(a.dos[2], tid);
-  const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, D);
-  const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, D);
+  qdm.init(a.qs[2], tid, a.dvalid);
+  dodm.init(a.dos[2], tid, a.dvalid);
+  const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb, a.qs[2], M, a.dvalid);
+  const __amdgpu_buffer_rsrc_t dors = make_rows_rsrc(dob, a.dos[2], M, a.dvalid);
   const uint32_t qstride_b = (uint32_t)a.qs[2] * 2u, dostride_b = (uint32_t)a.dos[2] * 2u;
   const __amdgpu_buffer_rsrc_t brs = make_rows_rsrc(bias_dma ? bbase + n0 : dob, bias_dma ? a.bs[2] : a.dos[2], M,
                                                     bias_dma ? min(BNK, N - n0) : D);
@@ -530,7 +530,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   const uint16_t* ob = SELFD ? a.o + ooff + (int64_t)h * a.os[1] : nullptr;
   const __amdgpu_buffer_rsrc_t ors = make_rows_rsrc(SELFD ? ob : dob, SELFD ? a.os[2] : a.dos[2], M, D);
   Dma odm;
-  odm.init(a.os[2], tid);
+  odm.init(a.os[2], tid, a.dvalid);
   const uint32_t ostride_b = (uint32_t)a.os[2] * 2u;
   // Row statistics of a tile, staged in the form the MFMA accumulators are INITIALISED with (C operand of the first
   // k-step instead of zero): S' = Q K^T - L/scale, so that p = exp2(S'*c2 + bias) needs no per-element "+ (-L)", and
@@ -848,8 +848,10 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
         wk[1] = pack2<BF16>(dkacc[db][4 * g + 2] * scale, dkacc[db][4 * g + 3] * scale);
         wv[0] = pack2<BF16>(dvacc[db][4 * g + 0], dvacc[db][4 * g + 1]);
         wv[1] = pack2<BF16>(dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]);
-        *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * hi) = wk;
-        *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
+        if (32 * db + 8 * g + 4 * hi < a.dvalid) {
+          *reinterpret_cast<u32x2*>(dkrow + 32 * db + 8 * g + 4 * hi) = wk;
+          *reinterpret_cast<u32x2*>(dvrow + 32 * db + 8 * g + 4 * hi) = wv;
+        }
       }
   }
 }

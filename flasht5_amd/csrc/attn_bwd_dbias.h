@@ -84,8 +84,8 @@ FAT5_DEV void attn_bwd_dbias_body(const AttnArgs& a, uint16_t* __restrict__ dbia
   FragAddr<D> fa;
   fa.init(l);
   DmaStage<D, BN, NT> kst, vst;
-  kst.init(a.ks[2], tid);
-  vst.init(a.vs[2], tid);
+  kst.init(a.ks[2], tid, a.dvalid);
+  vst.init(a.vs[2], tid, a.dvalid);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
   const float c2 = a.scale * kLog2e;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -108,8 +108,8 @@ FAT5_DEV void attn_bwd_dbias_body(const AttnArgs& a, uint16_t* __restrict__ dbia
       const uint16_t* dob = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1] + (int64_t)qrow_c * a.dos[2];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        qf[i][kk] = *reinterpret_cast<const u32x4*>(qb + 16 * kk + 8 * hi);
-        dof[i][kk] = *reinterpret_cast<const u32x4*>(dob + 16 * kk + 8 * hi);
+        qf[i][kk] = load_frag16(qb, kk, hi, a.dvalid);
+        dof[i][kk] = load_frag16(dob, kk, hi, a.dvalid);
       }
       const int64_t so = ((int64_t)b * a.H + h) * M + qrow_c;
       const float Lq = a.lse[so];
@@ -122,8 +122,8 @@ FAT5_DEV void attn_bwd_dbias_body(const AttnArgs& a, uint16_t* __restrict__ dbia
       const int b = c0 + EL(i);
       const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
       const uint16_t* vb_ = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
-      const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
-      const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb_, a.vs[2], N, D);
+      const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, a.dvalid);
+      const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb_, a.vs[2], N, a.dvalid);
       char* dst = smem + (g * 2 + buf) * Cfg::STAGE;
       kst.issue(krs, (uint32_t)(t * BN) * kstride_b, dst, tid);
       vst.issue(vrs, (uint32_t)(t * BN) * vstride_b, dst + Cfg::KRM, tid);

@@ -286,6 +286,7 @@ struct AttnArgs {
   int32_t part_rows2;       // ... and a 256-key workgroup j owns rows 2j, 2j + 1 of them
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
+  int32_t dvalid;           // valid head-dim columns: = D except head_dim 16, which runs the D = 32 instantiations with columns 16..31 read as zeros and never written
   int32_t lds_stage;        // 64-wide backward bodies: the register-resident operands arrive / the outputs leave through wave-private LDS images (set by the launcher when the LDS fits)
   float scale;
 };
@@ -332,6 +333,12 @@ FAT5_DEV __amdgpu_buffer_rsrc_t make_rows_rsrc(const uint16_t* base, int64_t row
   const int64_t bytes = nrows > 0 ? ((int64_t)(nrows - 1) * row_stride + D) * 2 : 0;
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
                                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// 16-byte operand fragment of a row: columns 16 kk + 8 hi .. + 7 (zeros beyond the valid columns)
+FAT5_DEV u32x4 load_frag16(const uint16_t* row, int kk, int hi, int dvalid) {
+  if (16 * kk + 8 * hi >= dvalid) return u32x4{0u, 0u, 0u, 0u};
+  return *reinterpret_cast<const u32x4*>(row + 16 * kk + 8 * hi);
 }
 
 // Row staging for row-major images only (one 16-byte chunk of one row per work item).
@@ -418,11 +425,15 @@ struct DmaStage {
                     PER % NV == 0, "unsupported tile split");
   uint32_t voff[NV];    // this lane's byte offset inside a tile for pieces 0 .. NV-1
   uint32_t piece_step;  // bytes between the rows of pieces i and i + NV (wave-uniform)
-  FAT5_DEV void init(int64_t row_stride, int tid) {
+  // dvalid < D: the source rows hold only dvalid columns -- the pieces beyond them get an out-of-range offset (bit 31: every descriptor
+  // here is shorter than 2 GiB) and arrive as zeros, like rows past the end
+  FAT5_DEV void init(int64_t row_stride, int tid, int dvalid = D) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int row = tid / C + RP * v, slot = tid % C;
-      voff[v] = (uint32_t)(row * row_stride * 2 + ((SWZ ? (slot ^ swz<D>(row)) : slot) << 4));
+      const int src = SWZ ? (slot ^ swz<D>(row)) : slot;  // (the image is lane-linear: the swizzle is applied to the source chunk)
+      voff[v] = (uint32_t)(row * row_stride * 2 + (src << 4));
+      if (8 * src >= dvalid) voff[v] = 0x80000000u;
     }
     piece_step = (uint32_t)(RP * NV * row_stride * 2);
   }

@@ -137,7 +137,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   u32x4 qf[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk)
-    qf[kk] = *reinterpret_cast<const u32x4*>(qb + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
+    qf[kk] = load_frag16(qb + (int64_t)qrow_c * a.qs[2], kk, hi, a.dvalid);
 
   const float* sTa = sT;  // this lane's aligned copy of the table
   if constexpr (BIAS == FAT5_BIAS_RPE1D) sTa = sT + ((a.R - qrow) & 3) * rpe_n1p(a.R);
@@ -178,10 +178,10 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   f32x2 l_run;  // per-lane partial row sum (two interleaved chains: v_pk_add_f32)
 
   DmaStage<D, BN, NT> kst, vst;
-  kst.init(a.ks[2], tid);
-  vst.init(a.vs[2], tid);
-  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, D);
-  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, D);
+  kst.init(a.ks[2], tid, a.dvalid);
+  vst.init(a.vs[2], tid, a.dvalid);
+  const __amdgpu_buffer_rsrc_t krs = make_rows_rsrc(kb_, a.ks[2], N, a.dvalid);
+  const __amdgpu_buffer_rsrc_t vrs = make_rows_rsrc(vb, a.vs[2], N, a.dvalid);
   const uint32_t kstride_b = (uint32_t)a.ks[2] * 2u, vstride_b = (uint32_t)a.vs[2] * 2u;
 
   // first K/V tile (+ dense bias tile) in flight BEFORE the RPE table is fetched: one memory round trip for the prologue
@@ -494,7 +494,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         u32x2 wv;
         wv[0] = pack2<BF16>(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
         wv[1] = pack2<BF16>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-        *reinterpret_cast<u32x2*>(orow + 32 * db + 8 * g + 4 * hi) = wv;
+        if (32 * db + 8 * g + 4 * hi < a.dvalid) *reinterpret_cast<u32x2*>(orow + 32 * db + 8 * g + 4 * hi) = wv;
       }
     if (hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run + fast_log2(l_tot)) * kLn2 : -INFINITY;
   }

@@ -58,6 +58,10 @@ struct BwdLayout {
   int nw_q, nw_kv;
 };
 
+// head_dim 16 runs the D = 32 instantiations with AttnArgs::dvalid = 16: columns 16..31 are read as zeros (out-of-range DMA pieces, masked
+// fragment loads) and never written -- no padded copies of q / k / v / do in HBM (the reference's kernels take 16 natively, flash_attention_v2_bias.py:233-234)
+static inline int effD(const fat5_attn_params* p) { return p->D == 16 ? 32 : p->D; }
+
 int pick_nw(long ctas_at_nw4) {
   // measured at S = 512: the 4-wave tile wins down to ~0.75 workgroups per CU
   return ctas_at_nw4 < 160 ? 2 : 4;
@@ -65,7 +69,7 @@ int pick_nw(long ctas_at_nw4) {
 
 int check_common(const fat5_attn_params* p) {
   if (!p) return fail(FAT5_EINVAL, "params is NULL");
-  if (p->D != 32 && p->D != 64 && p->D != 128) return fail(FAT5_EINVAL, "head_dim %d unsupported (32, 64, 128; pad 16 to 32)", p->D);
+  if (p->D != 16 && p->D != 32 && p->D != 64 && p->D != 128) return fail(FAT5_EINVAL, "head_dim %d unsupported (16, 32, 64, 128)", p->D);
   if (p->dtype != FAT5_F16 && p->dtype != FAT5_BF16) return fail(FAT5_EINVAL, "dtype %d unsupported (f16, bf16)", p->dtype);
   if (p->B <= 0 || p->H <= 0 || p->M <= 0 || p->N <= 0) return fail(FAT5_EINVAL, "empty problem B=%d H=%d M=%d N=%d", p->B, p->H, p->M, p->N);
   if (p->bias_mode < 0 || p->bias_mode > 2) return fail(FAT5_EINVAL, "bias_mode %d", p->bias_mode);
@@ -98,6 +102,7 @@ void fill_common(const fat5_attn_params* p, AttnArgs& a) {
     a.bs[i] = p->bias_stride[i];
   }
   a.B = p->B; a.H = p->H; a.M = p->M; a.N = p->N;
+  a.dvalid = p->D;
   a.causal = p->causal; a.scale = p->sm_scale; a.R = p->rpe_radius;
   a.bias = (const uint16_t*)p->bias; a.rpe1d = p->rpe1d;
   a.cu_q = p->cu_seqlens_q; a.cu_k = p->cu_seqlens_k;
@@ -227,7 +232,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   const FwdChoice fc = fwd_choice(p);
   int nw = fc.nw;
   a.n_mblk = fc.n_mblk;
-  launch_fn fn = fc.fwd64 ? launch_fwd64_d64 : (p->D == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
+  launch_fn fn = fc.fwd64 ? launch_fwd64_d64 : (effD(p) == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
   const long grid = n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
@@ -443,7 +448,7 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  return (bwd_fusable(L, grid_q, grid_kv, p->D, p->variant) || L.fused64) ? 1 : 2;
+  return (bwd_fusable(L, grid_q, grid_kv, effD(p), p->variant) || L.fused64) ? 1 : 2;
 }
 
 // Which kernel bodies a problem runs, as text (tests pin the dispatch rules with it; no device needed, no pointer of `p` is followed)
@@ -456,7 +461,7 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  const bool fused = bwd_fusable(L, grid_q, grid_kv, p->D, p->variant);
+  const bool fused = bwd_fusable(L, grid_q, grid_kv, effD(p), p->variant);
   char kv[48];
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
@@ -496,7 +501,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   if (p->bias_mode == FAT5_BIAS_RPE1D) {
     // the dK/dV body keeps the table and one private diagonal accumulator per wave in LDS
     const size_t lds = L.kv64 ? (L.kv64_half ? smem_bwd_kv64h_d64(p->rpe_radius, p->bias_mode) : smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode))
-                     : p->D == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
+                     : effD(p) == 32 ? smem_bwd_kv_d32(L.nw_kv, p->rpe_radius, p->bias_mode)
                                   : (p->D == 64 ? smem_bwd_kv_d64(L.nw_kv, p->rpe_radius, p->bias_mode) : smem_bwd_kv_d128(L.nw_kv, p->rpe_radius, p->bias_mode));
     if (lds > 160 * 1024)
       return fail(FAT5_EINVAL, "bwd: rpe_radius %d needs %zu bytes of LDS (160 KiB per workgroup; radius <= 1024 fits every head_dim)", p->rpe_radius, lds);
@@ -558,10 +563,10 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const long full_q = bh * a.n_mblk, full_kv = bh * a.n_nblk;  // (variant choice: see fat5_attn_fwd)
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
   // side by side (attn_bwd_fused_kernel).  fat5_attn_params.variant & FAT5_V_NO_FUSE forbids it (tests / profiling: _lib.variant()).
-  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, p->D, p->variant);
+  const bool fuse = (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV) && bwd_fusable(L, full_q, full_kv, effD(p), p->variant);
   if (fuse) {
     a.n_kv_blocks = (int)grid_kv;
-    launch_fn fn = p->D == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
+    launch_fn fn = effD(p) == 32 ? launch_bwd_fused_d32 : (p->D == 64 ? launch_bwd_fused_d64 : launch_bwd_fused_d128);
     hipError_t e = fn(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused launch");
   } else if (L.fused64 && (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV)) {
@@ -574,14 +579,14 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   } else {
     // 1) dQ (+ delta)
     if (stages & FAT5_BWD_DQ) {
-      launch_fn fn = p->D == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
+      launch_fn fn = effD(p) == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
       if (L.q64) fn = launch_bwd_q64_d64;
       hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)grid_q, stream);
       if (e != hipSuccess) return hip_fail(e, "attn_bwd_q launch");
     }
     // 2) dK, dV, dBias
     if (stages & FAT5_BWD_DKDV) {
-      launch_fn fn = p->D == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
+      launch_fn fn = effD(p) == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
       if (L.kv64) fn = launch_bwd_kv64_d64;
       a.part_stride = a.n_nblk;
       hipError_t e = hipSuccess;
@@ -624,7 +629,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     ab.n_nblk = (int)nsplit;
     const long grid = strips * nsplit;
     typedef hipError_t (*dbias_fn)(const AttnArgs&, int, void*, float*, int, hipStream_t);
-    dbias_fn fn = p->D == 32 ? launch_bwd_dbias_d32 : (p->D == 64 ? launch_bwd_dbias_d64 : launch_bwd_dbias_d128);
+    dbias_fn fn = effD(p) == 32 ? launch_bwd_dbias_d32 : (p->D == 64 ? launch_bwd_dbias_d64 : launch_bwd_dbias_d128);
     hipError_t e = fn(ab, bf16, p->dbias, p->B > 4 ? (float*)(ws + L.scratch_off) : nullptr, (int)grid, stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_dbias launch");
   }

@@ -230,12 +230,6 @@ def _tracing():
     return torch.compiler.is_compiling()
 
 
-def _pad16(ts):
-    """head_dim 16 -> 32 by zero padding: scores and the first 16 output columns are unchanged (the kernels' smallest MFMA
-    block spans 32 head-dim rows of the P.V product)"""
-    return tuple(torch.nn.functional.pad(t, (0, 16)) for t in ts)
-
-
 class FlashAttentionAdditiveBias(torch.autograd.Function):
     """Same contract as the reference class (flash_attention_v2_bias.py:228-271)."""
 
@@ -246,9 +240,6 @@ class FlashAttentionAdditiveBias(torch.autograd.Function):
         assert Dk in {16, 32, 64, 128}
         if sm_scale is None:
             sm_scale = 1.0 / math.sqrt(Dq)
-        pad16 = Dk == 16
-        if pad16:
-            q, k, v = _pad16((q, k, v))
         if _tracing():
             o, L = torch.ops.fat5.flash_attn_v2_fwd(q, k, v, bias, bool(causal), float(sm_scale))
         else:
@@ -256,20 +247,15 @@ class FlashAttentionAdditiveBias(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, bias, o, L)
         ctx.sm_scale = sm_scale
         ctx.causal = causal
-        ctx.pad16 = pad16
-        return o[..., :16] if pad16 else o
+        return o
 
     @staticmethod
     def backward(ctx, do, *ignored):
         q, k, v, bias, o, L = ctx.saved_tensors
-        if ctx.pad16:
-            do = torch.nn.functional.pad(do, (0, 16))
         if _tracing():
             dq, dk, dv, ds = torch.ops.fat5.flash_attn_v2_bwd(o, do, q, k, v, bias, L, bool(ctx.causal), float(ctx.sm_scale))
         else:
             dq, dk, dv, ds = _attn_bwd(o, do, q, k, v, bias, None, 0, L, bool(ctx.causal), float(ctx.sm_scale), bias is not None)
-        if ctx.pad16:
-            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         return dq, dk, dv, (ds if bias is not None else None), None, None, None, None
 
 
@@ -290,10 +276,8 @@ def flash_attention_v2_bias(q, k, v, bias, causal=False, sm_scale=None):
         _check_bias(bias, q, k)
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
-    if D == 16:
-        q, k, v = _pad16((q, k, v))
     o = nat.bias_apply(q, k, v, bias, bool(causal), float(sm_scale))
-    return o[..., :16] if D == 16 else o
+    return o
 
 
 # ------------------------------------------------------------------------------------------------
@@ -382,26 +366,19 @@ class FlashAttentionRPE(torch.autograd.Function):
             raise ValueError(f"max_distance {max_distance} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
         if rpe_table.shape != (num_buckets, q.shape[1]):
             raise ValueError("rpe_table must be (num_buckets, n_heads)")
-        pad16 = D == 16
-        if pad16:
-            q, k, v = _pad16((q, k, v))
         rpe1d = _rpe1d_of(rpe_table, R, bidirectional, num_buckets, max_distance)
         o, L = _rpe_fwd(q, k, v, rpe1d, R, causal, sm_scale)
         ctx.save_for_backward(q, k, v, o, L, rpe1d, _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device))
-        ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype, pad16)
-        return o[..., :16] if pad16 else o
+        ctx.meta = (R, causal, sm_scale, num_buckets, rpe_table.dtype)
+        return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, L, rpe1d, idx = ctx.saved_tensors
-        R, causal, sm_scale, num_buckets, tdtype, pad16 = ctx.meta
+        R, causal, sm_scale, num_buckets, tdtype = ctx.meta
         need = ctx.needs_input_grad[3]
-        if pad16:
-            do = torch.nn.functional.pad(do, (0, 16))
         # the (H, 2R+1) diagonal sums are scattered into the (num_buckets, H) table by the reduction launch itself
         dq, dk, dv, dtable = _rpe_bwd(o, do, q, k, v, rpe1d, L, R, causal, sm_scale, need, idx, num_buckets)
-        if pad16:
-            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         if dtable is not None:
             dtable = dtable.to(tdtype)
         return dq, dk, dv, dtable, None, None, None, None, None
@@ -426,14 +403,12 @@ def flash_attention_v2_rpe(q, k, v, rpe_table, bidirectional=True, num_buckets=3
         raise ValueError("rpe_table must be (num_buckets, n_heads)")
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
-    if D == 16:
-        q, k, v = _pad16((q, k, v))
     if rpe_table.device != q.device:
         raise ValueError("rpe_table must live on q's device")
     idx = _pe.bucket_index32(R, bidirectional, num_buckets, max_distance, q.device)
     # (the C++ function builds the (H, 2R+1) generator from the table itself, one launch per call, never cached)
     o = nat.rpe_table_apply(q, k, v, rpe_table, idx, R, int(num_buckets), bool(causal), float(sm_scale))
-    return o[..., :16] if D == 16 else o
+    return o
 
 
 class FlashAttentionRPE1D(torch.autograd.Function):
@@ -452,24 +427,17 @@ class FlashAttentionRPE1D(torch.autograd.Function):
             raise ValueError(f"radius {radius} exceeds the RPE-mode limit {_lib.MAX_RPE_RADIUS}; use the dense bias")
         if rpe1d.shape != (q.shape[1], 2 * radius + 1):
             raise ValueError("rpe1d must be (n_heads, 2 * radius + 1)")
-        pad16 = D == 16
-        if pad16:
-            q, k, v = _pad16((q, k, v))
         r1 = rpe1d.detach().float().contiguous()
         o, L = _rpe_fwd(q, k, v, r1, radius, causal, sm_scale)
         ctx.save_for_backward(q, k, v, o, L, r1)
-        ctx.meta = (radius, causal, sm_scale, rpe1d.dtype, pad16)
-        return o[..., :16] if pad16 else o
+        ctx.meta = (radius, causal, sm_scale, rpe1d.dtype)
+        return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, L, r1 = ctx.saved_tensors
-        radius, causal, sm_scale, rdtype, pad16 = ctx.meta
-        if pad16:
-            do = torch.nn.functional.pad(do, (0, 16))
+        radius, causal, sm_scale, rdtype = ctx.meta
         dq, dk, dv, d1 = _rpe_bwd(o, do, q, k, v, r1, L, radius, causal, sm_scale, ctx.needs_input_grad[3])
-        if pad16:
-            dq, dk, dv = dq[..., :16], dk[..., :16], dv[..., :16]
         return dq, dk, dv, (d1.to(rdtype) if d1 is not None else None), None, None, None
 
 
@@ -488,12 +456,10 @@ def flash_attention_v2_rpe1d(q, k, v, rpe1d, radius, causal=False, sm_scale=None
         raise ValueError("rpe1d must be (n_heads, 2 * radius + 1)")
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
-    if D == 16:
-        q, k, v = _pad16((q, k, v))
     r1 = rpe1d.detach().float().contiguous()
     _check_rpe1d(r1, q.shape[1], radius, q.device)
     o = nat.rpe1d_apply(q, k, v, rpe1d, r1, radius, bool(causal), float(sm_scale))
-    return o[..., :16] if D == 16 else o
+    return o
 
 
 # ------------------------------------------------------------------------------------------------
@@ -510,8 +476,8 @@ def _check_varlen(q, k, v, cu_q, cu_k, rpe1d, radius):
         raise TypeError("q, k, v must share dtype float16 or bfloat16")
     if q.dim() != 3 or k.dim() != 3 or v.dim() != 3 or k.shape != v.shape or k.shape[1:] != q.shape[1:]:
         raise ValueError("packed attention takes q (total_q, H, D) and k, v (total_k, H, D)")
-    if q.shape[-1] not in (32, 64, 128):
-        raise ValueError("head_dim must be 32, 64 or 128")
+    if q.shape[-1] not in (16, 32, 64, 128):
+        raise ValueError("head_dim must be 16, 32, 64 or 128")
     for name, cu in (("cu_seqlens_q", cu_q), ("cu_seqlens_k", cu_k)):
         # the kernels dereference these on the device
         if cu.device != q.device or cu.dtype != torch.int32 or cu.dim() != 1 or not cu.is_contiguous():

@@ -375,10 +375,11 @@ def test_varlen_backward(causal):
     """packed batches are differentiable -- dq/dk/dv of the cu_seqlens path vs the per-sequence oracle,
     at config-4 class sizes and on ragged edge cases (empty query / key sequences, length-1 sequences)."""
     from flasht5_amd import flash_attn_varlen_func
-    H, D = 12, 64
+    H = 12
     g = torch.Generator().manual_seed(14)
-    for cu_q, cu_k, mq, mk in (([0, 256, 512, 704, 768], [0, 1024, 1792, 2816, 3072], 256, 1024),
-                               ([0, 5, 5, 6, 70, 71], [0, 9, 12, 12, 141, 142], 64, 129)):
+    for cu_q, cu_k, mq, mk, D in (([0, 256, 512, 704, 768], [0, 1024, 1792, 2816, 3072], 256, 1024, 64),
+                                  ([0, 5, 5, 6, 70, 71], [0, 9, 12, 12, 141, 142], 64, 129, 64),
+                                  ([0, 40, 41, 130], [0, 33, 97, 200], 89, 103, 16)):   # head_dim 16: native (no padded copies)
         q = torch.randn(cu_q[-1], H, D, generator=g).bfloat16().cuda()
         k = torch.randn(cu_k[-1], H, D, generator=g).bfloat16().cuda()
         v = torch.randn(cu_k[-1], H, D, generator=g).bfloat16().cuda()
@@ -407,12 +408,12 @@ def test_bad_arguments_raise():
 
 
 # ---- seeded shape fuzz: every bias mode / dtype / mask / tail combination the tile classifiers can see ------------
-def _fuzz_cases():
+def _fuzz_cases(seed=20260928, count=36, dims=(32, 64, 64, 64, 128)):
     import random
-    rnd = random.Random(20260928)
+    rnd = random.Random(seed)
     cases = []
-    for i in range(36):
-        D = rnd.choice([32, 64, 64, 64, 128])
+    for i in range(count):
+        D = rnd.choice(list(dims))
         M = rnd.choice([1, 17, 33, 64, 95, 128, 200, 257, 320, 449, 512, 700])
         N = rnd.choice([1, 19, 32, 64, 100, 128, 191, 256, 333, 448, 512, 640])
         cases.append((i, rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5]), M, N, D, rnd.choice([False, True]),
@@ -424,12 +425,24 @@ def _fuzz_cases():
 
 @pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-B{c[1]}H{c[2]}M{c[3]}N{c[4]}D{c[5]}{'c' if c[6] else ''}-{c[7]}")
 def test_fuzz_shapes_modes(case):
+    _run_fuzz_case(case, strided=False)
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(seed=1616, count=20, dims=(16,)), ids=lambda c: f"{c[0]}-B{c[1]}H{c[2]}M{c[3]}N{c[4]}D{c[5]}{'c' if c[6] else ''}-{c[7]}")
+def test_head_dim_16_native(case):
+    """head_dim 16 (the reference's smallest, flash_attention_v2_bias.py:233-234) through the C ABI as it is -- no padded copies: the D = 32
+    bodies read columns 16..31 as zeros and never write them.  (B, S, H, D)-strided inputs: the 16 columns behind a row belong to the NEXT head,
+    so a kernel that read or wrote them would show up in o / dq / dk / dv of the neighbour."""
+    _run_fuzz_case(case, strided=True)
+
+
+def _run_fuzz_case(case, strided):
     from flasht5_amd import flash_attention_v2_rpe
     _, B, H, M, N, D, causal, mode, dtype, md, scale = case
     if mode == "rpe_uni" and md <= 16:
         md = 64  # unidirectional: max_exact = 16, max_distance must exceed it (the reference formula divides by log(md/16))
     if mode.startswith("rpe"):
-        q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=case[0])
+        q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=case[0], strided=strided)
         g = torch.Generator().manual_seed(case[0] + 500)
         table = torch.randn(32, H, generator=g) * 0.5
         bidir = mode == "rpe"
@@ -447,7 +460,7 @@ def test_fuzz_shapes_modes(case):
         assert maxdiff(dt.cpu(), tl.grad) <= 1e-2 * max(1.0, tl.grad.abs().max().item()) + 3e-2
     else:
         kind = {"none": None, "dense_bh": "bh", "dense_1h": "1h", "dense_11": "11"}[mode]
-        q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, kind, seed=case[0])
+        q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, kind, seed=case[0], strided=strided)
         ref = oracle_all(q, k, v, b, do, scale, causal)
         got = run_dense(q, k, v, b, do, scale, causal)
         if b is not None:
@@ -912,7 +925,7 @@ def test_native_host_path_equals_ctypes_path():
     for native_fn, ctypes_fn, extra in pairs:
         for x, y in zip(grads(native_fn, extra), grads(ctypes_fn, extra)):
             assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
-    # no-bias call, D = 16 (zero-padded on the way in, sliced on the way out), grads flow through the pad
+    # no-bias call, D = 16
     q16, k16, v16, _, do16 = make_inputs(1, 2, 96, 96, 16, torch.bfloat16, None, seed=4)
     ln = [t.detach().clone().requires_grad_() for t in (q16, k16, v16)]
     lc = [t.detach().clone().requires_grad_() for t in (q16, k16, v16)]
