@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 112 /* 0.1.2 (112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+#define FAT5_VERSION 113 /* 0.1.3 (113: head_dim 16 native, FAT5_V_DBIAS_NOSPLIT; 112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
                             AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_*, fat5_adamw_scale_step_dev */
 
 enum fat5_status {
@@ -76,7 +76,7 @@ enum fat5_bias_mode {
  */
 typedef struct fat5_attn_params {
   /* ---- problem ---- */
-  int32_t B, H, M, N, D; /* D in {32, 64, 128} (16: pad to 32 in the caller) */
+  int32_t B, H, M, N, D; /* D in {16, 32, 64, 128} (16: the D = 32 kernels with columns 16..31 read as zeros and never written; rows are 32 bytes: strides stay multiples of 8 elements) */
   int32_t dtype;         /* FAT5_F16 | FAT5_BF16 : dtype of q,k,v,o,do,dq,dk,dv and of dense bias */
   int32_t causal;        /* bottom-right aligned: key n visible to query m iff m + (N-M) >= n */
   int32_t bias_mode;     /* enum fat5_bias_mode */
