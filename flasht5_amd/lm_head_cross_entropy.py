@@ -48,8 +48,9 @@ class LMHeadCrossEntropy(torch.autograd.Function):
         z_losses = torch.empty(rows, dtype=torch.float32, device=hidden.device)
         lse = torch.empty(rows, dtype=torch.float32, device=hidden.device)
         wt = weight.t()
+        buf = torch.empty((min(rows, chunk_rows), weight.shape[0]), dtype=hidden.dtype, device=hidden.device)  # ONE chunk of logits, reused (a fresh tensor per chunk is allocated before the previous one dies: two chunks alive)
         for s, e in _chunks(rows, chunk_rows):
-            logits = hidden[s:e] @ wt                                    # (chunk, V), dies at the end of the iteration
+            logits = torch.mm(hidden[s:e], wt, out=buf[:e - s])          # (chunk, V)
             l, z, ls = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
             losses[s:e], z_losses[s:e], lse[s:e] = l, z, ls
         ctx.save_for_backward(hidden, weight, labels, lse)
@@ -68,8 +69,9 @@ class LMHeadCrossEntropy(torch.autograd.Function):
         dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device) if need_w else None  # fp32 accumulation over chunks
         g = grad_losses.contiguous().float()
         wt = weight.t()
+        buf = torch.empty((min(rows, chunk_rows), weight.shape[0]), dtype=hidden.dtype, device=hidden.device)  # ONE chunk of logits, reused (a fresh tensor per chunk is allocated before the previous one dies: two chunks alive)
         for s, e in _chunks(rows, chunk_rows):
-            logits = hidden[s:e] @ wt
+            logits = torch.mm(hidden[s:e], wt, out=buf[:e - s])
             cross_entropy_bwd(g[s:e], logits, lse[s:e], labels[s:e], True, smoothing, logit_scale, lse_square_scale, ignore_index)
             if need_h:
                 dh[s:e] = _dh_gemm(logits, weight)                       # logits now holds dlogits (in place)
@@ -101,8 +103,9 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
         dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev) if need_w else None
         wt = weight.t()
         g = torch.full((min(rows, chunk_rows),), 1.0 / max(rows, 1), dtype=torch.float32, device=dev)
+        buf = torch.empty((min(rows, chunk_rows), weight.shape[0]), dtype=hidden.dtype, device=hidden.device)  # ONE chunk of logits, reused (a fresh tensor per chunk is allocated before the previous one dies: two chunks alive)
         for s, e in _chunks(rows, chunk_rows):
-            logits = hidden[s:e] @ wt
+            logits = torch.mm(hidden[s:e], wt, out=buf[:e - s])
             l, z, ls = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
             total += l.sum()
             ztotal += z.sum()
