@@ -764,27 +764,34 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
   FAT5_STAMP(4);
-  // ---- partial per-diagonal sums of this key block (before the dK / dV stores: see attn_bwd.h) ----
-  if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 16)) {
-    if (want_drpe) {
-      diag_flush();
-      far_neg = wave_sum(far_neg);
-      far_pos = wave_sum(far_pos);
-      if (l == 0) {
-        sD0[(2 * w) * n1] += far_neg;
-        sD0[(2 * w) * n1 + 2 * a.R] += far_pos;
-      }
-      __syncthreads();
-      float* out = a.drpe_part + ((int64_t)bh * a.part_stride + part_row) * n1;
-      for (int i2 = tid; i2 < n1; i2 += NT) {
-        float acc = 0.f;
+  // ---- partial per-diagonal sums of this key block.  Staged 256-key form: AFTER the dK / dV rows are on their way (the stores drain
+  // while the partial rows are summed; the images and the diagonal arrays are different LDS areas) ----
+  auto partial_rows = [&]() {
+    if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 16)) {
+      if (want_drpe) {
+        diag_flush();
+        far_neg = wave_sum(far_neg);
+        far_pos = wave_sum(far_pos);
+        if (l == 0) {
+          sD0[(2 * w) * n1] += far_neg;
+          sD0[(2 * w) * n1 + 2 * a.R] += far_pos;
+        }
+        // (LDS only: a __syncthreads here would also wait for the dK / dV stores when they are already in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* out = a.drpe_part + ((int64_t)bh * a.part_stride + part_row) * n1;
+        for (int i2 = tid; i2 < n1; i2 += NT) {
+          float acc = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 2 * Cfg::NW; ++ww) acc += sD0[ww * n1 + i2];
-        out[i2] = acc;
-        if (part_zero_next) out[n1 + i2] = 0.f;
+          for (int ww = 0; ww < 2 * Cfg::NW; ++ww) acc += sD0[ww * n1 + i2];
+          out[i2] = acc;
+          if (part_zero_next) out[n1 + i2] = 0.f;
+        }
       }
     }
-  }
+  };
+  const bool stores_first = stg && !HALF;
+  if (!stores_first) partial_rows();
 
   FAT5_STAMP(5);
   if constexpr (HALF) {
@@ -851,6 +858,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         *reinterpret_cast<u32x4*>(dvb + (int64_t)(kw0 + row) * a.dvs[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
       }
     }
+    if (stores_first) partial_rows();
     FAT5_STAMP(6);
     return;
   }
