@@ -81,6 +81,27 @@ def _ce_bwd_fake(dlosses, logits, lse, labels, inplace_backward, smoothing, logi
     return torch.empty(logits.shape, dtype=logits.dtype, device=logits.device)
 
 
+def cross_entropy_fwd_bwd_(logits: torch.Tensor, labels: torch.Tensor, dlosses: torch.Tensor, losses: torch.Tensor, z_losses: torch.Tensor,
+                           lse: torch.Tensor, smoothing: float, logit_scale: float, lse_square_scale: float, ignore_index: int) -> None:
+    """forward AND backward of every row in one launch (fat5_ce_fwd_bwd; the row is read once): writes losses / z_losses / lse (fp32, one
+    per row, caller-provided slices) and overwrites `logits` with d loss / d logits for the upstream gradients `dlosses` (fp32, one per row
+    or one element with stride 0 via expand).  Same values as cross_entropy_fwd followed by cross_entropy_bwd(inplace).  For callers that
+    know the upstream gradient before the forward (lm_head_cross_entropy, reduction="mean")."""
+    if logits.stride(-1) != 1 or logits.data_ptr() % 16 != 0:
+        raise RuntimeError("cross_entropy_fwd_bwd_ needs logits with unit inner stride and 16-byte alignment")
+    n_rows, n_cols = logits.shape
+    if n_rows == 0:
+        return
+    labels = labels.to(torch.int64).contiguous()
+    assert dlosses.dtype == torch.float32 and losses.dtype == z_losses.dtype == lse.dtype == torch.float32
+    assert losses.is_contiguous() and z_losses.is_contiguous() and lse.is_contiguous()
+    with _lib.on_device(logits.device):
+        _lib.check(_lib.load().fat5_ce_fwd_bwd(
+            logits.data_ptr(), labels.data_ptr(), dlosses.data_ptr(), dlosses.stride(0), losses.data_ptr(), z_losses.data_ptr(), lse.data_ptr(),
+            logits.data_ptr(), n_rows, n_cols, logits.stride(0), logits.stride(0), float(smoothing), float(logit_scale),
+            float(lse_square_scale), int(ignore_index), _lib.dtype_code(logits.dtype), _lib.stream_ptr(logits.device)), "fat5_ce_fwd_bwd")
+
+
 class CrossEntropyLoss(torch.autograd.Function):
     """Same contract as the reference class (cross_entropy_loss.py:280-385)."""
 

@@ -1064,6 +1064,37 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
   return FAT5_OK;
 }
 
+int fat5_ce_fwd_bwd(const void* logits, const int64_t* labels, const float* dlosses, int64_t dloss_stride, float* losses, float* z_losses,
+                    float* lse, void* dlogits, int64_t rows, int64_t n_cols, int64_t row_stride, int64_t drow_stride, float smoothing,
+                    float logit_scale, float lse_square_scale, int64_t ignore_index, int dtype, void* stream_) {
+  if (!logits || !labels || !dlosses || !losses || !z_losses || !lse || !dlogits) return fail(FAT5_EINVAL, "ce_fwd_bwd: null pointer");
+  if (!dtype_ok(dtype)) return fail(FAT5_EINVAL, "ce_fwd_bwd: bad dtype");
+  if (rows <= 0 || n_cols <= 0 || n_cols > 0x7fffffffLL || rows > 0x7fffffffLL) return fail(FAT5_EINVAL, "ce_fwd_bwd: bad shape");
+  const int v = vec_of(dtype);
+  const bool vecok = (n_cols % v == 0) && (row_stride % v == 0) && (drow_stride % v == 0) && aligned16(logits) && aligned16(dlogits);
+  if (!vecok) {  // the two launches: same results
+    const int rc = fat5_ce_fwd(logits, labels, losses, z_losses, lse, rows, n_cols, row_stride, smoothing, logit_scale, lse_square_scale,
+                               ignore_index, 0, dtype, stream_);
+    if (rc != FAT5_OK) return rc;
+    return fat5_ce_bwd(dlosses, dloss_stride, logits, lse, labels, dlogits, rows, n_cols, row_stride, drow_stride, smoothing, logit_scale,
+                       lse_square_scale, ignore_index, dtype, stream_);
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool hold = n_cols <= (int64_t)16 * 256 * v;
+  CE_DISPATCH({
+    if (hold)
+      hipLaunchKernelGGL((ce_fwd_bwd_kernel<DT, true>), dim3((int)rows), dim3(256), 0, stream, logits, labels, dlosses, dloss_stride, losses,
+                         z_losses, lse, dlogits, (int)n_cols, row_stride, drow_stride, smoothing, logit_scale, lse_square_scale, ignore_index);
+    else
+      hipLaunchKernelGGL((ce_fwd_bwd_kernel<DT, false>), dim3((int)rows), dim3(256), 0, stream, logits, labels, dlosses, dloss_stride, losses,
+                         z_losses, lse, dlogits, (int)n_cols, row_stride, drow_stride, smoothing, logit_scale, lse_square_scale, ignore_index);
+  })
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "ce_fwd_bwd launch");
+  return FAT5_OK;
+}
+
+
 // ============================================================================================
 // AdamWScale
 // ============================================================================================

@@ -682,4 +682,126 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-entropy forward AND backward of a row in one launch (round 4; the mean-loss form of lm_head -> loss knows every row's
+// upstream gradient before the forward runs, lm_head_cross_entropy.py): the two kernels above back to back inside one workgroup --
+// same arithmetic in the same order, so lse / losses / dlogits are bit-identical to the two launches -- with the row read ONCE:
+// HOLD keeps the row's logits in registers between the passes (up to 16 chunks of 256 x VEC columns: 32768 columns of a
+// 16-bit dtype); otherwise the second pass re-reads the row (L2).  dlogits may alias logits (each thread rewrites its own chunks).
+// Needs the vectorised layout (the C entry point falls back to the two launches otherwise).
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool HOLD>
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const void* logits_, const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ dlosses, int64_t dloss_stride,
+                                                         float* __restrict__ losses, float* __restrict__ z_losses, float* __restrict__ lse_,
+                                                         void* dlogits_, int n_cols, int64_t row_stride, int64_t drow_stride,
+                                                         float smoothing, float logit_scale, float lse_square_scale, int64_t ignore_index) {
+  typedef Elem<DT> X;
+  constexpr int VEC = X::VEC, NCH = 16;
+  __shared__ float sm[4], sl[4], ssum[4];
+  const int64_t row = blockIdx.x;
+  const typename X::T* x = reinterpret_cast<const typename X::T*>(logits_) + row * row_stride;
+  typename X::T* dx = reinterpret_cast<typename X::T*>(dlogits_) + row * drow_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wv_ = tid >> 6;
+  const bool has_smooth = smoothing > 0.f;
+  float fr[HOLD ? NCH : 1][VEC];
+  float sum_logits = 0.f, m = -INFINITY, l = 0.f;
+  auto chunk = [&](const float (&f)[VEC]) {  // (ce_fwd_kernel's per-chunk update; f stays unscaled for the second pass)
+    float t[VEC];
+    float cm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      t[j] = f[j] * logit_scale;
+      cm = fmaxf(cm, t[j]);
+      sum_logits += t[j];
+    }
+    const float mn = fmaxf(m, cm);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc += fast_exp2((t[j] - mn) * kLog2e);
+    l = l * fast_exp2((m - mn) * kLog2e) + acc;
+    m = mn;
+  };
+  if constexpr (HOLD) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = (k * 256 + tid) * VEC;
+      if (c < n_cols) {
+        X::load(x + c, fr[k]);
+        chunk(fr[k]);
+      }
+    }
+  } else {
+    for (int c = tid * VEC; c < n_cols; c += 256 * VEC) {
+      float f[VEC];
+      X::load(x + c, f);
+      chunk(f);
+    }
+  }
+  const float wm = wave_max(m);
+  l = (m == -INFINITY) ? 0.f : l * fast_exp2((m - wm) * kLog2e);
+  l = wave_sum(l);
+  sum_logits = wave_sum(sum_logits);
+  if (lane == 0) { sm[wv_] = wm; sl[wv_] = l; ssum[wv_] = sum_logits; }
+  __syncthreads();
+  const float gm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float gl = 0.f;
+  sum_logits = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    gl += (sm[i] == -INFINITY) ? 0.f : sl[i] * fast_exp2((sm[i] - gm) * kLog2e);
+    sum_logits += ssum[i];
+  }
+  const float lse = logf(gl) + gm;
+  const int64_t label = labels[row];
+  if (tid == 0) {
+    lse_[row] = lse;
+    float loss = 0.f, z = 0.f;
+    if (label != ignore_index) {
+      if (label >= 0 && label < n_cols) {
+        const float ll = X::ld1(x + label) * logit_scale;
+        loss = has_smooth ? (lse - smoothing * sum_logits / (float)n_cols - (1.f - smoothing) * ll) : (lse - ll);
+      } else {
+        loss = has_smooth ? smoothing * (lse - sum_logits / (float)n_cols) : 0.f;
+      }
+      z = lse_square_scale * lse * lse;
+      loss += z;
+    }
+    losses[row] = loss;
+    z_losses[row] = z;
+  }
+  __syncthreads();  // (in place: the label's logit has been read before anything of the row is overwritten)
+  // ---- backward (ce_bwd_kernel's arithmetic on the stored logits) ----
+  const float dloss = (label != ignore_index) ? dlosses[row * dloss_stride] : 0.f;
+  const float g = dloss * logit_scale;
+  const float zf = 1.f + 2.f * lse_square_scale * lse;
+  const float sp = 1.f - smoothing, sn = smoothing / (float)n_cols;
+  const float nl = -lse * kLog2e, ls2 = logit_scale * kLog2e;
+  auto grad = [&](float (&f)[VEC], const int c, const float mul) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float p = fast_exp2(fmaf(f[j], mul, nl)) * zf;
+      if (has_smooth) p = ((c + j == label) ? p - sp : p) - sn;
+      else p = (c + j == label) ? p - 1.f : p;
+      f[j] = g * p;
+    }
+    X::store(dx + c, f);
+  };
+  if constexpr (HOLD) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = (k * 256 + tid) * VEC;
+      if (c < n_cols) {
+        grad(fr[k], c, ls2);
+      }
+    }
+  } else {
+    for (int c = tid * VEC; c < n_cols; c += 256 * VEC) {
+      float f[VEC];
+      X::load(x + c, f);
+      grad(f, c, ls2);
+    }
+  }
+}
+
 }  // namespace fat5

@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .cross_entropy_loss import cross_entropy_fwd, cross_entropy_bwd
+from .cross_entropy_loss import cross_entropy_fwd, cross_entropy_bwd, cross_entropy_fwd_bwd_
 
 __all__ = ["lm_head_cross_entropy", "LMHeadCrossEntropy", "LMHeadCrossEntropyMean"]
 
@@ -97,20 +97,20 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
         rows = hidden.shape[0]
         need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dev = hidden.device
-        total = torch.zeros((), dtype=torch.float32, device=dev)
-        ztotal = torch.zeros((), dtype=torch.float32, device=dev)
+        losses = torch.empty(rows, dtype=torch.float32, device=dev)   # per-row values: summed ONCE at the end (fixed order)
+        zs = torch.empty(rows, dtype=torch.float32, device=dev)
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
         dh = torch.empty_like(hidden) if need_h else None
         dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev) if need_w else None
         wt = weight.t()
-        g = torch.full((min(rows, chunk_rows),), 1.0 / max(rows, 1), dtype=torch.float32, device=dev)
+        g = torch.full((1,), 1.0 / max(rows, 1), dtype=torch.float32, device=dev)
         buf = torch.empty((min(rows, chunk_rows), weight.shape[0]), dtype=hidden.dtype, device=hidden.device)  # ONE chunk of logits, reused (a fresh tensor per chunk is allocated before the previous one dies: two chunks alive)
         for s, e in _chunks(rows, chunk_rows):
             logits = torch.mm(hidden[s:e], wt, out=buf[:e - s])
-            l, z, ls = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
-            total += l.sum()
-            ztotal += z.sum()
             if need_h or need_w:
-                cross_entropy_bwd(g[:e - s], logits, ls, labels[s:e], True, smoothing, logit_scale, lse_square_scale, ignore_index)
+                # loss and gradient of the chunk's rows in one launch, the logits read once (fat5_ce_fwd_bwd)
+                cross_entropy_fwd_bwd_(logits, labels[s:e], g.expand(e - s), losses[s:e], zs[s:e], lse[s:e], smoothing, logit_scale,
+                                       lse_square_scale, ignore_index)
                 if need_h:
                     dh[s:e] = _dh_gemm(logits, weight)                   # logits now holds dlogits (in place)
                 if need_w:  # (fp32 accumulation over the chunks inside the GEMM: bf16 operands, fp32 output added to the accumulator)
@@ -118,6 +118,10 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
                         dw.addmm_(logits.t(), hidden[s:e])
                     else:
                         torch.addmm(dw, logits.t(), hidden[s:e], out_dtype=torch.float32, out=dw)
+            else:
+                l, z, _ = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
+                losses[s:e], zs[s:e] = l, z
+        total, ztotal = losses.sum(), zs.sum()
         if need_w and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
         ctx.save_for_backward(dh, dw)

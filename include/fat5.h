@@ -260,6 +260,13 @@ int fat5_ce_bwd(const float* dlosses, int64_t dloss_stride, const void* logits, 
                 const int64_t* labels, void* dlogits, int64_t rows, int64_t n_cols,
                 int64_t row_stride, int64_t dlogits_row_stride, float smoothing, float logit_scale,
                 float lse_square_scale, int64_t ignore_index, int dtype, void* hip_stream);
+/* Both in one launch, the row read once (round 4; for callers that know d loss / d losses before the forward: a mean or sum loss --
+ * flasht5_amd/lm_head_cross_entropy.py).  losses / z_losses / lse / dlogits are bit-identical to fat5_ce_fwd followed by fat5_ce_bwd;
+ * dlogits may be logits (in place). */
+int fat5_ce_fwd_bwd(const void* logits, const int64_t* labels, const float* dlosses, int64_t dloss_stride, float* losses,
+                    float* z_losses, float* lse, void* dlogits, int64_t rows, int64_t n_cols, int64_t row_stride,
+                    int64_t dlogits_row_stride, float smoothing, float logit_scale, float lse_square_scale, int64_t ignore_index,
+                    int dtype, void* hip_stream);
 
 /*
  * AdamWScale step over a group of tensors.  Replaces the reference optimizer's per-tensor / foreach op

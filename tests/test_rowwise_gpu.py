@@ -284,3 +284,39 @@ def test_native_rmsnorm_path_equals_custom_op_path():
         assert a.shape == b.shape and torch.equal(a, b)
     for a, b in zip(run(fused_add_rms_layernorm, True), run(FusedAddRMSLayernorm.apply, True)):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows,V,dtype,smooth,zl,scale", [
+    (37, 32768, torch.bfloat16, 0.1, 1e-4, 1.0),     # the row held in registers between the passes (16 chunks of 256 x 8 columns)
+    (5, 32768 + 8, torch.bfloat16, 0.0, 0.0, 1.0),   # one chunk too long: the second pass re-reads the row
+    (9, 50264, torch.float16, 0.1, 1e-4, 0.7),       # logit_scale != 1
+    (7, 16384, torch.float32, 0.05, 2e-4, 1.0),      # fp32: 16 chunks of 256 x 4
+    (11, 1001, torch.bfloat16, 0.1, 1e-4, 1.0),      # not vectorisable: the entry point runs the two launches
+    (3, 264, torch.bfloat16, 0.0, 1e-4, 1.3),        # fewer columns than threads
+])
+def test_ce_forward_and_backward_in_one_launch(rows, V, dtype, smooth, zl, scale):
+    """fat5_ce_fwd_bwd (round 4): losses, z-losses, lse and the in-place dlogits are bit-identical to fat5_ce_fwd followed by fat5_ce_bwd --
+    same arithmetic, the row read once.  Rows with ignore_index and with out-of-range labels included."""
+    from flasht5_amd.cross_entropy_loss import cross_entropy_fwd, cross_entropy_bwd, cross_entropy_fwd_bwd_
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    logits = (torch.randn(rows, V, generator=g) * 3).to(dtype).cuda()
+    labels = torch.randint(0, V, (rows,), generator=g).cuda()
+    labels[0] = -100
+    if rows > 4:
+        labels[3] = V + 5   # out of range (not ignored): cross_entropy_loss.py:100-103
+    dl = torch.randn(rows, generator=g).cuda()
+    a = logits.clone()
+    l0, z0, lse0 = cross_entropy_fwd(a, labels, None, smooth, scale, zl, -100)
+    cross_entropy_bwd(dl, a, lse0, labels, True, smooth, scale, zl, -100)
+    b = logits.clone()
+    l1, z1, lse1 = (torch.empty(rows, device="cuda") for _ in range(3))
+    cross_entropy_fwd_bwd_(b, labels, dl, l1, z1, lse1, smooth, scale, zl, -100)
+    assert torch.equal(l0, l1) and torch.equal(z0, z1) and torch.equal(lse0, lse1)
+    assert torch.equal(a, b)
+    # one broadcast upstream gradient (stride 0): what the mean loss passes
+    c = logits.clone()
+    g1 = torch.full((1,), 1.0 / rows, device="cuda")
+    cross_entropy_fwd_bwd_(c, labels, g1.expand(rows), l1, z1, lse1, smooth, scale, zl, -100)
+    d = logits.clone()
+    cross_entropy_bwd(g1.expand(rows).contiguous(), d, lse0, labels, True, smooth, scale, zl, -100)
+    assert torch.equal(c, d)
