@@ -28,16 +28,19 @@ def _chunks(rows, chunk_rows):
     return [(s, min(rows, s + chunk_rows)) for s in range(0, rows, chunk_rows)]
 
 
-def _dh_gemm(dlogits, weight):
+def _dh_gemm(dlogits, weight, out=None):
     """dlogits (m, V) @ weight (V, K) for a row chunk: m x K is a few dozen output tiles with a contraction over the whole vocabulary
     -- the library runs it on a fraction of the chip (212 us against 117 us for the chunk's logits GEMM of the same flops, measured
     at m = 2048, V = 32768, K = 768).  Split the contraction four ways (one batched GEMM, fp32 partials) and add the parts."""
     m, V = dlogits.shape
     K = weight.shape[1]
     if dlogits.dtype == torch.float32 or V % 4 or (m // 256) * (K // 128) >= 192 or not weight.is_contiguous():
-        return dlogits @ weight
+        r = dlogits @ weight
+        return r if out is None else out.copy_(r)
     part = torch.bmm(dlogits.view(m, 4, V // 4).transpose(0, 1), weight.view(4, V // 4, K), out_dtype=torch.float32)
-    return part.sum(0).to(dlogits.dtype)
+    if out is None:
+        return part.sum(0).to(dlogits.dtype)
+    return out.copy_(torch.sum(part, 0, out=torch.empty((m, K), dtype=torch.float32, device=part.device)))   # (one fp32 sum, one converting copy into the caller's rows)
 
 
 class LMHeadCrossEntropy(torch.autograd.Function):
@@ -101,7 +104,7 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
         zs = torch.empty(rows, dtype=torch.float32, device=dev)
         lse = torch.empty(rows, dtype=torch.float32, device=dev)
         dh = torch.empty_like(hidden) if need_h else None
-        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev) if need_w else None
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=dev) if need_w else None
         wt = weight.t()
         g = torch.full((1,), 1.0 / max(rows, 1), dtype=torch.float32, device=dev)
         buf = torch.empty((min(rows, chunk_rows), weight.shape[0]), dtype=hidden.dtype, device=hidden.device)  # ONE chunk of logits, reused (a fresh tensor per chunk is allocated before the previous one dies: two chunks alive)
@@ -112,15 +115,20 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
                 cross_entropy_fwd_bwd_(logits, labels[s:e], g.expand(e - s), losses[s:e], zs[s:e], lse[s:e], smoothing, logit_scale,
                                        lse_square_scale, ignore_index)
                 if need_h:
-                    dh[s:e] = _dh_gemm(logits, weight)                   # logits now holds dlogits (in place)
-                if need_w:  # (fp32 accumulation over the chunks inside the GEMM: bf16 operands, fp32 output added to the accumulator)
+                    _dh_gemm(logits, weight, out=dh[s:e])                # logits now holds dlogits (in place)
+                if need_w:  # (fp32 accumulation over the chunks inside the GEMM: bf16 operands, fp32 output added to the accumulator;
+                    #          the first chunk writes the accumulator: no 100 MB memset, no read of zeros)
                     if weight.dtype == torch.float32:
-                        dw.addmm_(logits.t(), hidden[s:e])
+                        torch.mm(logits.t(), hidden[s:e], out=dw) if s == 0 else dw.addmm_(logits.t(), hidden[s:e])
+                    elif s == 0:
+                        torch.mm(logits.t(), hidden[s:e], out_dtype=torch.float32, out=dw)
                     else:
                         torch.addmm(dw, logits.t(), hidden[s:e], out_dtype=torch.float32, out=dw)
             else:
                 l, z, _ = cross_entropy_fwd(logits, labels[s:e], None, smoothing, logit_scale, lse_square_scale, ignore_index)
                 losses[s:e], zs[s:e] = l, z
+        if rows == 0 and dw is not None:
+            dw.zero_()
         total, ztotal = losses.sum(), zs.sum()
         if need_w and dw.dtype != weight.dtype:
             dw = dw.to(weight.dtype)
