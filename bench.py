@@ -623,6 +623,10 @@ def main():
     # bias(-table) gradient is kept (one stream-ordered copy per step inside the graph, what the reducer's staging copy is at U = 1) and
     # the U of them travel in ONE all-reduce per replay: every step's gradient is reduced exactly once, in buckets of U.
     U = max(1, args.graph_steps) if graph is not None else 1
+    if U > 1 and args.steps % U:  # a step count that is not a multiple: a nearby replay length that divides it, so no step is left to single replays
+        div = [u for u in range(8, 33) if args.steps % u == 0]
+        if div:
+            U = min(div, key=lambda u: (abs(u - U), u))
     graph_u, stash = None, None
     if U > 1:
         if want_reduce:
