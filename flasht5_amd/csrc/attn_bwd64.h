@@ -112,6 +112,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   const int bh = b * a.H + h;
   const int M = a.M, N = a.N;
   const int n0 = nblk * BNK;
+  [[maybe_unused]] RpeTableRegs tabr;  // (the bias table's first round of loads leaves before every other request of the prologue)
+  if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 8)) tabr = rpe_table_load_first(a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, 64 * Cfg::NW);
   const uint16_t* qb = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
   const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
   const uint16_t* vb = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
@@ -322,7 +324,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   for (int rg = 0; rg < Cfg::RINGS; ++rg)
     for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + rg * Cfg::RING + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 8)) {
-    rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT);
+    rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT, tabr);
     for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
   }
   wait_dma_all();
@@ -929,6 +931,8 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   const int M = a.M, N = a.N;
   const int m0 = mblk * BM;
   if (m0 >= M) return;
+  [[maybe_unused]] RpeTableRegs tabr;
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) tabr = rpe_table_load_first(a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   const uint16_t* qb_ = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
   const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
   const uint16_t* vb_ = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
@@ -1070,7 +1074,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
   FAT5_STAMP(7);
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr);
   FAT5_STAMP(8);
   wait_dma_all();
   __syncthreads();

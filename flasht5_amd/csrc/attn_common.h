@@ -251,6 +251,44 @@ FAT5_DEV void rpe_table_fill(float* sT_raw, const float* rpe1d_h, int R, int tid
   }
 }
 
+// The same fill in two halves for the prologues that have other requests to send first: the loads of the first round go out at the top
+// of the kernel (eight per thread, values parked in registers), the LDS stores -- and further rounds of a long table -- follow where the
+// single-call form would sit.  One memory round trip less on the way to the first tile (cfg2: ~1 k cycles per workgroup).
+struct RpeTableRegs { float vv[8]; };
+FAT5_DEV RpeTableRegs rpe_table_load_first(const float* rpe1d_h, int R, int tid, int nthreads) {
+  const int n1 = 2 * R + 1;
+  RpeTableRegs r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) r.vv[2 * c + u] = rpe1d_h[min(max(tid + u * nthreads + c - kRpePad, 0), n1 - 1)];
+  return r;
+}
+FAT5_DEV void rpe_table_fill_rest(float* sT_raw, const float* rpe1d_h, int R, int tid, int nthreads, const RpeTableRegs& first) {
+  const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = tid + u * nthreads;
+      if (m < n1p) sT_raw[c * n1p + m] = first.vv[2 * c + u] * kLog2e;
+    }
+  for (int m0 = tid + 2 * nthreads; m0 < n1p; m0 += 2 * nthreads) {
+    float vv[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) vv[2 * c + u] = rpe1d_h[min(max(m0 + u * nthreads + c - kRpePad, 0), n1 - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int m = m0 + u * nthreads;
+        if (m < n1p) sT_raw[c * n1p + m] = vv[2 * c + u] * kLog2e;
+      }
+  }
+}
+
 }  // namespace fat5
 
 namespace fat5 {

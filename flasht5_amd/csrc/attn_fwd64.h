@@ -32,14 +32,25 @@
 #include <utility>
 #include "attn_fwd.h"
 
+#ifndef FAT5_TRACE
+#define FAT5_TRACE 0
+#endif
+#if FAT5_TRACE  // developer build: thread 0 keeps s_memtime stamps of the phases and leaves them in the first O row of its workgroup (tools/trace64.py --fwd)
+#define FAT5_FSTAMP(slot) do { if (threadIdx.x == 0) fstamp[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FAT5_FSTAMP(slot) do { } while (0)
+#endif
 #ifndef FAT5_FWD_ABL
 #define FAT5_FWD_ABL 0  // developer ablations of the pipelined block (timing / counters only, wrong results unless noted): 1 no row sums, 2 row sums by v_add_f32 (correct results), 4 v_mov for v_exp, 8 no conversion to 16 bit (the words stay zero)
+#endif
+#ifndef FAT5_FWD_NS_KSPLIT
+#define FAT5_FWD_NS_KSPLIT 4
 #endif
 namespace fat5 {
 
 template <int D, bool KSPLIT = false>
 struct Fwd64Cfg {
-  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = 4;  // NS ring slots per operand
+  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = KSPLIT ? FAT5_FWD_NS_KSPLIT : 4;  // NS ring slots per operand
   static constexpr int TILE = rm_bytes<D, BN>();
   static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + 16;
   static constexpr int MERGE = 32 * 64 * 4 + 1024;  // KSPLIT: per wave, one query block's O^T (32 registers x 64 lanes) + (m, l) -- inside the rings
@@ -129,6 +140,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
   constexpr int NKB = KSPLIT ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
+  [[maybe_unused]] long long fstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  FAT5_FSTAMP(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + Cfg::FLAG);
   float* sT = reinterpret_cast<float*>(smem + Cfg::TAB) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
@@ -141,6 +154,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   const int M = a.M, N = a.N;
   const int m0 = mblk * BM;
   if (m0 >= M) return;
+  [[maybe_unused]] RpeTableRegs tabr;  // (the bias table's first round of loads leaves before every other request of the prologue)
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) tabr = rpe_table_load_first(a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
   const uint16_t* qb_ = a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[1];
   const uint16_t* kb_ = a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[1];
   const uint16_t* vb_ = a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[1];
@@ -158,9 +173,9 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   // iteration requests V tile 2) and are read back as fragments after the prologue's wait (rows past M arrive as zeros); the
   // 256-row form loads them straight from global (its prologue is < 1 % of a long sweep).
   u32x4 qf[2][KK];
-  const uint32_t qimg = (uint32_t)(uintptr_t)smem + (uint32_t)(Cfg::VOFF + 2 * TILE + rg * 64 * 2 * D);
+  const uint32_t qimg = (uint32_t)(uintptr_t)smem + (uint32_t)(Cfg::VOFF + (NS - 2) * TILE + rg * 64 * 2 * D);
   if constexpr (KSPLIT) {
-    static_assert(2 * TILE >= (Cfg::NW / 2) * 64 * 2 * D, "the Q images of the workgroup's 64-row groups fit V slots 2 and 3");
+    static_assert(2 * TILE >= (Cfg::NW / 2) * 64 * 2 * D, "the Q images of the workgroup's 64-row groups fit the last two V slots");
     using SDma = DmaStage<D, 64, 64>;
     static_assert(SDma::PER == 8 && SDma::NV == 2, "eight 1-KiB pieces of 8 rows");
     SDma sq;
@@ -289,10 +304,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     else wait_dma_all();
     __syncthreads();
   };
+  FAT5_FSTAMP(1);
   stage_first();
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr);
+  FAT5_FSTAMP(2);
   wait_dma_all();
   __syncthreads();
+  FAT5_FSTAMP(3);
   if constexpr (KSPLIT) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -772,6 +790,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   }
   if (tb1 < tb0) tb0 = tb1 = ta;
 
+  FAT5_FSTAMP(4);
   for (int pass = 0;; ++pass) {
     const bool nomax = OPT && pass == 0;
 #pragma unroll
@@ -842,6 +861,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       exact_range.template operator()<0, false>(t, nt, slot, 0.f);
     }
 
+    FAT5_FSTAMP(5);
     if constexpr (KSPLIT) {
       // ---- merge the two key halves of every 64-row group through LDS: wave kh keeps query block kh, hands the other one over ----
       __syncthreads();  // the rings are free
@@ -894,6 +914,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
     }
   }
 
+  FAT5_FSTAMP(6);
   // ---- epilogue: o = acc / l, L = m + ln(l) ----
   if constexpr (KSPLIT) {
     // Short sequences (round 4): O leaves through an LDS image of the wave's 32 rows -- 8-byte pieces into the swizzled row-major image,
@@ -950,6 +971,14 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
       }
     }
   }
+#if FAT5_TRACE
+  FAT5_FSTAMP(7);
+  if (threadIdx.x == 0) {
+    long long* dst = reinterpret_cast<long long*>(ob_ + (int64_t)m0 * a.os[2]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = fstamp[i];
+  }
+#endif
 }
 
 template <int D, bool BF16, int BIAS, bool KSPLIT>
