@@ -324,6 +324,7 @@ struct AttnArgs {
   int32_t part_rows2;       // ... and a 256-key workgroup j owns rows 2j, 2j + 1 of them
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
+  int32_t mix_na, mix_a_lo, mix_k_hi;  // forward, mixed launch (attn_fwd64_mixed_kernel): 256-row workgroups in total / per pair (low) / pairs per XCD with one more
   int32_t dvalid;           // valid head-dim columns: = D except head_dim 16, which runs the D = 32 instantiations with columns 16..31 read as zeros and never written
   int32_t lds_stage;        // 64-wide backward bodies: the register-resident operands arrive / the outputs leave through wave-private LDS images (set by the launcher when the LDS fits)
   float scale;

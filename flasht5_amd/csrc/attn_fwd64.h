@@ -43,6 +43,9 @@
 #ifndef FAT5_FWD_ABL
 #define FAT5_FWD_ABL 0  // developer ablations of the pipelined block (timing / counters only, wrong results unless noted): 1 no row sums, 2 row sums by v_add_f32 (correct results), 4 v_mov for v_exp, 8 no conversion to 16 bit (the words stay zero)
 #endif
+#ifndef FAT5_MIX_PRIO
+#define FAT5_MIX_PRIO 0  // mixed launch: 1 = the key-split (half-length) waves run at raised priority (s_setprio 3), 2 = the full-length ones.  Measured at (4,12,2048): 57.3 / 55.0 us against 55.2 without -- no gain, off
+#endif
 #ifndef FAT5_FWD_NS_KSPLIT
 #define FAT5_FWD_NS_KSPLIT 4
 #endif
@@ -133,15 +136,18 @@ FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); 
 
 
 template <int D, bool BF16, int BIAS, bool KSPLIT>
-FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
+FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const int m0) {
   static_assert(BIAS != FAT5_BIAS_DENSE || !KSPLIT, "dense bias: 256-row workgroups only");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
   using Cfg = Fwd64Cfg<D, KSPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
   constexpr int NKB = KSPLIT ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
-  [[maybe_unused]] long long fstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] long long fstamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   FAT5_FSTAMP(0);
+#if FAT5_TRACE
+  fstamp[8] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32) | ((long long)(KSPLIT ? 1 : 0) << 40);  // HW_ID | XCC_ID | kind
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + Cfg::FLAG);
   float* sT = reinterpret_cast<float*>(smem + Cfg::TAB) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
@@ -149,10 +155,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;
   const int rg = KSPLIT ? (w >> 1) : w;  // 64-row group of this wave
   const int kh = KSPLIT ? (w & 1) : 0;   // KSPLIT: the 32-key block of every tile this wave owns (wave-uniform)
-  int b, h, mblk;
-  decode_unit(a, item, a.n_mblk, b, h, mblk);
   const int M = a.M, N = a.N;
-  const int m0 = mblk * BM;
   if (m0 >= M) return;
   [[maybe_unused]] RpeTableRegs tabr;  // (the bias table's first round of loads leaves before every other request of the prologue)
   if constexpr (BIAS == FAT5_BIAS_RPE1D) tabr = rpe_table_load_first(a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT);
@@ -976,7 +979,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
   if (threadIdx.x == 0) {
     long long* dst = reinterpret_cast<long long*>(ob_ + (int64_t)m0 * a.os[2]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = fstamp[i];
+    for (int i = 0; i < 9; ++i) dst[i] = fstamp[i];
   }
 #endif
 }
@@ -984,13 +987,68 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int item) {
 template <int D, bool BF16, int BIAS, bool KSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  // (two waves per SIMD: <= 256 registers)
 void attn_fwd64_kernel(const AttnArgs a) {
-  attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, blockIdx.x);
+  int b, h, mblk;
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, b, h, mblk * Fwd64Cfg<D, KSPLIT>::BM);
 }
 // dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
 template <int D, bool BF16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd64_dense_kernel(const AttnArgs a) {
-  attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, false>(a, blockIdx.x);
+  int b, h, mblk;
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, false>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
+}
+// Both workgroup forms in ONE launch (round 4) for problems of 1 .. 2 64-row waves per SIMD.  With 1.5 waves of 64 rows per SIMD either
+// pure form leaves half of the SIMDs with twice the work of the others ((4,12,2048): 58 us where the matrix pipe's share is ~32).  Here
+// the first `mix_na` workgroups are 256-row ones (four waves, one per SIMD, each with all keys of its 64 rows), the others key-split
+// 128-row ones (four waves, one per SIMD, each with half the keys of 64 rows): one of each per CU gives every SIMD 1 + 1/2 units.
+// Pair k of XCD x (unit 8 k + x) gets a_lo (+1 for the first mix_k_hi pairs of the XCD) 256-row workgroups from row 0 on and 128-row
+// workgroups for the rest of its rows; both kinds of a pair sit on the pair's XCD (K / V stay in one L2).
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void attn_fwd64_mixed_kernel(const AttnArgs a) {
+  const int M = a.M;
+  const int a_lo = a.mix_a_lo, k_hi = a.mix_k_hi;
+  const int b_hi = (max(M - 256 * (a_lo + 1), 0) + 127) / 128, b_lo = (max(M - 256 * a_lo, 0) + 127) / 128;
+  // launch order inside an XCD (sequence number idx = blockIdx >> 3): all 256-row workgroups first.  The dispatcher deals the workgroups
+  // of an XCD round-robin over its 32 CUs (traced: HW_REG_HW_ID per workgroup in the FAT5_TRACE build), so with na_x = nb_x = 32 CU c gets
+  // 256-row workgroup c and 128-row workgroup c -- one of each; alternating the kinds in launch order pairs like with like (66 vs 62.5 us).
+  if (a.unit_count > 0) {
+    // a unit range (sharded runs): every row must go through the SAME form as in the unsharded launch (bit-identical results) -- the
+    // pair's share of 256-row workgroups follows from its place in the full problem.  (a_lo + 1) + b_lo slots per pair, the unused exit.
+    const int sp = a_lo + 1 + b_lo;
+    const int pi = blockIdx.x / sp, sl = blockIdx.x - pi * sp;
+    const int u = a.unit_begin + pi, h = u / a.B, b = u - h * a.B;
+    const int k = (b * a.H + h) >> 3, ak = a_lo + (k < k_hi ? 1 : 0), bk = k < k_hi ? b_hi : b_lo;
+    if (sl < a_lo + 1) {
+      if (sl < ak) attn_fwd64_body<D, BF16, BIAS, false>(a, b, h, 256 * sl);
+    } else if (sl - (a_lo + 1) < bk) {
+      attn_fwd64_body<D, BF16, BIAS, true>(a, b, h, 256 * ak + 128 * (sl - (a_lo + 1)));
+    }
+    return;
+  }
+  const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int na_x = a.mix_na >> 3;
+  const bool kindA = idx < na_x;
+  const int i = kindA ? idx : idx - na_x;
+  if (kindA) {
+    const int thr = k_hi * (a_lo + 1);
+    int k, j;
+    if (i < thr) { k = i / (a_lo + 1); j = i - k * (a_lo + 1); }
+    else { const int i2 = i - thr; k = i2 / a_lo; j = i2 - k * a_lo; k += k_hi; }
+    const int ui = 8 * k + x;
+    if (FAT5_MIX_PRIO == 2) __builtin_amdgcn_s_setprio(3);
+    attn_fwd64_body<D, BF16, BIAS, false>(a, ui / a.H, ui % a.H, 256 * j);
+  } else {
+    if (FAT5_MIX_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+    const int thr = k_hi * b_hi;
+    int k, j, r0;
+    if (i < thr) { k = i / b_hi; j = i - k * b_hi; r0 = 256 * (a_lo + 1); }
+    else { const int i2 = i - thr; k = i2 / b_lo; j = i2 - k * b_lo; k += k_hi; r0 = 256 * a_lo; }
+    const int ui = 8 * k + x;
+    attn_fwd64_body<D, BF16, BIAS, true>(a, ui / a.H, ui % a.H, r0 + 128 * j);
+  }
 }
 
 }  // namespace fat5

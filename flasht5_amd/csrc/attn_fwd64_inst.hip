@@ -1,6 +1,7 @@
 // Instantiations of the 64-rows-per-wave pipelined forward (attn_fwd64.h) for one head_dim (-DFAT5_INST_D=64).
 #include "attn_fwd64.h"
 #include <cstdlib>
+#include <algorithm>
 #include "attn_launch.h"
 
 #ifndef FAT5_INST_D
@@ -44,8 +45,23 @@ static hipError_t launch64_bias(const AttnArgs& a, int bf16, int bias, int grid,
     return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, KSPLIT>(a, grid, s);
   return bf16 ? launch64<FAT5_INST_D, true, FAT5_BIAS_NONE, KSPLIT>(a, grid, s) : launch64<FAT5_INST_D, false, FAT5_BIAS_NONE, KSPLIT>(a, grid, s);
 }
+// nw == 3: both workgroup forms in one launch (a.mix_*; grid = 256-row + 128-row workgroups)
+template <bool BF16, int BIAS>
+static hipError_t launch64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = std::max(Fwd64Cfg<FAT5_INST_D, false>::smem(a.R, BIAS), Fwd64Cfg<FAT5_INST_D, true>::smem(a.R, BIAS));
+  auto kern = attn_fwd64_mixed_kernel<FAT5_INST_D, BF16, BIAS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
 // nw == 2: the key-split variant (two waves per 64 query rows, 128-row workgroups); otherwise 256-row workgroups
 hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  if (nw == 3) {
+    if (bias == FAT5_BIAS_RPE1D) return bf16 ? launch64_mixed<true, FAT5_BIAS_RPE1D>(a, grid, s) : launch64_mixed<false, FAT5_BIAS_RPE1D>(a, grid, s);
+    return bf16 ? launch64_mixed<true, FAT5_BIAS_NONE>(a, grid, s) : launch64_mixed<false, FAT5_BIAS_NONE>(a, grid, s);
+  }
   return nw == 2 ? launch64_bias<true>(a, bf16, bias, grid, s) : launch64_bias<false>(a, bf16, bias, grid, s);
 }
 

@@ -150,10 +150,15 @@ struct FwdChoice {
   int n_mblk;    // query tiles per (b, h)
   bool fwd64;    // the 64-rows-per-wave pipelined body (attn_fwd64.h)
   bool ksplit;
+  bool mixed;    // 256-row and key-split 128-row workgroups in one launch (attn_fwd64_mixed_kernel): mix_* filled in
+  int mix_na, mix_a_lo, mix_k_hi;
+  long mix_grid;
 };
 static FwdChoice fwd_choice(const fat5_attn_params* p) {
   FwdChoice c;
-  c.fwd64 = c.ksplit = false;
+  c.fwd64 = c.ksplit = c.mixed = false;
+  c.mix_na = c.mix_a_lo = c.mix_k_hi = 0;
+  c.mix_grid = 0;
   const long bh = (long)p->B * p->H;
   int nw = pick_nw(bh * ((p->M + 127) / 128));
   c.n_mblk = (p->M + 32 * nw - 1) / (32 * nw);
@@ -209,6 +214,32 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     c.ksplit = ksplit;
     nw = ksplit ? 2 : 4;
     c.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
+    // Both forms in one launch (round 4): between one and two 64-row waves per SIMD either pure form leaves half of the SIMDs with
+    // twice the work of the others; one 256-row workgroup (a full-length wave per SIMD) plus one key-split 128-row workgroup (a
+    // half-length wave per SIMD) per CU gives every SIMD 1.5 units.  n = waves64 / 6 workgroups of each kind: taken where that is one
+    // round of the chip (0.9 .. 1.1 x 256), the pairs divide evenly over the XCDs and a pair has room for a 256-row workgroup.
+    // Measured (tools/attn_time.py, us, mixed vs the key-split form): (4,12,2048) T5 bias 54.4-55.8 vs 58.0-58.4, none 52.6-53.7 vs 56.7; (8,12,1024) 31.7-32.5 vs
+    // 33.8; (2,12,4096) 101.2 vs 108.0.  The per-SIMD model promised -40 %: traced (HW_ID per workgroup), every CU does get one workgroup of each
+    // kind, but the half-length waves -- one block per tile barrier -- take as long as the full-length ones beside them (86 k vs 77 k cycles).
+    const int mx_env = vsel(p->variant, FAT5_V_FWD64_MIX_ON, FAT5_V_FWD64_MIX_OFF);
+    if (mx_env != 0 && bh % 8 == 0 && p->M >= 384 && !p->causal && ks_env == -1 &&
+        (mx_env == 1 || (waves64 * 10 >= 6 * 256 * 9 && waves64 * 10 <= 6 * 256 * 11 && p->N >= 1024))) {
+      const long npx = bh / 8;                                   // pairs per XCD
+      long na_x = (waves64 + 24) / 48;                           // 256-row workgroups per XCD (waves64 / 6 in total)
+      na_x = std::max(na_x, npx);                                // (at least one per pair)
+      const long a_max = (p->M - 128) / 256;                     // (a pair keeps at least one 128-row workgroup)
+      na_x = std::min(na_x, npx * a_max);
+      if (a_max >= 1) {
+        c.mixed = true;
+        c.mix_a_lo = (int)(na_x / npx);
+        c.mix_k_hi = (int)(na_x % npx);
+        c.mix_na = (int)(8 * na_x);
+        const long b_hi = (std::max<long>(p->M - 256L * (c.mix_a_lo + 1), 0) + 127) / 128, b_lo = (std::max<long>(p->M - 256L * c.mix_a_lo, 0) + 127) / 128;
+        c.mix_grid = p->unit_count > 0 ? (long)p->unit_count * (c.mix_a_lo + 1 + b_lo)   // (a unit range: fixed slots per pair, see the kernel)
+                                       : 8 * (na_x + c.mix_k_hi * b_hi + (npx - c.mix_k_hi) * b_lo);
+        nw = 3;
+      }
+    }
   }
   c.nw = nw;
   return c;
@@ -232,8 +263,9 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   const FwdChoice fc = fwd_choice(p);
   int nw = fc.nw;
   a.n_mblk = fc.n_mblk;
+  a.mix_na = fc.mix_na; a.mix_a_lo = fc.mix_a_lo; a.mix_k_hi = fc.mix_k_hi;
   launch_fn fn = fc.fwd64 ? launch_fwd64_d64 : (effD(p) == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
-  const long grid = n_units(p) * a.n_mblk;
+  const long grid = fc.mixed ? fc.mix_grid : n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);
   if (e != hipSuccess) return hip_fail(e, "attn_fwd launch");
@@ -465,7 +497,7 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   char kv[48];
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
-  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.ksplit ? "64row-ksplit" : "64row") : (fc.nw == -4 ? "32row-split" : "32row"),
+  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
            L.q64 ? "64row" : "32row", kv, (fused || L.fused64) ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
   return FAT5_OK;
 }
