@@ -43,3 +43,36 @@ def test_fwd64_mixed_launch_matches_oracle(B, H, M, N, mode, dtype):
         else:
             o2 = flash_attention_v2_bias(q, k, v, None, False, 0.125)
     assert maxdiff(o.detach(), o2) <= bound(ref["o"], dtype)
+
+
+@pytest.mark.parametrize("boost,rows,at,dtype", [(72.0, "all", 1024, torch.bfloat16), (1000.0, "even", 768, torch.bfloat16), (-60.0, "all", 0, torch.bfloat16),
+                                                 (14.0, "all", 512, torch.float16), (30.0, "all", 768, torch.float16)])
+def test_fwd64_mixed_launch_exact_pass_fallback(boost, rows, at, dtype):
+    """rows whose sums leave the range of the sweep without a running maximum (attn_fwd64.h) rerun their workgroup through the exact pass --
+    in both workgroup forms of the mixed launch (8 pairs of 2048 rows: 256-row workgroups for the first rows of a pair, key-split ones
+    for the rest); fp16: scores beyond the first tile's row maximum by more than the format's range."""
+    from flasht5_amd import _lib, flash_attention_v2_bias
+    from attn_helpers import eager_lowprec_errors
+    B, H, S, D = 1, 8, 2048, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, S, D, generator=g).to(dtype)
+    k = torch.randn(B, H, S, D, generator=g).to(dtype)
+    v = torch.randn(B, H, S, D, generator=g).to(dtype)
+    q[..., 0] = 4.0
+    if rows == "even":
+        q[..., 1::2, 0] = 0.0
+    k[..., at:, 0] = boost / 4.0
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B, H, S, D, generator=g).to(dtype).cuda()
+    with _lib.variant(_lib.V_FWD64_ON | _lib.V_FWD64_MIX_ON):
+        leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+        o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], None, False, 1.0)
+        grads = torch.autograd.grad(o, leaves, do)
+    ref = oracle_all(q, k, v, None, do, 1.0, False)
+    assert torch.isfinite(o.float()).all()
+    assert maxdiff(o, ref["o"]) <= bound(ref["o"], dtype)
+    lp = eager_lowprec_errors(q, k, v, None, do, 1.0, False, ref)
+    for got, key in zip(grads, ("dq", "dk", "dv")):
+        e = maxdiff(got, ref[key])
+        assert torch.isfinite(got.float()).all(), key
+        assert e <= max(gbound(ref[key], dtype), 3 * lp[key]), (key, e, lp[key])
