@@ -138,7 +138,6 @@ V_FWD64_KSPLIT_ON, V_FWD64_KSPLIT_OFF = 1024, 2048
 V_KV64_HALF_ON, V_KV64_HALF_OFF = 4096, 8192
 V_KV64_MIX_ON, V_KV64_MIX_OFF = 16384, 32768
 V_FWD64_MIX_ON, V_FWD64_MIX_OFF = 524288, 1048576
-V_FWD64_KS2_ON, V_FWD64_KS2_OFF = 2097152, 4194304
 V_FUSED64_ON, V_FUSED64_OFF = 65536, 131072
 V_DBIAS_NOSPLIT = 262144
 _variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)

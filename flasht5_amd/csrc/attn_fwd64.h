@@ -51,12 +51,9 @@
 #endif
 namespace fat5 {
 
-// KSPLIT: 0 = 256-row workgroups; 1 = key-split, each wave of a pair one 32-key block of every 64-key tile; 2 = key-split over 128-key tiles
-// (round 4): each wave of a pair two consecutive 32-key blocks of every tile -- half as many tile barriers per key; 128 KB of rings, so for
-// grids of at most one workgroup per CU (cfg2: a wave's block between two barriers took 1460 cycles against ~1000 with two blocks)
-template <int D, int KSPLIT = 0>
+template <int D, bool KSPLIT = false>
 struct Fwd64Cfg {
-  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = KSPLIT == 2 ? 128 : 64, NT = 64 * NW, NS = KSPLIT == 1 ? FAT5_FWD_NS_KSPLIT : 4;  // NS ring slots per operand
+  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = KSPLIT ? FAT5_FWD_NS_KSPLIT : 4;  // NS ring slots per operand
   static constexpr int TILE = rm_bytes<D, BN>();
   static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + 16;
   static constexpr int MERGE = 32 * 64 * 4 + 1024;  // KSPLIT: per wave, one query block's O^T (32 registers x 64 lanes) + (m, l) -- inside the rings
@@ -138,15 +135,14 @@ FAT5_DEV void mfma16_acc(f32x4& acc, const u32x4 A, const u32x4 B) {
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
-template <int D, bool BF16, int BIAS, int KSPLIT>
+template <int D, bool BF16, int BIAS, bool KSPLIT>
 FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const int m0) {
   static_assert(BIAS != FAT5_BIAS_DENSE || !KSPLIT, "dense bias: 256-row workgroups only");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
   using Cfg = Fwd64Cfg<D, KSPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
-  constexpr int NKB = KSPLIT == 1 ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
-  constexpr int KHB = KSPLIT == 2 ? 64 : 32;  // key-split: first key of wave kh's share inside a tile = KHB * kh
+  constexpr int NKB = KSPLIT ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
   [[maybe_unused]] long long fstamp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   FAT5_FSTAMP(0);
 #if FAT5_TRACE
@@ -328,7 +324,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   }
   // per-lane LDS addresses of the fragment reads (ring base folded in; slot / block / step offsets are immediates;
   // KSPLIT: the wave's own 32-key block of every tile is folded in as well)
-  const uint32_t khoff = (uint32_t)(kh * KHB * 2 * D);
+  const uint32_t khoff = (uint32_t)(kh * 32 * 2 * D);
   uint32_t rmA[KK], trA[2][DB];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
@@ -399,8 +395,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     const uint32_t soff = (uint32_t)(slot * TILE);
 #pragma unroll
     for (int kbi = 0; kbi < NKB; ++kbi) {
-      const int kb = KSPLIT == 1 ? kh : (KSPLIT == 2 ? 2 * kh + kbi : kbi);  // key block inside the tile
-      const int kbo = KSPLIT == 1 ? 0 : kbi;    // ... as an address offset (key-split: the wave's share is folded into the lane bases)
+      const int kb = KSPLIT ? kh : kbi;         // key block inside the tile
+      const int kbo = KSPLIT ? 0 : kbi;         // ... as an address offset (KSPLIT: folded into the lane bases)
       const int nb = n0 + 32 * kb;
       f32x16 s[2];
       {
@@ -542,8 +538,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // are volatile asm: hipcc neither reorders nor packs them (v_pk_*_f32 beside MFMAs is an anti-lever, MI355X_MICROARCH.md)
   // and pads no hazards for them -- the youngest MFMA result they read (S'[0], finished by MFMA 14) is two MFMA issue
   // periods old when chunk 0 of the next block reads it.
-  // NSTEP: first key of the wave's next block minus first key of this one
-  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND, int NSTEP>(const float ad0, const float ad1, const int nbS) {
+  constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
+  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS) {
     static_assert(D == 64, "gap schedule written for D = 64 (16 MFMAs, 16 two-element chunks per block)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
     u32x4 kf[KK];
@@ -740,11 +736,11 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
       begin_iter(tt, SL);
-      if constexpr (KSPLIT == 1) {
-        pipe_block.template operator()<S1, 0, SL, 0, BAND, 64>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
-      } else {  // (key-split over 128-key tiles: the wave's two blocks start at key 64 kh of the tile; the next tile's first one 96 keys after the second)
-        pipe_block.template operator()<SL, 1, SL, 0, BAND, 32>(ad0, ad1, tt * BN + KHB * kh * (KSPLIT == 2));
-        pipe_block.template operator()<S1, 0, SL, 1, BAND, BN - 32>(ad0, ad1, tt * BN + KHB * kh * (KSPLIT == 2) + 32);
+      if constexpr (KSPLIT) {
+        pipe_block.template operator()<S1, 0, SL, 0, BAND>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
+      } else {
+        pipe_block.template operator()<SL, 1, SL, 0, BAND>(ad0, ad1, tt * BN);
+        pipe_block.template operator()<S1, 0, SL, 1, BAND>(ad0, ad1, tt * BN + 32);
       }
       end_iter(tt);
     };
@@ -840,7 +836,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           if constexpr (BIAS == FAT5_BIAS_RPE1D) {
             pipe_run.template operator()<false>(t, tbA, slot, cst_a);
             if (t < tbB) {  // entering the band: the first block's table entries for query block 0 (later blocks prefetch their successor's)
-              tadr0 = tab_addr(0, t * BN + KHB * kh);
+              tadr0 = tab_addr(0, t * BN + 32 * kh);
               TN[0] = lds_rd128(tadr0);
               TN[1] = lds_rd128(tadr0 + 32u);
             }
@@ -988,20 +984,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
 #endif
 }
 
-template <int D, bool BF16, int BIAS, int KSPLIT>
+template <int D, bool BF16, int BIAS, bool KSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  // (two waves per SIMD: <= 256 registers)
 void attn_fwd64_kernel(const AttnArgs a) {
   int b, h, mblk;
   decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
   attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, b, h, mblk * Fwd64Cfg<D, KSPLIT>::BM);
-}
-// key-split over 128-key tiles: 128 KB of rings, one workgroup per CU -- one wave per SIMD, so the allocator may use all 512 registers
-template <int D, bool BF16, int BIAS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void attn_fwd64_ks2_kernel(const AttnArgs a) {
-  int b, h, mblk;
-  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
-  attn_fwd64_body<D, BF16, BIAS, 2>(a, b, h, mblk * Fwd64Cfg<D, 2>::BM);
 }
 // dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
 template <int D, bool BF16>
@@ -1009,7 +997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd64_dense_kernel(const AttnArgs a) {
   int b, h, mblk;
   decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
-  attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, 0>(a, b, h, mblk * Fwd64Cfg<D, 0>::BM);
+  attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, false>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
 }
 // Both workgroup forms in ONE launch (round 4) for problems of 1 .. 2 64-row waves per SIMD.  With 1.5 waves of 64 rows per SIMD either
 // pure form leaves half of the SIMDs with twice the work of the others ((4,12,2048): 58 us where the matrix pipe's share is ~32).  Here
@@ -1034,9 +1022,9 @@ void attn_fwd64_mixed_kernel(const AttnArgs a) {
     const int u = a.unit_begin + pi, h = u / a.B, b = u - h * a.B;
     const int k = (b * a.H + h) >> 3, ak = a_lo + (k < k_hi ? 1 : 0), bk = k < k_hi ? b_hi : b_lo;
     if (sl < a_lo + 1) {
-      if (sl < ak) attn_fwd64_body<D, BF16, BIAS, 0>(a, b, h, 256 * sl);
+      if (sl < ak) attn_fwd64_body<D, BF16, BIAS, false>(a, b, h, 256 * sl);
     } else if (sl - (a_lo + 1) < bk) {
-      attn_fwd64_body<D, BF16, BIAS, 1>(a, b, h, 256 * ak + 128 * (sl - (a_lo + 1)));
+      attn_fwd64_body<D, BF16, BIAS, true>(a, b, h, 256 * ak + 128 * (sl - (a_lo + 1)));
     }
     return;
   }
@@ -1051,7 +1039,7 @@ void attn_fwd64_mixed_kernel(const AttnArgs a) {
     else { const int i2 = i - thr; k = i2 / a_lo; j = i2 - k * a_lo; k += k_hi; }
     const int ui = 8 * k + x;
     if (FAT5_MIX_PRIO == 2) __builtin_amdgcn_s_setprio(3);
-    attn_fwd64_body<D, BF16, BIAS, 0>(a, ui / a.H, ui % a.H, 256 * j);
+    attn_fwd64_body<D, BF16, BIAS, false>(a, ui / a.H, ui % a.H, 256 * j);
   } else {
     if (FAT5_MIX_PRIO == 1) __builtin_amdgcn_s_setprio(3);
     const int thr = k_hi * b_hi;
@@ -1059,7 +1047,7 @@ void attn_fwd64_mixed_kernel(const AttnArgs a) {
     if (i < thr) { k = i / b_hi; j = i - k * b_hi; r0 = 256 * (a_lo + 1); }
     else { const int i2 = i - thr; k = i2 / b_lo; j = i2 - k * b_lo; k += k_hi; r0 = 256 * a_lo; }
     const int ui = 8 * k + x;
-    attn_fwd64_body<D, BF16, BIAS, 1>(a, ui / a.H, ui % a.H, r0 + 128 * j);
+    attn_fwd64_body<D, BF16, BIAS, true>(a, ui / a.H, ui % a.H, r0 + 128 * j);
   }
 }
 

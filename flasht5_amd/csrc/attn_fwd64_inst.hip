@@ -12,11 +12,10 @@
 
 namespace fat5 {
 
-template <int D, bool BF16, int BIAS, int KSPLIT>
+template <int D, bool BF16, int BIAS, bool KSPLIT>
 static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = Fwd64Cfg<D, KSPLIT>::smem(a.R, BIAS);
-  void (*kern)(const AttnArgs) = attn_fwd64_kernel<D, BF16, BIAS, KSPLIT == 2 ? 1 : KSPLIT>;
-  if constexpr (KSPLIT == 2) kern = attn_fwd64_ks2_kernel<D, BF16, BIAS>;
+  auto kern = attn_fwd64_kernel<D, BF16, BIAS, KSPLIT>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -29,7 +28,7 @@ static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
 
 template <int D, bool BF16>
 static hipError_t launch64_dense(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = Fwd64Cfg<D, 0>::smem(a.R, FAT5_BIAS_DENSE);
+  const size_t smem = Fwd64Cfg<D, false>::smem(a.R, FAT5_BIAS_DENSE);
   auto kern = attn_fwd64_dense_kernel<D, BF16>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
@@ -37,7 +36,7 @@ static hipError_t launch64_dense(const AttnArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int KSPLIT>
+template <bool KSPLIT>
 static hipError_t launch64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
   if constexpr (!KSPLIT) {
     if (bias == FAT5_BIAS_DENSE) return bf16 ? launch64_dense<FAT5_INST_D, true>(a, grid, s) : launch64_dense<FAT5_INST_D, false>(a, grid, s);
@@ -49,7 +48,7 @@ static hipError_t launch64_bias(const AttnArgs& a, int bf16, int bias, int grid,
 // nw == 3: both workgroup forms in one launch (a.mix_*; grid = 256-row + 128-row workgroups)
 template <bool BF16, int BIAS>
 static hipError_t launch64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
-  const size_t smem = std::max(Fwd64Cfg<FAT5_INST_D, 0>::smem(a.R, BIAS), Fwd64Cfg<FAT5_INST_D, 1>::smem(a.R, BIAS));
+  const size_t smem = std::max(Fwd64Cfg<FAT5_INST_D, false>::smem(a.R, BIAS), Fwd64Cfg<FAT5_INST_D, true>::smem(a.R, BIAS));
   auto kern = attn_fwd64_mixed_kernel<FAT5_INST_D, BF16, BIAS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
@@ -63,11 +62,9 @@ hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bia
     if (bias == FAT5_BIAS_RPE1D) return bf16 ? launch64_mixed<true, FAT5_BIAS_RPE1D>(a, grid, s) : launch64_mixed<false, FAT5_BIAS_RPE1D>(a, grid, s);
     return bf16 ? launch64_mixed<true, FAT5_BIAS_NONE>(a, grid, s) : launch64_mixed<false, FAT5_BIAS_NONE>(a, grid, s);
   }
-  if (nw == 5) return launch64_bias<2>(a, bf16, bias, grid, s);  // key-split over 128-key tiles (one workgroup per CU)
-  return nw == 2 ? launch64_bias<1>(a, bf16, bias, grid, s) : launch64_bias<0>(a, bf16, bias, grid, s);
+  return nw == 2 ? launch64_bias<true>(a, bf16, bias, grid, s) : launch64_bias<false>(a, bf16, bias, grid, s);
 }
 
 size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D>::smem(R, bias); }
-size_t CAT(smem_fwd64_ks2_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D, 2>::smem(R, bias); }
 
 }  // namespace fat5

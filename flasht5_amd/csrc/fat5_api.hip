@@ -150,14 +150,13 @@ struct FwdChoice {
   int n_mblk;    // query tiles per (b, h)
   bool fwd64;    // the 64-rows-per-wave pipelined body (attn_fwd64.h)
   bool ksplit;
-  bool ks2;      // key-split over 128-key tiles (two blocks per wave and tile barrier; one workgroup per CU)
   bool mixed;    // 256-row and key-split 128-row workgroups in one launch (attn_fwd64_mixed_kernel): mix_* filled in
   int mix_na, mix_a_lo, mix_k_hi;
   long mix_grid;
 };
 static FwdChoice fwd_choice(const fat5_attn_params* p) {
   FwdChoice c;
-  c.fwd64 = c.ksplit = c.ks2 = c.mixed = false;
+  c.fwd64 = c.ksplit = c.mixed = false;
   c.mix_na = c.mix_a_lo = c.mix_k_hi = 0;
   c.mix_grid = 0;
   const long bh = (long)p->B * p->H;
@@ -215,16 +214,6 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     c.ksplit = ksplit;
     nw = ksplit ? 2 : 4;
     c.n_mblk = ksplit ? (p->M + 127) / 128 : (p->M + 255) / 256;
-    // Key-split over 128-key tiles (round 4): a wave's TWO blocks of a tile between two tile barriers instead of one.  At cfg2 (192
-    // workgroups on 256 CUs: one wave per SIMD) a block took 1460 cycles of the sweep against ~800 in the steady state of long
-    // sequences -- tile barriers and the waits in front of them; 128 KB of K / V rings, so only while the grid is one workgroup per CU.
-    // Measured (tools/attn_time.py, us, against the 64-key form): see below.
-    const int k2_env = vsel(p->variant, FAT5_V_FWD64_KS2_ON, FAT5_V_FWD64_KS2_OFF);
-    if (ksplit && k2_env != 0 && smem_fwd64_ks2_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024 && p->N >= 256 &&
-        (k2_env == 1 || bh * c.n_mblk <= 256)) {
-      c.ks2 = true;
-      nw = 5;
-    }
     // Both forms in one launch (round 4): between one and two 64-row waves per SIMD either pure form leaves half of the SIMDs with
     // twice the work of the others; one 256-row workgroup (a full-length wave per SIMD) plus one key-split 128-row workgroup (a
     // half-length wave per SIMD) per CU gives every SIMD 1.5 units.  n = waves64 / 6 workgroups of each kind: taken where that is one
@@ -242,7 +231,6 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
       na_x = std::min(na_x, npx * a_max);
       if (a_max >= 1) {
         c.mixed = true;
-        c.ks2 = false;
         c.mix_a_lo = (int)(na_x / npx);
         c.mix_k_hi = (int)(na_x % npx);
         c.mix_na = (int)(8 * na_x);
@@ -509,7 +497,7 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   char kv[48];
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
-  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? (fc.ks2 ? "64row-ksplit128" : "64row-ksplit") : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
+  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
            L.q64 ? "64row" : "32row", kv, (fused || L.fused64) ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
   return FAT5_OK;
 }

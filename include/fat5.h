@@ -53,7 +53,6 @@ enum fat5_variant {
   FAT5_V_KV64_HALF_ON = 4096, FAT5_V_KV64_HALF_OFF = 8192,       /* 64-key dK/dV body: half-length (128-key workgroup) variant always / never */
   FAT5_V_KV64_MIX_ON = 16384, FAT5_V_KV64_MIX_OFF = 32768,       /* 64-key dK/dV body: 256-key and half-length workgroups in one launch wherever legal / never */
   FAT5_V_FWD64_MIX_ON = 524288, FAT5_V_FWD64_MIX_OFF = 1048576,  /* 64-row forward: 256-row and key-split 128-row workgroups in ONE launch wherever legal / never */
-  FAT5_V_FWD64_KS2_ON = 2097152, FAT5_V_FWD64_KS2_OFF = 4194304,  /* key-split 64-row forward: 128-key tiles (two blocks per wave and tile barrier) wherever legal / never */
   FAT5_V_DBIAS_NOSPLIT = 262144,                                 /* batch-inner dbias kernel: the one-group form (one wave per SIMD) of rounds 2-3 */
   FAT5_V_FUSED64_ON = 65536, FAT5_V_FUSED64_OFF = 131072         /* backward: the 64-wide dK/dV and dQ bodies in ONE launch (the dK/dV half forms its row statistics itself) wherever legal / never */
 };

@@ -11,15 +11,12 @@ from test_attention_gpu import bound, gbound, _rpe_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["rows256", "ksplit", "ksplit128"])
+@pytest.fixture(autouse=True, params=["rows256", "ksplit"])
 def force_fwd64(request):
-    """every test of this module runs three times: 256-row workgroups (one wave per 64 rows), the key-split variant (128-row
-    workgroups, two waves per 64 rows merging through LDS, one 32-key block of every 64-key tile each) and the key-split variant over
-    128-key tiles (round 4: two blocks per wave and tile)"""
+    """every test of this module runs twice: 256-row workgroups (one wave per 64 rows), and the key-split variant (128-row
+    workgroups, two waves per 64 rows merging through LDS)"""
     from flasht5_amd import _lib
-    bits = {"rows256": _lib.V_FWD64_KSPLIT_OFF, "ksplit": _lib.V_FWD64_KSPLIT_ON | _lib.V_FWD64_KS2_OFF,
-            "ksplit128": _lib.V_FWD64_KSPLIT_ON | _lib.V_FWD64_KS2_ON}[request.param]
-    with _lib.variant(_lib.V_FWD64_ON | bits):
+    with _lib.variant(_lib.V_FWD64_ON | (_lib.V_FWD64_KSPLIT_ON if request.param == "ksplit" else _lib.V_FWD64_KSPLIT_OFF)):
         yield request.param
 
 
@@ -168,7 +165,7 @@ def test_fwd64_dense_bias_matches_oracle(B, H, M, N, causal, kind, force_fwd64):
     """Round 4: the dense-bias instantiation of the 64-row body (bias tiles by LDS-DMA into a two-tile ring, the bias words as the
     addend of the exponent FMA inside the pipelined stream; reference kernel bias path flash_attention_v2_bias.py:440-443) forced on
     shapes the oracle finishes in seconds: o, lse and -- through the backward that consumes this lse -- all four gradients."""
-    if force_fwd64 != "rows256":
+    if force_fwd64 == "ksplit":
         pytest.skip("dense bias: 256-row workgroups only")
     from flasht5_amd import _lib
     assert _lib.describe(B=B, H=H, M=M, N=N, bias_mode=_lib.BIAS_DENSE, variant=_lib.V_FWD64_ON)["fwd"] == "64row"
@@ -191,7 +188,7 @@ def test_fwd64_dense_bias_masking_values_and_edge_rows(force_fwd64):
     """a bias holding finfo.min (the reference's `use_masking`, modeling_flash_t5.py:266-270) on half of the keys of every row and on ALL
     keys of some rows: masked keys get p = 0 inside the pipelined sweep (the product overflows to -inf), a fully masked row has
     l = 0 there and sends its workgroup through the exact pass, which clamps like the 32-row body: same results as that body"""
-    if force_fwd64 != "rows256":
+    if force_fwd64 == "ksplit":
         pytest.skip("dense bias: 256-row workgroups only")
     from flasht5_amd import _lib
     from flasht5_amd.flash_attention_v2_bias import _attn_fwd
