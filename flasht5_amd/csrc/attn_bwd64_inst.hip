@@ -15,6 +15,7 @@ template <int D, bool BF16, int BIAS, bool HALF>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   // (operands / outputs through LDS images whenever the workgroup's LDS allows: see BwdQ64Cfg)
   AttnArgs as = a;
+  fill_div_magic(as, grid);
   as.lds_stage = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, true) <= 160 * 1024;
   const size_t smem = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, as.lds_stage != 0);
   auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF>;
@@ -30,6 +31,7 @@ template <int D, bool BF16, int BIAS>
 static hipError_t launch_q64(const AttnArgs& a, int grid, hipStream_t s) {
   // (operands / outputs through wave-private LDS images whenever the workgroup's LDS allows: a radius beyond ~500 does not)
   AttnArgs as = a;
+  fill_div_magic(as, grid);
   as.lds_stage = BwdQ64Cfg<D>::smem(a.R, BIAS, true) <= 160 * 1024;
   const size_t smem = BwdQ64Cfg<D>::smem(a.R, BIAS, as.lds_stage != 0);
   auto kern = attn_bwd_q64_kernel<D, BF16, BIAS>;
@@ -55,6 +57,7 @@ static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int gr
 template <int D, bool BF16, int BIAS>
 static hipError_t launch_kv64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
   AttnArgs as = a;
+  fill_div_magic(as, grid);
   as.lds_stage = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS, true), Bwd64Cfg<D, true>::smem(a.R, BIAS, true)) <= 160 * 1024;
   const bool st = as.lds_stage != 0;
   const size_t smem = std::max(Bwd64Cfg<D, false>::smem(a.R, BIAS, st), Bwd64Cfg<D, true>::smem(a.R, BIAS, st));
@@ -80,6 +83,7 @@ hipError_t CAT(launch_bwd_kv64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int 
 template <int D, bool BF16, int BIAS>
 static hipError_t launch_fused64(const AttnArgs& a, int grid, hipStream_t s) {
   AttnArgs as = a;
+  fill_div_magic(as, grid);
   as.lds_stage = std::max(Bwd64Cfg<D, false, true>::smem(a.R, BIAS, true), BwdQ64Cfg<D>::smem(a.R, BIAS, true)) <= 160 * 1024;
   const bool st = as.lds_stage != 0;
   const size_t smem = std::max(Bwd64Cfg<D, false, true>::smem(a.R, BIAS, st), BwdQ64Cfg<D>::smem(a.R, BIAS, st));

@@ -189,21 +189,26 @@ FAT5_DEV u32x4 gload16(const uint16_t* p, bool valid) {
 // All tiles of one (b,h) are given to one XCD so K/V (fwd, bwd_q) or Q/dO (bwd_kv) of that pair
 // stay in that XCD's L2.  Bijective for every (nbh, ntile).
 // ------------------------------------------------------------------------------------------
-FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile) {
+FAT5_DEV int fast_div(int n, int d, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)n, mg) : n / d; }
+__host__ inline uint32_t div_magic(long d, long n_max) {  // n_max: the largest dividend
+  if (d <= 1 || d >= (1L << 31) || n_max < 0 || (unsigned long long)n_max * (unsigned long long)d >= (1ull << 32)) return 0u;
+  return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d);
+}
+FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile, uint32_t mg_tile = 0) {
   const int total = nbh * ntile;
   const int nx = 8;
   if ((nbh % nx) == 0) {
     const int xcd = bid % nx;
     const int idx = bid / nx;           // sequence number inside this XCD
     const int per = nbh / nx;           // (b,h) pairs per XCD
-    const int pair = idx / ntile;       // which of this XCD's pairs
-    tile = idx % ntile;
+    const int pair = fast_div(idx, ntile, mg_tile);  // which of this XCD's pairs
+    tile = idx - pair * ntile;
     bh = pair * nx + xcd;               // pairs dealt round-robin to XCDs
     (void)per;
     (void)total;
   } else {
-    bh = bid / ntile;
-    tile = bid % ntile;
+    bh = fast_div(bid, ntile, mg_tile);
+    tile = bid - bh * ntile;
   }
 }
 
@@ -324,6 +329,9 @@ struct AttnArgs {
   int32_t part_rows2;       // ... and a 256-key workgroup j owns rows 2j, 2j + 1 of them
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
+  uint32_t mg_mblk, mg_nblk, mg_H;   // 2^32 / d rounded up for d = n_mblk, n_nblk, H, or 0: the launchers fill them where the workgroup index is small enough for
+                                     // q = umulhi(n, mg) to be the exact quotient (n d < 2^32); the index decode of a workgroup is then two instructions per division
+                                     // instead of ~35 (a prologue of ~500 scalar instructions is 2.7 k cycles of the 20 k a cfg2 forward workgroup lives)
   int32_t mix_na, mix_a_lo, mix_k_hi;  // forward, mixed launch (attn_fwd64_mixed_kernel): 256-row workgroups in total / per pair (low) / pairs per XCD with one more
   int32_t dvalid;           // valid head-dim columns: = D except head_dim 16, which runs the D = 32 instantiations with columns 16..31 read as zeros and never written
   int32_t lds_stage;        // 64-wide backward bodies: the register-resident operands arrive / the outputs leave through wave-private LDS images (set by the launcher when the LDS fits)
@@ -332,6 +340,7 @@ struct AttnArgs {
 
 // workgroup index -> (batch, head, tile).  The grid covers the call's units x tiles (all B * H units, or a unit range).
 FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h, int& tile) {
+  const uint32_t mg_tile = ntile == a.n_mblk ? a.mg_mblk : (ntile == a.n_nblk ? a.mg_nblk : 0u);
   if (a.batch_inner) {
     // A batch-broadcast dense bias tile (1, h, m-tile, n-tile) is read by all B batch elements: give the B workgroups of one
     // (head, tile) consecutive slots of ONE XCD, so the tile crosses the fabric once and is then served by that XCD's L2
@@ -352,13 +361,13 @@ FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h,
     return;
   }
   int ui;
-  decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile);
+  decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile, mg_tile);
   if (a.unit_count > 0) {
     const int u = a.unit_begin + ui;
     h = u / a.B;
     b = u - h * a.B;
   } else {
-    b = ui / a.H;
+    b = fast_div(ui, a.H, a.mg_H);
     h = ui - b * a.H;
   }
 }

@@ -22,7 +22,9 @@ static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
   }
   // One workgroup per item (persistent workgroups walking the items were measured no faster at (4,12,8192,64): 1536 equal items
   // over 512 slots balance by themselves).
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, am);
   return hipGetLastError();
 }
 

@@ -4,6 +4,12 @@
 #include "attn_common.h"
 
 namespace fat5 {
+// exact quotients by multiplication for the workgroup-index decode (attn_common.h: fast_div) wherever grid x divisor < 2^32
+inline void fill_div_magic(AttnArgs& a, long grid) {
+  a.mg_mblk = div_magic(a.n_mblk, grid);
+  a.mg_nblk = div_magic(a.n_nblk, grid);
+  a.mg_H = div_magic(a.H, grid);
+}
 // each returns hipError_t of the launch; nw in {2,4}
 #define FAT5_DECL_LAUNCH(D)                                                                           \
   hipError_t launch_fwd_d##D(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s); \
