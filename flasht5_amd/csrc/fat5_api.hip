@@ -685,7 +685,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       if (ea != hipSuccess) return hip_fail(ea, "drpe_reduce attribute");
     }
     hipLaunchKernelGGL(drpe_reduce_kernel, dim3(p->H), dim3(1024), smem, stream, a.drpe_part, p->drpe1d, p->rpe_bucket,
-                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets, p->unit_begin, p->unit_count);
+                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets, p->unit_begin, p->unit_count, div_magic(n1, 4L * n1),
+                       div_magic(a.n_nblk, (long)p->B * a.n_nblk));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
   }

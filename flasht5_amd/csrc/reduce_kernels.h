@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void dbias_reduce_kernel(const uint16_t* __res
 __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restrict__ part, float* __restrict__ out1d,
                                                            const int32_t* __restrict__ bucket, float* __restrict__ dtable,
                                                            int B, int H, int nblk, int n1, int nbuckets, int unit_begin,
-                                                           int unit_count) {
+                                                           int unit_count, uint32_t mg_n1, uint32_t mg_nblk) {  // (mg_*: fast_div magics of n1 / nblk or 0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sv4 = reinterpret_cast<float*>(smem);          // [4][n1] partial chains
   float* sv = sv4 + 4 * n1;                             // [n1] reduced diagonal sums of this head
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
   // threads around the loop again, and every trip is a cross-XCD memory round trip the whole workgroup waits for)
   const int NG = n1 <= 256 ? 4 : (n1 <= 341 ? 3 : (n1 <= 512 ? 2 : 1));
   for (int wv = tid; wv < NG * n1; wv += 1024) {
-    const int i = wv % n1, g = wv / n1;
+    const int g = fast_div(wv, n1, mg_n1), i = wv - g * n1;
     float acc = 0.f;
     // 16 partial rows per round, all loads in flight before the first add (each is a cross-XCD round trip: walking
     // them one by one cost 39 us for the 256 partial rows per head of S = 8192); adds stay in the chain's fixed order
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void drpe_reduce_kernel(const float* __restri
         const int pidx = p0 + NG * u;
         vv[u] = 0.f;
         if (pidx < nparts) {
-          const int b = pidx / nblk, blk = pidx - b * nblk;
+          const int b = fast_div(pidx, nblk, mg_nblk), blk = pidx - b * nblk;
           // a unit-range call wrote the partial rows of its own units only (u = h * B + b): the others stay out of the sum
           const bool mine = unit_count <= 0 || (unsigned)(h * B + b - unit_begin) < (unsigned)unit_count;
           if (mine) vv[u] = part[(((int64_t)b * H + h) * nblk + blk) * n1 + i];
