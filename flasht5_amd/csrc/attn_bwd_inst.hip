@@ -29,7 +29,9 @@ static hipError_t launch_q(const AttnArgs& a, int grid, hipStream_t s) {
   static size_t configured = 0;
   hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, am);
   return hipGetLastError();
 }
 template <int D, bool BF16, int BIAS, int NW>
@@ -39,7 +41,9 @@ static hipError_t launch_kv(const AttnArgs& a, int grid, hipStream_t s) {
   static size_t configured = 0;
   hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, am);
   return hipGetLastError();
 }
 
@@ -50,7 +54,9 @@ static hipError_t launch_fused(const AttnArgs& a, int grid, hipStream_t s) {
   static size_t configured = 0;
   hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, am);
   return hipGetLastError();
 }
 
@@ -60,7 +66,9 @@ template <typename K>
 static hipError_t launch_dbias_one(K kern, size_t smem, size_t& configured, int threads, const AttnArgs& a, void* dbias, float* scratch, int grid, hipStream_t s) {
   hipError_t e = set_smem(kern, smem, configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, a, (uint16_t*)dbias, scratch);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, s, am, (uint16_t*)dbias, scratch);
   return hipGetLastError();
 }
 hipError_t CAT(launch_bwd_dbias_d, FAT5_INST_D)(const AttnArgs& a, int bf16, void* dbias, float* scratch, int grid, hipStream_t s) {

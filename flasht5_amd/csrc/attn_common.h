@@ -332,6 +332,7 @@ struct AttnArgs {
   uint32_t mg_mblk, mg_nblk, mg_H;   // 2^32 / d rounded up for d = n_mblk, n_nblk, H, or 0: the launchers fill them where the workgroup index is small enough for
                                      // q = umulhi(n, mg) to be the exact quotient (n d < 2^32); the index decode of a workgroup is then two instructions per division
                                      // instead of ~35 (a prologue of ~500 scalar instructions is 2.7 k cycles of the 20 k a cfg2 forward workgroup lives)
+  uint32_t mg_mix[4];                // ... of the mixed forward launch's divisors a_lo + 1, a_lo, b_hi, b_lo
   int32_t mix_na, mix_a_lo, mix_k_hi;  // forward, mixed launch (attn_fwd64_mixed_kernel): 256-row workgroups in total / per pair (low) / pairs per XCD with one more
   int32_t dvalid;           // valid head-dim columns: = D except head_dim 16, which runs the D = 32 instantiations with columns 16..31 read as zeros and never written
   int32_t lds_stage;        // 64-wide backward bodies: the register-resident operands arrive / the outputs leave through wave-private LDS images (set by the launcher when the LDS fits)

@@ -1035,19 +1035,19 @@ void attn_fwd64_mixed_kernel(const AttnArgs a) {
   if (kindA) {
     const int thr = k_hi * (a_lo + 1);
     int k, j;
-    if (i < thr) { k = i / (a_lo + 1); j = i - k * (a_lo + 1); }
-    else { const int i2 = i - thr; k = i2 / a_lo; j = i2 - k * a_lo; k += k_hi; }
-    const int ui = 8 * k + x;
+    if (i < thr) { k = fast_div(i, a_lo + 1, a.mg_mix[0]); j = i - k * (a_lo + 1); }
+    else { const int i2 = i - thr; k = fast_div(i2, a_lo, a.mg_mix[1]); j = i2 - k * a_lo; k += k_hi; }
+    const int ui = 8 * k + x, bb = fast_div(ui, a.H, a.mg_H);
     if (FAT5_MIX_PRIO == 2) __builtin_amdgcn_s_setprio(3);
-    attn_fwd64_body<D, BF16, BIAS, false>(a, ui / a.H, ui % a.H, 256 * j);
+    attn_fwd64_body<D, BF16, BIAS, false>(a, bb, ui - bb * a.H, 256 * j);
   } else {
     if (FAT5_MIX_PRIO == 1) __builtin_amdgcn_s_setprio(3);
     const int thr = k_hi * b_hi;
     int k, j, r0;
-    if (i < thr) { k = i / b_hi; j = i - k * b_hi; r0 = 256 * (a_lo + 1); }
-    else { const int i2 = i - thr; k = i2 / b_lo; j = i2 - k * b_lo; k += k_hi; r0 = 256 * a_lo; }
-    const int ui = 8 * k + x;
-    attn_fwd64_body<D, BF16, BIAS, true>(a, ui / a.H, ui % a.H, r0 + 128 * j);
+    if (i < thr) { k = fast_div(i, b_hi, a.mg_mix[2]); j = i - k * b_hi; r0 = 256 * (a_lo + 1); }
+    else { const int i2 = i - thr; k = fast_div(i2, b_lo, a.mg_mix[3]); j = i2 - k * b_lo; k += k_hi; r0 = 256 * a_lo; }
+    const int ui = 8 * k + x, bb = fast_div(ui, a.H, a.mg_H);
+    attn_fwd64_body<D, BF16, BIAS, true>(a, bb, ui - bb * a.H, r0 + 128 * j);
   }
 }
 

@@ -54,7 +54,14 @@ static hipError_t launch64_mixed(const AttnArgs& a, int grid, hipStream_t s) {
   auto kern = attn_fwd64_mixed_kernel<FAT5_INST_D, BF16, BIAS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  {
+    const long b_hi = (std::max<long>(a.M - 256L * (a.mix_a_lo + 1), 0) + 127) / 128, b_lo = (std::max<long>(a.M - 256L * a.mix_a_lo, 0) + 127) / 128;
+    am.mg_mix[0] = div_magic(a.mix_a_lo + 1, grid); am.mg_mix[1] = div_magic(a.mix_a_lo, grid);
+    am.mg_mix[2] = div_magic(b_hi, grid); am.mg_mix[3] = div_magic(b_lo, grid);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, am);
   return hipGetLastError();
 }
 

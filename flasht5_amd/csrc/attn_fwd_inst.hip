@@ -21,7 +21,9 @@ static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
     if (e != hipSuccess) return e;
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), smem, s, am);
   return hipGetLastError();
 }
 
@@ -35,7 +37,9 @@ static hipError_t launch_split(const AttnArgs& a, int grid, hipStream_t s) {
     if (e != hipSuccess) return e;
     configured = smem;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, am);
   return hipGetLastError();
 }
 
