@@ -121,6 +121,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   uint16_t* dkb = a.dk + (int64_t)b * a.dks[0] + (int64_t)h * a.dks[1];
   uint16_t* dvb = a.dv + (int64_t)b * a.dvs[0] + (int64_t)h * a.dvs[1];
   const int P = N - M;
+  // causal mask by the bias table itself (attn_common.h: rpe_table_fill_rest): the diagonal d = P lies inside the band (-R <= P < R: the far-negative
+  // constant stays visible, the far-positive one is masked), entries above it are -inf
+  [[maybe_unused]] const bool ctab = BIAS == FAT5_BIAS_RPE1D && a.causal && P < a.R && P >= -a.R;
   const int kw0 = n0 + 64 * wp;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
 
   // K and V fragments (B operands) of this lane's two keys: staged (whole rows by LDS-DMA into the images of this wave's keys, read
@@ -324,7 +327,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   for (int rg = 0; rg < Cfg::RINGS; ++rg)
     for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + rg * Cfg::RING + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 8)) {
-    rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT, tabr);
+    rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
     for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
   }
   wait_dma_all();
@@ -715,7 +718,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       return fast;
     };
     // all of the wave's 64 keys visible to all 32 rows of the step (no key tail, no causal mask)?  Monotone in j: later steps see more
-    auto all_visible = [&](const int j) { return kw0 + 64 <= N && (!a.causal || kw0 + 63 <= (mt0 + j) * 32 + P); };
+    auto all_visible = [&](const int j) { return kw0 + 64 <= N && (!a.causal || ctab || kw0 + 63 <= (mt0 + j) * 32 + P); };  // (ctab: the table masks)
     // (single-body inner loops, not one loop over `class ? A : B`: the register allocator keeps one assignment per loop and pays its
     //  copies only at the few transitions)
     int j = 0;
@@ -941,6 +944,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   uint16_t* dqb_ = a.dq + (int64_t)b * a.dqs[0] + (int64_t)h * a.dqs[1];
   const int64_t stat_off = ((int64_t)b * a.H + h) * a.M;
   const int P = N - M;
+  [[maybe_unused]] const bool ctab = BIAS == FAT5_BIAS_RPE1D && a.causal && P < a.R && P >= -a.R;  // (the causal mask by the bias table itself: see the dK/dV body)
   int n_end = N;
   if (a.causal) n_end = min(N, m0 + BM + P);
   const int nt = n_end > 0 ? (n_end + 31) / 32 : 0;
@@ -1074,7 +1078,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
   FAT5_STAMP(7);
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
   FAT5_STAMP(8);
   wait_dma_all();
   __syncthreads();
@@ -1369,7 +1373,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       return fast;
     };
     // every key of the step visible to all 64 rows of the wave (no key tail, no causal mask)?  Monotone: earlier steps see more
-    auto all_visible = [&](const int t) { return t * 32 + 32 <= N && (!a.causal || t * 32 + 31 <= qw0 + P); };
+    auto all_visible = [&](const int t) { return t * 32 + 32 <= N && (!a.causal || ctab || t * 32 + 31 <= qw0 + P); };  // (ctab: the table masks)
     // (single-body inner loops, not one loop over `fast ? A : B`: the register allocator keeps one assignment per loop and
     //  pays its copies only at the few transitions)
     int t = 0;

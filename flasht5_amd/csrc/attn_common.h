@@ -269,14 +269,17 @@ FAT5_DEV RpeTableRegs rpe_table_load_first(const float* rpe1d_h, int R, int tid,
     for (int u = 0; u < 2; ++u) r.vv[2 * c + u] = rpe1d_h[min(max(tid + u * nthreads + c - kRpePad, 0), n1 - 1)];
   return r;
 }
-FAT5_DEV void rpe_table_fill_rest(float* sT_raw, const float* rpe1d_h, int R, int tid, int nthreads, const RpeTableRegs& first) {
+// dcut: entries of relative positions d = key - row ABOVE dcut are stored as -inf (p = 0, dS = 0): with a causal mask whose diagonal lies inside the
+// band (d <= P visible, P < R) the masked elements of a diagonal step then need no instruction of their own -- the step runs the pipelined band iteration
+FAT5_DEV void rpe_table_fill_rest(float* sT_raw, const float* rpe1d_h, int R, int tid, int nthreads, const RpeTableRegs& first, int dcut = 0x7fffffff) {
   const int n1 = 2 * R + 1, n1p = rpe_n1p(R);
+  const int mcut = dcut == 0x7fffffff ? 0x7fffffff : dcut + R + kRpePad;  // (copy c, entry m holds d = m + c - kRpePad - R)
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int m = tid + u * nthreads;
-      if (m < n1p) sT_raw[c * n1p + m] = first.vv[2 * c + u] * kLog2e;
+      if (m < n1p) sT_raw[c * n1p + m] = (m + c > mcut) ? -INFINITY : first.vv[2 * c + u] * kLog2e;
     }
   for (int m0 = tid + 2 * nthreads; m0 < n1p; m0 += 2 * nthreads) {
     float vv[8];
@@ -289,7 +292,7 @@ FAT5_DEV void rpe_table_fill_rest(float* sT_raw, const float* rpe1d_h, int R, in
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int m = m0 + u * nthreads;
-        if (m < n1p) sT_raw[c * n1p + m] = vv[2 * c + u] * kLog2e;
+        if (m < n1p) sT_raw[c * n1p + m] = (m + c > mcut) ? -INFINITY : vv[2 * c + u] * kLog2e;
       }
   }
 }

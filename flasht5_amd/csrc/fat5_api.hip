@@ -388,7 +388,12 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     constexpr long FUSED64_MAX_WG = 1152;
     // (a call that forces or forbids one of the 64-wide bodies / launch forms keeps that choice)
     const bool squarish = 2 * (p->M < p->N ? p->M : p->N) >= (p->M < p->N ? p->N : p->M);
-    const bool rule = !p->causal && (tot <= 384 || (tot <= FUSED64_MAX_WG && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    // causal with the T5 bias and the diagonal inside the band (-R <= N - M < R): the bias table in LDS carries the mask (-inf above the diagonal), the
+    // diagonal steps run the pipelined band iteration (round 4).  Measured, one-launch 64-wide form vs the previous choice: (4,12,512) 29.7 vs 32.9 us,
+    // (4,12,1024) 64.6 vs 60.8, (4,12,2048) 156.0 vs 174.5, (4,12,4096) 433.7 vs 428.1, (16,12,512) 76.5 vs 94.2, (16,12,1024) 208.0 vs 210.1
+    const bool ctab = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
+    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= 256 || (tot >= 512 && tot <= FUSED64_MAX_WG)));
+    const bool rule = causal_ok && (tot <= 384 || (tot <= FUSED64_MAX_WG && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }
   if (L.fused64) {
