@@ -166,6 +166,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   const int64_t lse_off = ((int64_t)b * a.H + h) * a.M;
 
   const int P = N - M;  // bottom-right causal offset
+  // the causal mask carried by the bias table (attn_bwd64.h: -inf above the diagonal when it lies inside the band): diagonal tiles run the pipelined band block
+  [[maybe_unused]] const bool ctab = BIAS == FAT5_BIAS_RPE1D && a.causal && P < a.R && P >= -a.R;
   int n_end = N;
   if (a.causal) n_end = min(N, m0 + BM + P);
   const int nt = n_end > 0 ? (n_end + BN - 1) / BN : 0;
@@ -309,7 +311,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   };
   FAT5_FSTAMP(1);
   stage_first();
-  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr);
+  if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
   FAT5_FSTAMP(2);
   wait_dma_all();
   __syncthreads();
@@ -770,7 +772,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   //   optimistic sweep: [0, tbA) constant | [tbA, tbB) band (rounded outwards to multiples of NS tiles: a band-mode tile reads
   //                     the padded table whatever its position) | [tbB, t_full) constant | [t_full, nt) masked, unpipelined
   int t_full = N / BN;
-  if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));
+  if (a.causal && !ctab) t_full = min(t_full, max(0, (m0 + P + 1) / BN));
   t_full = min(t_full, nt);
   int ta = 0, tb0 = 0, tb1 = 0, tbA = 0, tbB = 0;
   float cst_a = 0.f, cst_b = 0.f;
