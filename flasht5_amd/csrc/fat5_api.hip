@@ -173,6 +173,7 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   // the chip (fat5_attn_params.variant: FAT5_V_FWD64_OFF disables, FAT5_V_FWD64_ON forces wherever the body applies)
   const int f64_env = vsel(p->variant, FAT5_V_FWD64_ON, FAT5_V_FWD64_OFF);
   const long waves64 = bh * ((p->M + 63) / 64);  // waves of 64 query rows x all keys
+  const bool ctab = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;  // (the bias table carries the causal mask: attn_fwd64.h)
   // Dense bias (round 4): the 64-row body with a two-tile bias ring in LDS -- one workgroup per CU, one wave per SIMD, so it needs
   // the chip full of 64-row waves; bf16 (the sweep without a running maximum), bias rows 16-byte aligned (LDS-DMA)
   const bool dense64 = p->D == 64 && p->bias_mode == FAT5_BIAS_DENSE && p->dtype == FAT5_BF16 && !p->cu_seqlens_q && f64_env != 0 &&
@@ -194,7 +195,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                         //  tools/dispatch_audit.py: (4,12,512) causal 10.0 vs 11.2 us, (8,12,512) causal 15.7 vs 17.5 -- or in the 1.5-waves-per-SIMD
                         //  range where the 64-row waves fill the chip unevenly: (16,12,512) 22.2 vs 24.8; (16,12,1024x512) and (16,12,2048x512),
                         //  2 and 4 full rounds, stay on the 64-row body: 33.6 vs 36.8, 62.4 vs 68.5)
-                        !(p->N <= 512 && (p->causal || (waves64 > 1024 && waves64 < 2048))) &&
+                        // (causal with the T5 bias and the diagonal inside the band -- ctab, round 4: the table carries the mask, diagonal tiles are pipelined band
+                        //  tiles: (4,12,512) causal 9.9 vs 10.8 us, (8,12,512) 13.7 vs 16.9, (16,12,512) 21.7 vs 23.8)
+                        !(p->N <= 512 && ((p->causal && !ctab) || (!p->causal && waves64 > 1024 && waves64 < 2048))) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     c.fwd64 = true;
@@ -208,7 +211,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 ||
-                                                        (p->causal && waves64 <= std::min<long>(8192, 2L * p->N) && p->N < 2 * p->M)));
+                                                        (p->causal && waves64 <= (ctab ? 8192 : std::min<long>(8192, 2L * p->N)) && p->N < 2 * p->M)));
+    // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
     //  interleaved A/B timings: tools/ab_variants.py)
     c.ksplit = ksplit;

@@ -294,7 +294,8 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
-        (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(dq="64row", dkdv="64key", fused="1")),   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
+        (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
+        (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
         (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="32row")),                          # (384 workgroups: the measured exception)
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(dq="32row", dkdv="32key", fused="1")),          # causal without bias: the 32-wide bodies side by side
         (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-mixed", dq="64row", dkdv="64key", fused="1")),   # 1.5 64-row waves per SIMD: 256-row and key-split workgroups in one launch
