@@ -197,7 +197,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                         //  2 and 4 full rounds, stay on the 64-row body: 33.6 vs 36.8, 62.4 vs 68.5)
                         // (causal with the T5 bias and the diagonal inside the band -- ctab, round 4: the table carries the mask, diagonal tiles are pipelined band
                         //  tiles: (4,12,512) causal 9.9 vs 10.8 us, (8,12,512) 13.7 vs 16.9, (16,12,512) 21.7 vs 23.8)
-                        !(p->N <= 512 && ((p->causal && !ctab) || (!p->causal && waves64 > 1024 && waves64 < 2048))) &&
+                        //  (round-4 audit, profiles/r04_dispatch_audit.log: the non-causal 1.5-waves-per-SIMD exception at <= 512 keys is gone -- (16,12,512) T5 bias 23.3
+                        //   key-split vs 25.0 us for the 32-row body, 21.7 vs 22.0 without bias)
+                        !(p->N <= 512 && p->causal && !ctab) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     c.fwd64 = true;
@@ -210,7 +212,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // Causal: the workgroups of a (b, h) pair have unequal lengths, finer units balance better -- (4,12,1024) 22.0 vs 23.5 us, (8,12,2048)
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && ((waves64 > 1024 && waves64 < 2048) || waves64 < 512 ||
+    // (round-4 audit: also between 512 and 1024 waves -- (4,12,1024) T5 bias 20.7 vs 22.6 us, none 19.4 vs 19.9; (8,12,512) 14.3 vs 16.1, 12.9 vs 13.5)
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && (waves64 < 2048 ||
                                                         (p->causal && waves64 <= (ctab ? 8192 : std::min<long>(8192, 2L * p->N)) && p->N < 2 * p->M)));
     // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
@@ -396,8 +399,10 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // diagonal steps run the pipelined band iteration (round 4).  Measured, one-launch 64-wide form vs the previous choice: (4,12,512) 29.7 vs 32.9 us,
     // (4,12,1024) 64.6 vs 60.8, (4,12,2048) 156.0 vs 174.5, (4,12,4096) 433.7 vs 428.1, (16,12,512) 76.5 vs 94.2, (16,12,1024) 208.0 vs 210.1
     const bool ctab = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
-    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= 256 || (tot >= 512 && tot <= FUSED64_MAX_WG)));
-    const bool rule = causal_ok && (tot <= 384 || (tot <= FUSED64_MAX_WG && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    // (round-4 audit: (2,12,2048) causal 80.9 vs 92.9 us -- the 384-workgroup exception holds at <= 1024 keys only; (8,12,2048) causal, 1536 workgroups: 269.8 vs 283.4)
+    const long max_wg = (ctab && p->N <= 2048) ? 1536 : FUSED64_MAX_WG;
+    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= 256 || tot >= 512 || p->N >= 2048));
+    const bool rule = causal_ok && (tot <= 384 || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }
   if (L.fused64) {

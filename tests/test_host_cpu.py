@@ -318,7 +318,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row")),                    # 3072 waves of 16 tiles: nothing left to split
         (dict(B=16, H=12, M=1024, N=4096, causal=True), dict(fwd="64row")),                    # N >= 2M: the mask shortens nothing
         # large batch, short keys: the uneven 1.5-waves-per-SIMD range keeps the 32-row forward; whole rounds do not
-        (dict(B=16, H=12, M=512, N=512), dict(fwd="32row")),
+        (dict(B=16, H=12, M=512, N=512), dict(fwd="64row-ksplit")),                            # (round-4 audit: the 1.5-waves-per-SIMD exception at <= 512 keys is gone)
         (dict(B=16, H=12, M=1024, N=512), dict(fwd="64row")),
         (dict(B=16, H=12, M=1024, N=1024), dict(fwd="64row", dq="32row", dkdv="64key")),
         # under-filled grids with long streams

@@ -18,8 +18,10 @@ ap.add_argument("--max-work", type=float, default=48 * 8192.0 ** 2 * 1.01)
 ap.add_argument("--MN", default="")  # rectangular problems instead of --S: "512x1024,2048x512" (M x N)
 a = ap.parse_args()
 
-FWD = {"default": 0, "32row": L.V_FWD64_OFF, "64row": L.V_FWD64_ON | L.V_FWD64_KSPLIT_OFF, "64row-ksplit": L.V_FWD64_ON | L.V_FWD64_KSPLIT_ON}
+FWD = {"default": 0, "32row": L.V_FWD64_OFF, "64row": L.V_FWD64_ON | L.V_FWD64_KSPLIT_OFF, "64row-ksplit": L.V_FWD64_ON | L.V_FWD64_KSPLIT_ON | L.V_FWD64_MIX_OFF,
+       "64row-mixed": L.V_FWD64_ON | L.V_FWD64_MIX_ON}
 DQ = {"default": 0, "32row": L.V_Q64_OFF, "64row": L.V_Q64_ON}
+BWD = {"default": 0, "separate": L.V_FUSED64_OFF, "fused64": L.V_FUSED64_ON}  # (round 4: dQ + dK/dV of one call, the library's choice against the one-launch 64-wide form forced / forbidden)
 KV = {"default": 0, "32key": L.V_KV64_OFF, "64key": L.V_KV64_ON | L.V_KV64_HALF_OFF | L.V_KV64_MIX_OFF, "64key-half": L.V_KV64_ON | L.V_KV64_HALF_ON,
       "64key-mixed": L.V_KV64_ON | L.V_KV64_MIX_ON}
 
@@ -73,6 +75,16 @@ for bh in a.bh.split(","):
                     line += f" | {stage}: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
                     if bad:
                         flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
+                res = {}
+                for name, bits in BWD.items():
+                    plan.set_variant(bits)
+                    res[name] = gpu_time(lambda: plan.backward(3), it)
+                plan.set_variant(0)
+                best = min((t, n) for n, t in res.items() if n != "default")
+                bad = res["default"] > 1.05 * best[0]
+                line += f" | bwd: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
+                if bad:
+                    flags.append((B, H, M, S, causal, mode, "bwd", round(res["default"], 1), best[1], round(best[0], 1)))
                 print(line, flush=True)
                 del plan, q, k, v, do
 print("\nmis-dispatches (> 5 % behind the best forced body):", len(flags))
