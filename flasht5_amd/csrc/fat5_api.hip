@@ -214,7 +214,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     // (round-4 audit: also between 512 and 1024 waves -- (4,12,1024) T5 bias 20.7 vs 22.6 us, none 19.4 vs 19.9; (8,12,512) 14.3 vs 16.1, 12.9 vs 13.5)
     const bool ksplit = ks_env == 1 || (ks_env != 0 && (waves64 < 2048 ||
-                                                        (p->causal && waves64 <= (ctab ? 8192 : std::min<long>(8192, 2L * p->N)) && p->N < 2 * p->M)));
+                                                        (p->causal && waves64 <= 8192 && p->N < 2 * p->M)));
+    // (round-4 audit: without bias as well -- (16,12,1024) causal 51.1 split vs 55.1 us, (16,12,2048) 138.7 vs 151.5: the split form's Q / O now travel as whole rows)
     // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
     //  interleaved A/B timings: tools/ab_variants.py)
@@ -351,7 +352,10 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   // at ~2.5x the cost of a pipelined step -- half of all steps at S = 1024, 6 % at 8192.  Measured dK/dV, 64-key against 32-key body:
   // (4,12,8192) 853 vs 940 us, (4,12,4096) 239 vs 246, (4,12,2048) T5 bias 118 vs 104, (16,12,2048) 298 vs 273, (16,12,1024) 111 vs 95
   // -> causal problems take the 64-key body from 4096 keys on.
-  const bool kv64_causal_ok = !p->causal || p->N >= 4096;
+  // (round 4: with the T5 bias and the diagonal inside the band the table carries the mask and the diagonal steps are pipelined band steps: (16,12,2048) causal
+  //  64-key mixed 292 vs 326 us, (8,12,2048) 154 vs 169 -> from 2048 keys on)
+  const bool ctab_kv = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
+  const bool kv64_causal_ok = !p->causal || p->N >= (ctab_kv ? 2048 : 4096);
   L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
            (b64_env == 1 || ((wg256 >= (fills ? 320 : 512) ||
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
@@ -375,7 +379,7 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
           (q64_env == 1 || ((bh * ((p->M + 255) / 256) >= 512 || (bh * ((p->M + 255) / 256) >= 160 && p->N >= 8192)) &&  // ((4,12,1024x8192): 153 vs 166 us)
-                            p->N >= (p->bias_mode == FAT5_BIAS_RPE1D ? 4096 : 2048) && (!p->causal || p->M >= 16384)));  // (T5 bias, band steps in the pipelined iteration since round 4:
+                            p->N >= ((p->bias_mode == FAT5_BIAS_RPE1D && bh * ((p->M + 255) / 256) < 1024) ? 4096 : 2048) && (!p->causal || p->M >= 16384)));  // ((16,12,2048) T5 bias, 1536 workgroups: 309 vs 325 us)  // (T5 bias, band steps in the pipelined iteration since round 4:
                                                               //  (4,12,4096) 284-295 vs 298 us, (4,12,8192) 1089 vs 1107; (4,12,2048), 1.5 rounds: 97 vs 83 -> from 4096 keys on)
   // Both 64-wide bodies in ONE launch (attn_bwd_fused64_kernel; the dK/dV half forms its row statistics itself): one workgroup per CU
   // either way, so the two grids fill each other's empty last rounds -- and at cfg2 (96 + 96 workgroups) run side by side.

@@ -315,7 +315,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
         (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),
-        (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row")),                    # 3072 waves of 16 tiles: nothing left to split
+        (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row-ksplit")),             # (round-4 audit: 51.1 vs 55.1 us -- the split form's Q / O travel as whole rows now)
         (dict(B=16, H=12, M=1024, N=4096, causal=True), dict(fwd="64row")),                    # N >= 2M: the mask shortens nothing
         # large batch, short keys: the uneven 1.5-waves-per-SIMD range keeps the 32-row forward; whole rounds do not
         (dict(B=16, H=12, M=512, N=512), dict(fwd="64row-ksplit")),                            # (round-4 audit: the 1.5-waves-per-SIMD exception at <= 512 keys is gone)
