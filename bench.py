@@ -534,6 +534,33 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def drive_steps(steps, U, one_step, replay_u, reducer, grad, stash):
+    """The loop of the timed region: exactly `steps` steps of the local path and the exchange of each step's bias(-table) gradient.
+    U == 1 (the default with N > 1 ranks): after every step `grad` goes into ONE all-reduce (asynchronous, double-buffered: it overlaps
+    the next step like a DDP bucket).  U > 1 (--bucket-allreduce): `replay_u` runs U steps that leave their gradients in `stash`, which
+    travels in one all-reduce per replay.  Returns the number of all-reduces this rank submitted (tests/test_distributed_cpu.py checks it
+    over gloo; the JSON line reports it as allreduces_per_step)."""
+    n0 = reducer.n if reducer is not None else 0
+    if U > 1 and replay_u is not None:
+        for _ in range(steps // U):
+            replay_u()
+            if reducer is not None:
+                reducer.submit(stash)
+        for _ in range(steps % U):
+            one_step()
+            if reducer is not None:
+                stash[0].copy_(grad)
+                reducer.submit(stash)
+    else:
+        for _ in range(steps):
+            one_step()
+            if reducer is not None:
+                reducer.submit(grad)
+    if reducer is not None:
+        reducer.drain()  # every step's all-reduce finishes inside the timed region
+    return (reducer.n - n0) if reducer is not None else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -545,7 +572,11 @@ def main():
                     help="N > 1: weak = one (4,12,S,64) batch per rank; strong = ONE batch split over the ranks by (batch, head) units")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=16, help="steps captured per HIP graph replay (the timed region still runs exactly --steps steps, "
-                    "every one the same launches on the same batch; 1 = one replay per step: a replay boundary costs ~5 us on this stack)")
+                    "every one the same launches on the same batch; 1 = one replay per step: a replay boundary costs ~5 us on this stack).  "
+                    "With more than one rank the default is ONE step per replay and one all-reduce per step (see --bucket-allreduce)")
+    ap.add_argument("--bucket-allreduce", action="store_true", help="N > 1 only: keep --graph-steps steps per replay and send their bias(-table) gradients in ONE "
+                    "all-reduce per replay (what DDP's bucketing does with small gradients).  NOT the default: a data-parallel step cannot defer its gradient "
+                    "past its own optimizer step, so the default N > 1 line runs exactly one all-reduce per step; with this flag the line also reports the per-step form")
     ap.add_argument("--no-extras", action="store_true", help="skip by_seq / cpu baseline (profiling runs)")
     args = ap.parse_args()
 
@@ -563,9 +594,29 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
+        # the N > 1 loop of the timed region with a stand-in for the local step (the HIP path needs a GPU): what is under test is how
+        # many collectives a step costs
+        from flasht5_amd.sharding import OverlappedGradReduce
+        grad = torch.zeros(32, H)
+        U = max(1, args.graph_steps) if args.bucket_allreduce else 1
+        stash = torch.zeros((U, 32, H)) if U > 1 else None
+        cnt = {"i": 0}
+
+        def one_step():
+            cnt["i"] += 1
+            grad.fill_(float(cnt["i"] * (rank + 1)))
+
+        def replay_u():
+            for u in range(U):
+                one_step()
+                stash[u].copy_(grad)
+
+        red = OverlappedGradReduce(stash if stash is not None else grad)
+        n_ar = drive_steps(args.steps, U, one_step, replay_u if U > 1 else None, red, grad, stash)
         if rank == 0:
             print(json.dumps({"rendezvous": world, "n_gpus": world, "gpus_arg": args.gpus, "sum_of_ranks_plus_1": t.item(),
-                              "scaling": args.scaling}), flush=True)
+                              "scaling": args.scaling, "steps": args.steps, "allreduces": n_ar,
+                              "allreduces_per_step": round(n_ar / args.steps, 4)}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -623,6 +674,8 @@ def main():
     # bias(-table) gradient is kept (one stream-ordered copy per step inside the graph, what the reducer's staging copy is at U = 1) and
     # the U of them travel in ONE all-reduce per replay: every step's gradient is reduced exactly once, in buckets of U.
     U = max(1, args.graph_steps) if graph is not None else 1
+    if want_reduce and not args.bucket_allreduce:
+        U = 1  # north star: "a single RCCL all-reduce of the bias gradient" per backward -- every step's gradient leaves in its own collective
     if U > 1 and args.steps % U:  # a step count that is not a multiple: a nearby replay length that divides it, so no step is left to single replays
         div = [u for u in range(8, 33) if args.steps % u == 0]
         if div:
@@ -642,19 +695,11 @@ def main():
         torch.cuda.synchronize()
     reducer = OverlappedGradReduce(stash if stash is not None else plan.dbias) if want_reduce else None
 
-    def step():
+    def one_step():
         if graph is not None:
             graph.replay()
         else:
             step_local()
-        if reducer is not None:
-            # the ONE exchange of the path: bias(-table) gradient, fp32 SUM over xGMI -- one all-reduce per step (U > 1: per replay of U
-            # steps), asynchronous on RCCL's stream (overlaps the next step's kernels like DDP overlaps its buckets)
-            if stash is not None:
-                stash[0].copy_(plan.dbias)
-                reducer.submit(stash)
-            else:
-                reducer.submit(plan.dbias)
 
     # Untimed pre-warm, by wall clock: a step is ~60 us, so a fixed W would end long before the GPU has left its idle
     # clock (585 MHz -> ~1.95 GHz sustained) and before the host's graph-launch path is warm.
@@ -668,35 +713,37 @@ def main():
             else:
                 step_local()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    if reducer is not None:
-        reducer.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+
+    def timed(use_bucket):
+        """exactly args.steps steps between two barriers; returns (max-over-ranks seconds, all-reduces submitted by this rank inside the region)"""
+        u = U if (use_bucket and graph_u is not None) else 1
+        drive_steps(args.warmup, 1, one_step, None, reducer if u == 1 else None, plan.dbias, None)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = drive_steps(args.steps, u, one_step, graph_u.replay if u > 1 else None, reducer, plan.dbias, stash)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el, n
+
+    elapsed, n_ar = timed(True)
+    per_step_form = None
     if graph_u is not None:
-        for _ in range(args.steps // U):
-            graph_u.replay()
-            if reducer is not None:
-                reducer.submit(stash)
-        for _ in range(args.steps % U):
-            step()
-    else:
-        for _ in range(args.steps):
-            step()
-    if reducer is not None:
-        reducer.drain()  # every step's all-reduce finishes inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        # the other launch form beside the headline: one replay (and, N > 1, one all-reduce) per step
+        if reducer is not None:
+            reducer = OverlappedGradReduce(plan.dbias)
+        e1, n1 = timed(False)
+        per_step_form = {"ms_per_step": round(e1 / args.steps * 1e3, 5), "launch": "hipGraph replay, 1 step per replay"}
+        if want_reduce:
+            per_step_form["allreduces_per_step"] = round(n1 / args.steps, 4)
     ms_per_step = elapsed / args.steps * 1e3
     flops_step = 3.5 * fwd_flops(S) * (1 if strong else world)
     value = flops_step / (ms_per_step * 1e-3) / 1e12
@@ -726,6 +773,13 @@ def main():
             "frac_of_peak": round(value / (PEAK_BF16_TFLOPS * world), 4),
             "per_gpu_tflops": round(value / world, 2),
         }
+        if want_reduce:
+            # collectives this rank submitted inside the timed region / steps: 1.0 = the north star's "single RCCL all-reduce of the bias
+            # gradient" per backward (the default); 1/U only with --bucket-allreduce
+            out["allreduces_per_step"] = round(n_ar / args.steps, 4)
+            out["allreduce_mode"] = "bucketed: one per replay of %d steps" % U if (args.bucket_allreduce and U > 1) else "one per step"
+        if per_step_form is not None:
+            out["one_replay_per_step"] = per_step_form
         if ar_ms is not None:
             out["bias_grad_allreduce_ms"] = round(ar_ms, 4)
             if strong:

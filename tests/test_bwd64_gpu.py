@@ -71,7 +71,10 @@ def _table_truth(q, k, v, bias, o, L, do, scale, causal, table, M, N, bidir, md)
     (2, 3, 1024, 1024, False, "none", 128),   # four key blocks per (b, h)
     (2, 3, 1024, 1024, False, "rpe", 128),    # far-positive range, band (general steps), far-negative range
     (1, 2, 1024, 1024, False, "rpe", 32),     # narrow band: pipelined ranges on both sides of every workgroup
-    (1, 2, 2048, 2048, True, "rpe", 128),     # causal: diagonal steps general, steps above the diagonal skipped
+    (1, 2, 2048, 2048, True, "rpe", 128),     # causal: the mask rides in the bias table (P = 0), steps above the diagonal skipped
+    (1, 2, 1000, 1100, True, "rpe", 128),     # ... 0 < P = N - M < R: the cut at a non-zero table offset, ragged rows / keys
+    (1, 2, 1100, 1000, True, "rpe", 128),     # ... -R <= P < 0: dead rows (L = -inf) meet -inf table entries
+    (1, 2, 2048, 1952, True, "rpe", 128),     # ... P = -96, whole steps
     (1, 2, 2048, 2048, True, "none", 128),
     (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: last step padded (rows past M), key tail workgroup (all general)
     (1, 2, 300, 2500, True, "rpe", 128),      # M << N, bottom-right causal
@@ -260,6 +263,9 @@ def test_bwd64_mixed_launch_matches_the_256_key_launch(B, H, M, N, causal, mode)
     (4, 12, 1536, 1536, False, "rpe", 128),   # 576 workgroups on 256 CUs: dQ workgroups queue behind the dK/dV ones
     (2, 3, 1024, 1024, False, "none", 128),
     (1, 2, 2048, 2048, True, "rpe", 128),     # causal: masked (general) steps produce their statistics the same way
+    (1, 2, 1000, 1100, True, "rpe", 128),     # causal with the mask in the table at a non-zero offset (0 < N - M < R)
+    (1, 2, 1100, 1000, True, "rpe", 128),     # ... N - M < 0: dead rows whose statistics the dK/dV half forms itself
+    (1, 2, 2048, 1952, True, "rpe", 128),
     (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: the last step's rows past M (raw L reads as zero there), a key tail
     (1, 2, 300, 2500, True, "rpe", 32),       # M << N
     (1, 2, 2500, 300, True, "none", 128),     # M >> N: dead rows

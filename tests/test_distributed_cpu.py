@@ -152,3 +152,62 @@ def test_bench_gpus_flag_spawns_the_ranks():
         assert len(line) == 1, r.stdout  # ONE JSON line, from rank 0 only
         out = json.loads(line[0])
         assert out["rendezvous"] == 2 and out["n_gpus"] == 2 and out["sum_of_ranks_plus_1"] == 3.0 and out["scaling"] == scaling
+        # the default N > 1 loop (bench.py::drive_steps, the loop of the timed region) submits ONE all-reduce per step
+        assert out["allreduces"] == 2 and out["allreduces_per_step"] == 1.0
+
+
+def test_bench_allreduce_count_per_step_and_bucketed():
+    """north star: "a single RCCL all-reduce of the bias gradient" per backward.  bench.py's N > 1 loop (drive_steps) over gloo: the default
+    submits exactly one all-reduce per step; --bucket-allreduce --graph-steps 4 one per replay of four steps (and one per leftover step)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["FAT5_BENCH_RENDEZVOUS_ONLY"] = "1"
+    for extra, want in (([], 10), (["--bucket-allreduce", "--graph-steps", "4"], 2 + 2)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["allreduces"] == want and out["allreduces_per_step"] == round(want / 10, 4), out
+
+
+def _drive_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from flasht5_amd.sharding import OverlappedGradReduce
+    grad = torch.zeros(32, 12)
+    red = OverlappedGradReduce(grad)
+    red.keep_results = True
+    seen = []
+    orig = red.submit
+
+    def submit(g):  # every reduced value, in order
+        r = orig(g)
+        if r is not None:
+            seen.append(r)
+        return r
+    red.submit = submit
+    i = {"n": 0}
+
+    def one_step():
+        i["n"] += 1
+        grad.fill_(float(i["n"] * (rank + 1)))
+    n = bench.drive_steps(6, 1, one_step, None, red, grad, None)
+    assert n == 6 and i["n"] == 6  # six steps, six collectives
+    want = sum(r + 1 for r in range(world))
+    for j, t in enumerate(seen):  # step j's own gradient, summed over the ranks (the last two are returned by the drain inside)
+        assert torch.all(t == want * (j + 1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_drive_steps_reduces_every_step_once_two_ranks():
+    mp.spawn(_drive_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -37,7 +37,12 @@ def _run(q, k, v, do, causal, scale, table=None, bidir=True, md=128):
     (2, 3, 1024, 1024, False, "none", torch.bfloat16),    # pipelined range + remainder tiles
     (2, 3, 1024, 1024, False, "rpe", torch.bfloat16),     # far-negative range, band, far-positive range
     (1, 2, 1280, 1280, False, "rpe", torch.bfloat16),     # band range cut short by the end of the keys (tail tiles in band mode)
-    (1, 2, 2048, 2048, True, "rpe", torch.bfloat16),      # causal: diagonal tiles generic, ranges shortened per workgroup
+    (1, 2, 2048, 2048, True, "rpe", torch.bfloat16),      # causal: the mask rides in the bias table (P = N - M = 0 inside the band): diagonal tiles run band blocks
+    (1, 2, 1000, 1100, True, "rpe", torch.bfloat16),      # ... with the cut at a non-zero table offset (0 < P < R), ragged rows and keys
+    (1, 2, 1100, 1000, True, "rpe", torch.bfloat16),      # ... P < 0: the first 100 rows see no key (L = -inf together with a -inf table)
+    (1, 2, 2048, 1952, True, "rpe", torch.bfloat16),      # ... P = -96 on whole tiles
+    (1, 2, 1100, 1000, True, "rpe", torch.float16),       # ... fp16: dead rows and partly masked first tiles under the first-tile reference point
+    (1, 2, 1000, 1100, True, "rpe", torch.float16),
     (1, 2, 2048, 2048, True, "none", torch.bfloat16),
     (1, 2, 1000, 1100, False, "rpe", torch.bfloat16),     # ragged M and N (row clamp, N tail)
     (1, 2, 300, 2500, True, "rpe", torch.bfloat16),       # M << N, bottom-right causal
