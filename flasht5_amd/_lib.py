@@ -140,6 +140,7 @@ V_KV64_MIX_ON, V_KV64_MIX_OFF = 16384, 32768
 V_FWD64_MIX_ON, V_FWD64_MIX_OFF = 524288, 1048576
 V_FUSED64_ON, V_FUSED64_OFF = 65536, 131072
 V_DBIAS_NOSPLIT = 262144
+V_QDB64_ON, V_QDB64_OFF = 2097152, 4194304
 _variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)
 
 

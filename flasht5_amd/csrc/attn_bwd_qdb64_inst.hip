@@ -1,0 +1,37 @@
+// Instantiations of the dense-bias dQ + batch-reduced dBias body (attn_bwd_qdb64.h), D = 64, bf16.
+#include "attn_bwd_qdb64.h"
+#include "attn_launch.h"
+
+namespace fat5 {
+
+// grid = H * ceil(B / 4) * ceil(M / 64) workgroups; `dbias_out`: the (H, M, N) 16-bit dbias (B <= 4) or the (ceil(B / 4), H, M, N) fp32 slabs
+hipError_t launch_bwd_qdb64_d64(const AttnArgs& a, int bf16, void* dbias_out, int partial, int grid, hipStream_t s) {
+  if (!bf16) return hipErrorInvalidValue;
+  AttnArgs as = a;
+  as.n_mblk = (a.M + 63) / 64;
+  as.mg_mblk = div_magic(as.n_mblk, grid);
+  grid = (grid + 7) / 8 * 8;  // (eight contiguous chunks of work items, one per XCD: see the kernel)
+  constexpr int smem = BwdQdb64Cfg<64>::SMEM;
+  if (partial) {
+    auto kern = attn_bwd_qdb64_kernel<64, true, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as, dbias_out);
+  } else {
+    auto kern = attn_bwd_qdb64_kernel<64, true, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as, dbias_out);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_dbias_partial_reduce(const float* part, void* out, int bf16, int ngrp, int H, int M, int N, int causal, hipStream_t s) {
+  const int64_t HMN = (int64_t)H * M * N;
+  const int grid = (int)((HMN / 8 + 255) / 256);
+  if (bf16) hipLaunchKernelGGL(dbias_partial_reduce_kernel<true>, dim3(grid), dim3(256), 0, s, part, (uint16_t*)out, ngrp, HMN, M, N, causal, N - M);
+  else hipLaunchKernelGGL(dbias_partial_reduce_kernel<false>, dim3(grid), dim3(256), 0, s, part, (uint16_t*)out, ngrp, HMN, M, N, causal, N - M);
+  return hipGetLastError();
+}
+
+}  // namespace fat5

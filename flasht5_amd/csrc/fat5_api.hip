@@ -54,6 +54,8 @@ struct BwdLayout {
   bool fused64;     // both 64-wide bodies in one launch when a call asks for both stages (attn_bwd_fused64_kernel); implies kv64 (256-key) and q64
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
+  bool qdb64;       // dense (1, H, M, N) bias shared by the batch: dQ AND the batch-reduced dbias by attn_bwd_qdb64_kernel (four batch elements per workgroup)
+  int qdb_groups;   // ... ceil(B / 4); > 1: fp32 slabs in the workspace + dbias_partial_reduce_kernel
   int n_nblk;
   int nw_q, nw_kv;
 };
@@ -427,7 +429,28 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   L.dbias_inkernel = false;
   L.ds_off = off;
   L.scratch_off = off;
-  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias) {
+  L.qdb64 = false;
+  L.qdb_groups = 0;
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && p->D == 64 && p->dtype == FAT5_BF16) {
+    // Round 5: the reference's own operator -- one (1, H, M, N) bias for the whole batch (modeling_flash_t5.py:280-285) -- runs its dQ and the batch
+    // sum of dS in ONE kernel (attn_bwd_qdb64.h): no (B, H, M, N) staging tensor, no third recomputation of S / dP.
+    const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
+    const int ngrp = (p->B + 3) / 4;
+    const bool legal = p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
+                       p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
+                       (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
+                       (int64_t)p->M * p->N * (ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
+                       ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+    if (legal && qdb_env != 0 && (qdb_env == 1 || p->B >= 2)) {
+      L.qdb64 = true;
+      L.qdb_groups = ngrp;
+      L.q64 = false;
+      L.fused64 = false;
+      L.nw_q = 2;  // (64 query rows per workgroup: n_mblk = ceil(M / 64))
+      if (ngrp > 1) off = align_up(off + (size_t)ngrp * p->H * p->M * p->N * sizeof(float), 256);
+    }
+  }
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && !L.qdb64) {
     const bool reduced = (p->dbias_batch != p->B) || (p->dbias_heads != p->H);
     // (variant FAT5_V_DBIAS_STAGED: the staged (B, H, M, N) + reduction path; FAT5_V_DBIAS_INKERNEL: the batch-inner kernel at any size)
     const int inker_env = (p->variant & FAT5_V_DBIAS_STAGED) ? 0 : ((p->variant & FAT5_V_DBIAS_INKERNEL) ? 2 : 1);
@@ -459,19 +482,21 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
 // search: the last answer is kept per thread, keyed on every argument the function reads.
 static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
   struct Key {
-    int64_t v[20];
+    int64_t v[24];
     bool operator==(const Key& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
   };
   const Key k = {{p->B, p->H, p->M, p->N, p->D, p->bias_mode, p->causal, (int64_t)p->variant, p->rpe_radius, p->dbias_batch, p->dbias_heads,
                   p->bias_stride[0], p->bias_stride[1], p->unit_count, p->total_q, p->cu_seqlens_q != nullptr, p->dbias != nullptr,
-                  p->drpe1d != nullptr, p->drpe_table != nullptr, 0}};
+                  p->drpe1d != nullptr, p->drpe_table != nullptr, p->dtype, p->bias_stride[2], (int64_t)(reinterpret_cast<uintptr_t>(p->bias) & 15), 0, 0}};
   thread_local Key last_k;
   thread_local BwdLayout last_L;
   thread_local int last_rc = -1;
-  if (last_rc >= 0 && last_k == k) {
+  if (last_rc == FAT5_OK && last_k == k) {
     L = last_L;
-    return last_rc;
+    return FAT5_OK;
   }
+  // (only successful answers are kept: a failing call runs again, so that fat5_last_error() is this call's message -- ADVICE r4.
+  //  A rule in bwd_layout_compute that reads a NEW field of *p must add that field to Key above, or a stale layout is returned.)
   const int rc = bwd_layout_compute(p, L);
   last_k = k;
   last_L = L;
@@ -489,7 +514,7 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
 static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D, int variant) {
   if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
   const long fuse_max = 4L * 256;  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
-  return !(variant & FAT5_V_NO_FUSE) && !L.kv64 && !L.q64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
+  return !(variant & FAT5_V_NO_FUSE) && !L.kv64 && !L.q64 && !L.qdb64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
 int fat5_attn_bwd_launches(const fat5_attn_params* p) {
@@ -516,7 +541,8 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
   snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
-           L.q64 ? "64row" : "32row", kv, (fused || L.fused64) ? 1 : 0, L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct"));
+           L.qdb64 ? "64row-batch4" : (L.q64 ? "64row" : "32row"), kv, (fused || L.fused64) ? 1 : 0,
+           L.qdb64 ? (L.qdb_groups > 1 ? "dq-kernel+partials" : "dq-kernel") : (L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct")));
   return FAT5_OK;
 }
 
@@ -575,7 +601,13 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const int64_t MN = (int64_t)p->M * p->N;
   const long bh = (long)p->B * p->H;
   const bool bf16 = p->dtype == FAT5_BF16;
-  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && !L.dbias_inkernel) {
+  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && L.qdb64) {
+    // (tiles above the causal diagonal are never visited: zeros by definition, reference :153,:160; with partial slabs the reduction knows the mask)
+    if (p->causal && (stages & FAT5_BWD_DQ) && L.qdb_groups == 1) {
+      hipError_t e = hipMemsetAsync(p->dbias, 0, (size_t)p->H * MN * 2, stream);
+      if (e != hipSuccess) return hip_fail(e, "memset dbias");
+    }
+  } else if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && !L.dbias_inkernel) {
     if (L.ds_staged) {
       a.ds_out = (uint16_t*)(ws + L.ds_off);
     } else {
@@ -628,7 +660,13 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused64 launch");
   } else {
     // 1) dQ (+ delta)
-    if (stages & FAT5_BWD_DQ) {
+    if ((stages & FAT5_BWD_DQ) && L.qdb64) {
+      // ... and the batch-reduced dbias (or its fp32 slabs) in the same launch
+      const long g = (long)p->H * L.qdb_groups * ((p->M + 63) / 64);
+      if (g > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
+      hipError_t e = launch_bwd_qdb64_d64(a, bf16, L.qdb_groups > 1 ? (void*)(ws + L.scratch_off) : p->dbias, L.qdb_groups > 1, (int)g, stream);
+      if (e != hipSuccess) return hip_fail(e, "attn_bwd_qdb64 launch");
+    } else if (stages & FAT5_BWD_DQ) {
       launch_fn fn = effD(p) == 32 ? launch_bwd_q_d32 : (p->D == 64 ? launch_bwd_q_d64 : launch_bwd_q_d128);
       if (L.q64) fn = launch_bwd_q64_d64;
       hipError_t e = fn(a, bf16, p->bias_mode, L.nw_q, (int)grid_q, stream);
@@ -682,6 +720,10 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     dbias_fn fn = effD(p) == 32 ? launch_bwd_dbias_d32 : (p->D == 64 ? launch_bwd_dbias_d64 : launch_bwd_dbias_d128);
     hipError_t e = fn(ab, bf16, p->dbias, p->B > 4 ? (float*)(ws + L.scratch_off) : nullptr, (int)grid, stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_dbias launch");
+  }
+  if (L.qdb64 && L.qdb_groups > 1 && (stages & FAT5_BWD_REDUCE)) {
+    hipError_t e = launch_dbias_partial_reduce((const float*)(ws + L.scratch_off), p->dbias, bf16, L.qdb_groups, p->H, p->M, p->N, p->causal, stream);
+    if (e != hipSuccess) return hip_fail(e, "dbias_partial_reduce launch");
   }
   if (L.ds_staged && (stages & FAT5_BWD_REDUCE)) {
     const int64_t chunks = (MN + 7) / 8 * p->dbias_batch * p->dbias_heads;

@@ -342,7 +342,7 @@ class GraphedTrainStep:
     `zero_grad(set_to_none=True)` / re-assignment of `p.grad` between replays raises (the graph would keep writing the old buffers
     while `allreduce_gradients` skipped the parameter); clipping happens only if the optimizer was built with `max_grad_norm`
     (the eager warm-up steps behave the same: `train_step(..., max_grad_norm=None)`); one captured step per optimizer
-    (`AdamWScale.release_captured_step()` after destroying this object to capture again)."""
+    (`close()` -- also run when this object is destroyed -- releases it: `AdamWScale.release_captured_step()`)."""
 
     def __init__(self, model, optimizer, group=None, warmup=2, split=None):
         from .adamw_scaled import AdamWScale
@@ -366,22 +366,40 @@ class GraphedTrainStep:
         self.ids, self.labels = input_ids.clone(), labels.clone()
         self.optimizer.init_state()
         self.optimizer.zero_grad(set_to_none=True)  # the gradients are (re)allocated inside the graph's pool
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self.loss = self.model(self.ids, self.labels)
-            self.loss.backward()
-            if not self.split:
-                self.optimizer.step()
-            self.loss = self.loss.detach()
-        self.graphs = [g1]
-        if self.split:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self.optimizer.step()
-            self.graphs.append(g2)
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.loss = self.model(self.ids, self.labels)
+                self.loss.backward()
+                if not self.split:
+                    self.optimizer.step()
+                self.loss = self.loss.detach()
+            graphs = [g1]
+            if self.split:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self.optimizer.step()
+                graphs.append(g2)
+        except BaseException:
+            # a capture that threw midway must not leave the optimizer "holding a captured step" for good
+            self.optimizer.release_captured_step()
+            raise
+        self.graphs = graphs
         # what the capture baked in (see the class docstring)
         self._baked = [(tuple(g["betas"]), float(g["eps"])) for g in self.optimizer.param_groups]
         self._grads = [(p, p.grad) for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+
+    def close(self):
+        """Drop the captured step: the graphs go and the optimizer may capture again (another GraphedTrainStep, e.g. for a new batch shape)."""
+        if self.graphs is not None:
+            self.graphs = None
+            self.optimizer.release_captured_step()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _check_baked(self):
         for g, (betas, eps) in zip(self.optimizer.param_groups, self._baked):

@@ -141,8 +141,13 @@ class LMHeadCrossEntropyMean(torch.autograd.Function):
     def backward(ctx, grad_loss, grad_z):
         del grad_z
         dh, dw = ctx.saved_tensors
-        return (dh * grad_loss.to(dh.dtype) if dh is not None else None, dw * grad_loss.to(dw.dtype) if dw is not None else None,
-                None, None, None, None, None, None)
+        # the upstream scalar is applied in fp32 (rounded to bf16 first, a factor like 1/3 under gradient accumulation is off by
+        # up to 2^-9 and scales every gradient upstream of lm_head; the per-row form and the reference apply dloss in fp32 inside the CE kernel)
+        gl = grad_loss.float()
+
+        def rescale(t):
+            return None if t is None else (t if t.dtype == torch.float32 else t.float()).mul(gl).to(t.dtype)
+        return (rescale(dh), rescale(dw), None, None, None, None, None, None)
 
 
 def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, label_smoothing: float = 0.0,

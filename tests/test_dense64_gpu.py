@@ -1,0 +1,98 @@
+"""GPU parity tests of the dense-bias bodies of round 5 -- the reference's own operator, one (1, H, M, N) bias shared by the batch
+(flash_attention_v2_bias.py:228-288; caller modeling_flash_t5.py:280-285):
+
+ * csrc/attn_bwd_qdb64.h: dQ and the batch-reduced dbias in ONE kernel (four batch elements per workgroup, the batch sum of the rounded dS
+   through LDS on the matrix pipe), forced / forbidden per call with FAT5_V_QDB64_ON / _OFF;
+ * the dense instantiations of the 64-key dK/dV body (csrc/attn_bwd64.h, FAT5_V_KV64_ON) and of the 64-row forward (csrc/attn_fwd64.h, FAT5_V_FWD64_ON).
+
+Against the fp32 oracle at sizes it finishes in seconds, and against the bodies they replace (same terms, same roundings)."""
+import pytest
+import torch
+
+from attn_helpers import make_inputs, oracle_all, maxdiff
+from test_attention_gpu import bound, gbound
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(q, k, v, do, b, causal, scale, bits):
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=scale, variant=bits)
+    plan.forward()
+    plan.dbias.fill_(float("nan"))
+    plan.ws.view(torch.uint8).fill_(255)  # (NaN patterns in the workspace: nothing may be read that was not written)
+    plan.dq.fill_(float("nan"))
+    out = [t.clone() for t in plan.backward()]
+    torch.cuda.synchronize()
+    return plan, out
+
+
+@pytest.mark.parametrize("B,H,M,N,causal", [
+    (4, 3, 256, 256, False),     # one trip of the 3-step loop and change, four waves = four batch elements
+    (4, 2, 512, 512, True),      # causal: masked (general) steps on the diagonal, tiles above it never visited (dbias zero there)
+    (2, 2, 200, 336, False),     # two idle waves, ragged rows, a key tail (N % 32 != 0)
+    (3, 2, 300, 304, True),      # three batch elements, bottom-right causal with N - M = 4
+    (1, 2, 256, 320, False),     # forced at B = 1: three idle waves
+    (6, 2, 192, 256, False),     # B > 4: two groups -> fp32 slabs + partial reduction
+    (16, 2, 256, 256, True),     # the reference benchmark's batch: four groups, causal (the reduction knows the mask)
+    (5, 2, 520, 72, True),       # M >> N: dead rows (lse = -inf), a single partly filled key step
+    (4, 1, 64, 2048, False),     # one row block, many trips
+    (8, 12, 128, 1024, False),   # grid over heads x groups: the XCD-aware decode with 24 (head, group) pairs
+    (4, 2, 1000, 1096, True),    # ragged rows and keys with the mask
+])
+def test_qdb64_matches_oracle_and_the_staged_path(B, H, M, N, causal):
+    from flasht5_amd import _lib
+    dtype = torch.bfloat16
+    q, k, v, b, do = make_inputs(B, H, M, N, 64, dtype, "1h", seed=B * M + N, strided=True)
+    ref = oracle_all(q, k, v, b, do, 0.25, causal)
+    pn, new = _plan(q, k, v, do, b, causal, 0.25, _lib.V_QDB64_ON)
+    po, old = _plan(q, k, v, do, b, causal, 0.25, _lib.V_QDB64_OFF | _lib.V_DBIAS_STAGED)
+    assert pn.describe()["dq"] == "64row-batch4" and po.describe()["dq"] != "64row-batch4"
+    dq, dk, dv, db = new
+    for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert torch.isfinite(got.float()).all(), key
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    assert torch.isfinite(db.float()).all()
+    assert maxdiff(db, ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
+    # same terms (dS rounded to bf16 per batch element), fp32 sum, one rounding -- as the staged path: equal up to one rounding of the sum
+    assert maxdiff(db, old[3]) <= 2.0 ** -7 * max(1.0, ref["db"].abs().max().item())
+    assert maxdiff(dq, old[0]) <= 2.0 ** -7 * max(1.0, ref["dq"].abs().max().item())
+    # workspace: no (B, H, M, N) tensor
+    assert pn.ws.numel() <= B * H * (M + 64) * 4 * 3 + ((B + 3) // 4 > 1) * ((B + 3) // 4) * H * M * N * 4 + 8192
+    if causal:  # above the diagonal: exact zeros
+        keep = torch.arange(N, device="cuda")[None, :] <= torch.arange(M, device="cuda")[:, None] + (N - M)
+        assert bool((db[0][:, ~keep] == 0).all())
+
+
+def test_qdb64_deterministic_and_default_dispatch():
+    from flasht5_amd import _lib
+    q, k, v, b, do = make_inputs(4, 4, 512, 512, 64, torch.bfloat16, "1h", seed=9, strided=True)
+    p0, a = _plan(q, k, v, do, b, False, 0.125, 0)
+    assert p0.describe()["dq"] == "64row-batch4"  # the library's own choice for the model's case
+    _, c = _plan(q, k, v, do, b, False, 0.125, 0)
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)
+    # not legal -> the older paths, same answers to rounding: a per-batch bias, fp16, keys not a multiple of 8
+    qb, kb, vb, bb, dob = make_inputs(2, 2, 256, 256, 64, torch.bfloat16, "bh", seed=3)
+    pb, _ = _plan(qb, kb, vb, dob, bb, False, 0.125, 0)
+    assert pb.describe()["dq"] != "64row-batch4"
+    qh, kh, vh, bh_, doh = make_inputs(2, 2, 256, 252, 64, torch.bfloat16, "1h", seed=4)
+    ph, got = _plan(qh, kh, vh, doh, bh_, False, 0.125, 0)
+    assert ph.describe()["dq"] != "64row-batch4"
+    ref = oracle_all(qh, kh, vh, bh_, doh, 0.125, False)
+    assert maxdiff(got[3], ref["db"]) <= gbound(ref["db"], torch.bfloat16) * 3
+
+
+def test_qdb64_strided_bias_view_and_masked_bias():
+    """a bias that is a (1, H, M, N) view of a larger tensor (row pitch > N), with finfo.min entries (`use_masking`, modeling_flash_t5.py:266-270)"""
+    from flasht5_amd import _lib
+    B, H, M, N = 4, 2, 256, 256
+    q, k, v, _, do = make_inputs(B, H, M, N, 64, torch.bfloat16, None, seed=12, strided=True)
+    big = torch.randn(1, H, M, N + 64, generator=torch.Generator().manual_seed(2)).bfloat16().cuda()
+    big[..., 200:256] = torch.finfo(torch.bfloat16).min  # a padded tail of keys masked for every row
+    b = big[..., :N]
+    ref = oracle_all(q, k, v, b, do, 0.125, False)
+    _, got = _plan(q, k, v, do, b, False, 0.125, _lib.V_QDB64_ON)
+    for x, key in zip(got, ("dq", "dk", "dv")):
+        assert maxdiff(x, ref[key]) <= gbound(ref[key], torch.bfloat16), key
+    assert maxdiff(got[3], ref["db"]) <= gbound(ref["db"], torch.bfloat16) * (1 + B)
