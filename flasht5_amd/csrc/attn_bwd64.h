@@ -48,9 +48,14 @@ namespace fat5 {
 // itself instead of reading the dQ kernel's (AttnArgs::stat2) -- the only dependency between the two kernels.  Every step brings its
 // O rows and its 32 raw log-sum-exp values along; two steps ahead of their use every wave turns 8 of the step's rows into
 // -L/scale and -delta = -rowsum(o * do) (reference _bwd_preprocess, flash_attention_v2_bias.py:516-556) in the slot's statistics area.
-template <int D, bool HALF = false, bool SELF = false>
+// DENSE (round 5): a dense additive bias (the reference's own operator, flash_attention_v2_bias.py:436-443 / :652-729).  Every step's slot carries, per
+// wave, the (32 query rows x the wave's 64 keys) 16-bit bias tile as one more row-major image -- fetched by the wave itself (four 1-KiB LDS-DMA pieces,
+// covered by its own counted vmcnt: no barrier) -- and the lane reads its elements (lane = key, register = row: a TRANSPOSED access) with the same
+// ds_read_b64_tr_b16 addressing that gives it the Q^T / dO^T fragments: one read = the four rows of a register group, eight reads per step.
+template <int D, bool HALF = false, bool SELF = false, bool DENSE = false>
 struct Bwd64Cfg {
   static_assert(!(HALF && SELF), "the self-sufficient variant exists for 256-key workgroups only");
+  static_assert(!(DENSE && (HALF || SELF)), "dense bias: 256-key workgroups with the dQ kernel's statistics only");
   static constexpr int NW = 4, BNK = HALF ? 128 : 64 * NW, QT = 32, NT = 64 * NW, NS = 4;
   static constexpr int IMG = rm_bytes<D, QT>();  // one 32-row image (Q or dO)
   static constexpr int IMGS = SELF ? 3 : 2;      // Q | dO (| O)
@@ -58,7 +63,8 @@ struct Bwd64Cfg {
   // piece of raw L (its first 128 bytes become -L/scale in place) + [32] -delta behind it
   static constexpr int STATB = SELF ? 1024 + 256 : NW * 1024;
   static constexpr int DLOFF = SELF ? 1024 : 128;  // byte offset of -delta inside the statistics area
-  static constexpr int SLOT = IMGS * IMG + STATB;
+  static constexpr int BIASO = IMGS * IMG + STATB;  // DENSE: the waves' bias images of the step
+  static constexpr int SLOT = BIASO + (DENSE ? NW * IMG : 0);
   static constexpr int RING = NS * SLOT;
   static constexpr int RINGS = HALF ? 2 : 1;     // one ring of query steps per wave pair
   static constexpr int RINGB = RINGS * RING;
@@ -99,9 +105,10 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 // 128-key units: attn_bwd_kv64_mixed_kernel)
 template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
-  static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
+  static_assert(D == 64, "gap schedule written for D = 64");
+  constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
   FAT5_STAMP(0);
-  using Cfg = Bwd64Cfg<D, HALF, SELF>;
+  using Cfg = Bwd64Cfg<D, HALF, SELF, DENSE>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
   constexpr int KK = D / 16, DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -266,9 +273,26 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ring0 = (uint32_t)(pr * Cfg::RING);  // this pair's ring
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)wp * 1024u);
+  // DENSE: this wave's bias tile of a step (32 rows x its 64 keys) as a D = 64 image: four pieces of 8 rows, two swizzle phases
+  using BDma = DmaStage<64, 32, 64>;
+  [[maybe_unused]] BDma bst;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t brs = qrs;
+  [[maybe_unused]] uint32_t bias_lds = 0u, bstride_b = 0u;
+  if constexpr (DENSE) {
+    static_assert(BDma::PER == 4 && BDma::NV == 2, "four 1-KiB pieces of 8 rows");
+    bst.init(a.bs[2], l);
+    brs = make_rows_rsrc(a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1], a.bs[2], M, N);
+    bias_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)(Cfg::BIASO + wp * IMG));
+    bstride_b = (uint32_t)a.bs[2] * 2u;
+  }
   auto dma_step = [&](int j, uint32_t slot_off_) {
     const uint32_t mt = (uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j);
     const uint32_t slot_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_off_);  // (provably wave-uniform: it feeds M0)
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int i = 0; i < BDma::PER; ++i)
+        dma16_asm(brs, bias_lds + slot_off + (uint32_t)(i * 1024), bst.voff[i % 2], mt * 32u * bstride_b + (uint32_t)kw0 * 2u + bst.piece_step * (uint32_t)(i / 2));
+    }
 #pragma unroll
     for (int i = 0; i < Dma::PER; ++i) {
       dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
@@ -311,7 +335,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   auto produce_stats = [&](const int j, const uint32_t so) { stats_write(stats_value(stats_read(so), j), so); };
   // E(j): step j+1 (SELF: j+2) has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
   auto sync_step = [&](int j, uint32_t slot3_off) {
-    if ((!SELF || (FAT5_ABL & 128)) && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SELF ? 3 : 2) * Dma::PER + 1) : "memory");
+    if ((!SELF || (FAT5_ABL & 128)) && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SELF ? 3 : 2) * Dma::PER + 1 + (DENSE ? 4 : 0)) : "memory");
     else wait_dma_all();
     __syncthreads();
     if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
@@ -366,6 +390,18 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
   stA = lds0 + ring0 + (uint32_t)(SELF ? 3 * IMG + 16 * hi : 2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +DLOFF+32g (-delta)
   asm volatile("" : "+v"(stA));
+  // DENSE: the transposing-read addresses of this wave's bias image (slot / 16-row offsets are immediates): btr[j2][kb] + 2048 t gives the lane the bias of
+  // rows 16 t + 8 j2 + 4 hi + (0..3) at its key of block kb -- the four registers 4 (2 t + j2) .. + 3 of its score tile, two per word (low half first)
+  [[maybe_unused]] uint32_t btr[2][2] = {{0u, 0u}, {0u, 0u}};
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        btr[j2][kb] = trA[j2][kb] + (uint32_t)(Cfg::BIASO + wp * IMG);
+        asm volatile("" : "+v"(btr[j2][kb]));
+      }
+  }
   if constexpr (SELF) {  // the statistics of the first two steps (step 2's follow in iteration 0)
     produce_stats(0, 0u);
     produce_stats(1, (uint32_t)SLOT);
@@ -398,6 +434,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // address of that window (both formed one iteration ahead), and this lane's addressing of its padded table copy: entry of row mb + crow(r, hi), r = 4 gg + i, is component
   // 3 - i of the 16 bytes at tab_addr(kb, mb) - 32 gg (the window runs DOWN with the row; see softmax_generic)
   u32x4 TN0;
+  [[maybe_unused]] u32x2 TN0d = {0u, 0u};
   uint32_t tadr0 = 0u;
   uint32_t tabB[2] = {0u, 0u};
   int tpos[2] = {0, 0};
@@ -455,14 +492,23 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   };
 
   // general softmax stage of the step at query row mb: S, DP -> PB, DS (+ per-diagonal sums of dS)
-  auto softmax_generic = [&](const int mb) {
+  auto softmax_generic = [&](const int mb, [[maybe_unused]] const uint32_t so) {
     DiagStep gst[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16& s = S[kb];
       const f32x16& dp = DP[kb];
       const int k0 = kw0 + 32 * kb, krow = k0 + lq;
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      if constexpr (DENSE) {
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const u32x2 bw = lds_rd_tr_half(btr[gg & 1][kb] + so + (uint32_t)((gg >> 1) * 16 * 2 * D));
+          s[4 * gg + 0] = fmaf(s[4 * gg + 0], c2, cvt_lo<BF16>(bw[0]) * kLog2e);
+          s[4 * gg + 1] = fmaf(s[4 * gg + 1], c2, cvt_hi<BF16>(bw[0]) * kLog2e);
+          s[4 * gg + 2] = fmaf(s[4 * gg + 2], c2, cvt_lo<BF16>(bw[1]) * kLog2e);
+          s[4 * gg + 3] = fmaf(s[4 * gg + 3], c2, cvt_hi<BF16>(bw[1]) * kLog2e);
+        }
+      } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
         const int R = a.R;
         const int al = (R + krow - 3) & 3;
@@ -520,7 +566,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     if constexpr (SELF) produce_stats(j + 2, (uint32_t)(((j + 2) & 3) * SLOT));
     f32x16 Sn[2], DPn[2];
     score_step(o_next, Sn, DPn);
-    softmax_generic((mt0 + j) * 32);
+    softmax_generic((mt0 + j) * 32, o_cur);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       S[kb] = Sn[kb];
@@ -545,11 +591,16 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // addend, read from this lane's padded table copy (attn_common.h) -- four 16-byte reads per key block, each issued three gaps ahead of
   // its FMAs (the first one during the previous iteration: TN0) -- and the per-diagonal sums of the step's rounded dS follow the
   // iteration as a block (diag_sums on DS).  A band step was the general, unpipelined iteration before: ~2.9x a pipelined step.
-  auto fast_iter = [&]<int SL, bool BAND>(const int j, const float cst) {
+  // DN (round 5): the same iteration with a DENSE bias: the element's bias comes out of the wave's bias image of the step (eight transposing reads,
+  // placed like BAND's table reads; the first one -- key block 0, rows 0..3 -- during the previous iteration: TN0d), one shift / mask, one multiply
+  // by log2(e) and the FMA per element (the table entries of BAND mode are stored pre-scaled; a 16-bit bias tile cannot be)
+  auto fast_iter = [&]<int SL, bool BAND, bool DN = false>(const int j, const float cst) {
     constexpr uint32_t o_prev = ((SL + 3) & 3) * SLOT, o_cur = SL * SLOT, o_next = ((SL + 1) & 3) * SLOT;
     u32x4 T[2][4];
+    [[maybe_unused]] u32x2 TD[2][4];
     uint32_t tadr1 = 0u;
     if constexpr (BAND) T[0][0] = TN0;
+    if constexpr (DN) TD[0][0] = TN0d;
     // BAND: the step's dS onto its diagonals (diag_sum.h), element e three gaps after its exponent argument: one rotating add for
     // everything, one rotating multiply-add by the borrow mask (both read Dv[e], written one gap earlier: no DPP hazard)
     [[maybe_unused]] DiagStep dst[2];
@@ -632,8 +683,22 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
       if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
       if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
-      if constexpr (BAND && !(FAT5_ABL & 4)) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
+      if constexpr (DN) {
+        const uint32_t wd = TD[g >> 4][(g & 15) >> 2][(g & 3) >> 1];
+        const float u = (g & 1) ? asm_and_hi(wd) : asm_shl16(wd);
+        X[g] = asm_fma(S[g >> 4][g & 15], c2, asm_mulf(u, kLog2e));
+      } else if constexpr (BAND && !(FAT5_ABL & 4)) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
       else X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
+      if constexpr (DN) {  // bias words: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
+        if constexpr (g == 1) TD[0][1] = lds_rd_tr_half(btr[1][0] + o_cur);
+        else if constexpr (g == 5) TD[0][2] = lds_rd_tr_half(btr[0][0] + o_cur + 2048u);
+        else if constexpr (g == 9) TD[0][3] = lds_rd_tr_half(btr[1][0] + o_cur + 2048u);
+        else if constexpr (g == 13) TD[1][0] = lds_rd_tr_half(btr[0][1] + o_cur);
+        else if constexpr (g == 18) TD[1][1] = lds_rd_tr_half(btr[1][1] + o_cur);
+        else if constexpr (g == 21) TD[1][2] = lds_rd_tr_half(btr[0][1] + o_cur + 2048u);
+        else if constexpr (g == 25) TD[1][3] = lds_rd_tr_half(btr[1][1] + o_cur + 2048u);
+        else if constexpr (g == 29) TN0d = lds_rd_tr_half(btr[0][0] + o_next);  // (the next step's tile has landed since E(j))
+      }
       if constexpr (BAND && !(FAT5_ABL & 4)) {  // table entries: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
         if constexpr (g == 1) T[0][1] = lds_rd128(tadr0 - 32u);
         else if constexpr (g == 5) T[0][2] = lds_rd128(tadr0 - 64u);
@@ -722,6 +787,21 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     // (single-body inner loops, not one loop over `class ? A : B`: the register allocator keeps one assignment per loop and pays its
     //  copies only at the few transitions)
     int j = 0;
+    if constexpr (DENSE) {
+      while (j < nsteps) {
+        // trips of four steps that see every key run the pipelined dense iteration (visibility is monotone in j); everything else -- the causal
+        // diagonal, a key tail, the remainder of the sweep -- the general one
+        while (j + 4 <= nsteps && (j & 3) == 0 && all_visible(j)) {
+          TN0d = lds_rd_tr_half(btr[0][0]);
+          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false, true>(j + decltype(si)::value, 0.f); });
+          j += 4;
+        }
+        if (j < nsteps && !(j + 4 <= nsteps && (j & 3) == 0 && all_visible(j))) {
+          generic_iter(j);
+          ++j;
+        }
+      }
+    }
     while (j < nsteps) {
       int side, side3;
       // steady state: four steps (ring slots 0..3) per trip, straight-line; the fast steps of one side are contiguous, so the

@@ -16,8 +16,9 @@ static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   // (operands / outputs through LDS images whenever the workgroup's LDS allows: see BwdQ64Cfg)
   AttnArgs as = a;
   fill_div_magic(as, grid);
-  as.lds_stage = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, true) <= 160 * 1024;
-  const size_t smem = Bwd64Cfg<D, HALF>::smem(a.R, BIAS, as.lds_stage != 0);
+  using Cfg = Bwd64Cfg<D, HALF, false, BIAS == FAT5_BIAS_DENSE>;
+  as.lds_stage = Cfg::smem(a.R, BIAS, true) <= 160 * 1024;
+  const size_t smem = Cfg::smem(a.R, BIAS, as.lds_stage != 0);
   auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -50,6 +51,9 @@ hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int b
 
 template <bool HALF>
 static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
+  if constexpr (!HALF) {  // (dense bias, round 5: 256-key workgroups, bf16)
+    if (bias == FAT5_BIAS_DENSE) return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false>(a, grid, s) : hipErrorInvalidValue;
+  }
   if (bias == FAT5_BIAS_RPE1D)
     return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, HALF>(a, grid, s);
   return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_NONE, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_NONE, HALF>(a, grid, s);
@@ -103,7 +107,9 @@ hipError_t CAT(launch_bwd_fused64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, i
 size_t CAT(smem_bwd_fused64_d, FAT5_INST_D)(int R, int bias) {
   return std::max(Bwd64Cfg<FAT5_INST_D, false, true>::smem(R, bias), BwdQ64Cfg<FAT5_INST_D>::smem(R, bias));
 }
-size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D>::smem(R, bias); }
+size_t CAT(smem_bwd_kv64_d, FAT5_INST_D)(int R, int bias) {
+  return bias == FAT5_BIAS_DENSE ? Bwd64Cfg<FAT5_INST_D, false, false, true>::smem(R, bias) : Bwd64Cfg<FAT5_INST_D>::smem(R, bias);
+}
 size_t CAT(smem_bwd_kv64h_d, FAT5_INST_D)(int R, int bias) { return Bwd64Cfg<FAT5_INST_D, true>::smem(R, bias); }
 
 }  // namespace fat5

@@ -302,14 +302,20 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const int kvh_env = vsel(p->variant, FAT5_V_KV64_HALF_ON, FAT5_V_KV64_HALF_OFF);
   const int mix_env = vsel(p->variant, FAT5_V_KV64_MIX_ON, FAT5_V_KV64_MIX_OFF);
   const double r_full = (double)((wg256 + 255) / 256), r_half = 0.5 * 1.04 * (double)((2 * wg256 + 255) / 256);
-  L.kv64_half = kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full);
+  // dense bias (round 5): the 256-key form of the 64-key body with the step's bias tile as one more LDS image per wave (attn_bwd64.h, DENSE): bf16,
+  // bias rows 16-byte aligned (LDS-DMA)
+  const bool dense = p->bias_mode == FAT5_BIAS_DENSE;
+  const bool dense_kv_ok = dense && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
+                           (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) &&
+                           ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+  L.kv64_half = !dense && (kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full));
   // Both variants in one launch (attn_bwd_kv64_mixed_kernel): the first `pf` (b, h) pairs of every XCD as 256-key workgroups, the
   // others half-length.  pf by a list-scheduling model of one XCD (32 CUs, one workgroup per CU, launch order; a half-length
   // workgroup costs 0.65 of a full one without bias, 0.73 with the T5 bias: measured round times 56 / 36 us and 70 / 51 us at
   // S = 2048); taken when it beats both pure variants by 5 %.
   L.kv64_mix_pf = -1;
   double mix_gain = 1.0;
-  if (bh % 8 == 0 && mix_env != 0 && kvh_env == -1) {
+  if (bh % 8 == 0 && mix_env != 0 && kvh_env == -1 && !dense) {
     const int per = (int)(bh / 8), ntf = (p->N + 255) / 256, nth = (p->N + 127) / 128;
     const double rh = p->bias_mode == FAT5_BIAS_NONE ? 0.65 : 0.73;
     // Greedy list scheduling with two job sizes, without walking the jobs (this runs on the host inside every backward call): the F unit
@@ -358,7 +364,7 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   //  64-key mixed 292 vs 326 us, (8,12,2048) 154 vs 169 -> from 2048 keys on)
   const bool ctab_kv = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
   const bool kv64_causal_ok = !p->causal || p->N >= (ctab_kv ? 2048 : 4096);
-  L.kv64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && b64_env != 0 &&
+  L.kv64 = p->D == 64 && (!dense || dense_kv_ok) && !p->cu_seqlens_q && b64_env != 0 &&
            (b64_env == 1 || ((wg256 >= (fills ? 320 : 512) ||
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
                               //  (4,12,8192x1024) 190 vs 234; with the T5 bias 117 vs 146 and 213 vs 274)

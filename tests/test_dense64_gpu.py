@@ -96,3 +96,33 @@ def test_qdb64_strided_bias_view_and_masked_bias():
     for x, key in zip(got, ("dq", "dk", "dv")):
         assert maxdiff(x, ref[key]) <= gbound(ref[key], torch.bfloat16), key
     assert maxdiff(got[3], ref["db"]) <= gbound(ref["db"], torch.bfloat16) * (1 + B)
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,kind", [
+    (2, 3, 1024, 1024, False, "1h"),   # four key blocks per (b, h): trips of the pipelined dense iteration
+    (1, 2, 256, 256, False, "1h"),     # one workgroup, two trips
+    (2, 2, 1024, 1024, True, "1h"),    # causal: diagonal steps general, steps above the diagonal skipped
+    (1, 2, 1000, 1096, False, "1h"),   # ragged: last step padded (rows past M), a key-tail workgroup (all general)
+    (1, 2, 300, 2504, True, "1h"),     # M << N, bottom-right causal
+    (1, 2, 2500, 296, True, "1h"),     # M >> N: dead rows (lse = -inf) in the pipelined range
+    (1, 1, 3000, 520, False, "1h"),    # remainder iterations after the 4-step loop
+    (1, 2, 90, 72, False, "1h"),       # fewer steps than ring slots
+    (2, 2, 512, 768, False, "bh"),     # a per-batch bias (B, H, M, N): dbias = dS, no reduction
+    (3, 2, 384, 512, False, "11"),     # one bias for all heads: head + batch reduction by the older dQ path, dK/dV by the 64-key body
+])
+def test_kv64_dense_matches_oracle_and_the_32key_body(B, H, M, N, causal, kind):
+    """the dense instantiation of the 64-key dK/dV body (FAT5_V_KV64_ON): dk / dv against the oracle and against the 32-key body (same roundings)"""
+    from flasht5_amd import _lib
+    dtype = torch.bfloat16
+    q, k, v, b, do = make_inputs(B, H, M, N, 64, dtype, kind, seed=3 * M + N, strided=True)
+    ref = oracle_all(q, k, v, b, do, 0.125, causal)
+    pn, new = _plan(q, k, v, do, b, causal, 0.125, _lib.V_KV64_ON)
+    po, old = _plan(q, k, v, do, b, causal, 0.125, _lib.V_KV64_OFF)
+    assert pn.describe()["dkdv"] == "64key" and po.describe()["dkdv"] == "32key"
+    for i, key in enumerate(("dq", "dk", "dv")):
+        assert torch.isfinite(new[i].float()).all(), key
+        assert maxdiff(new[i], ref[key]) <= gbound(ref[key], dtype), key
+    for i in (1, 2):
+        assert maxdiff(new[i], old[i]) <= 2.0 ** -6 * max(1.0, float(old[i].float().abs().max()))
+    nred = (B if b.shape[0] == 1 else 1) * (H if b.shape[1] == 1 else 1)
+    assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + nred)
