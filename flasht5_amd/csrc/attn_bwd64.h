@@ -50,8 +50,11 @@ namespace fat5 {
 // -L/scale and -delta = -rowsum(o * do) (reference _bwd_preprocess, flash_attention_v2_bias.py:516-556) in the slot's statistics area.
 // DENSE (round 5): a dense additive bias (the reference's own operator, flash_attention_v2_bias.py:436-443 / :652-729).  Every step's slot carries, per
 // wave, the (32 query rows x the wave's 64 keys) 16-bit bias tile as one more row-major image -- fetched by the wave itself (four 1-KiB LDS-DMA pieces,
-// covered by its own counted vmcnt: no barrier) -- and the lane reads its elements (lane = key, register = row: a TRANSPOSED access) with the same
-// ds_read_b64_tr_b16 addressing that gives it the Q^T / dO^T fragments: one read = the four rows of a register group, eight reads per step.
+// covered by its own counted vmcnt: no barrier).  The bias is added ON THE MATRIX PIPE: S' = Q K^T + E B - L/scale with B the bias tile read as a
+// transposed operand fragment (lane = key, k-slot = row: the ds_read_b64_tr_b16 addressing of the Q^T / dO^T fragments) and E[row][k] = 1/scale where
+// k-slot k is that row -- two more 32x32x16 MFMAs per key block and step (+12.5 % pipe time, inside the slack of the VALU-bound gaps) instead of a
+// shift / mask, a multiply by log2(e) and an add per element (+64 VALU instructions per step: measured +32 % on the kernel).  Exact: a 16-bit bias
+// times a 1/scale that is itself a 16-bit value (1, 8: T5's and the default scale; the dispatcher checks) accumulates in fp32 without rounding.
 template <int D, bool HALF = false, bool SELF = false, bool DENSE = false>
 struct Bwd64Cfg {
   static_assert(!(HALF && SELF), "the self-sufficient variant exists for 256-key workgroups only");
@@ -132,6 +135,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // constant stays visible, the far-positive one is masked), entries above it are -inf
   [[maybe_unused]] const bool ctab = BIAS == FAT5_BIAS_RPE1D && a.causal && P < a.R && P >= -a.R;
   const int kw0 = n0 + 64 * wp;  // first key of this wave; key block kb covers kw0 + 32*kb .. +31
+  const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY;  // a score this large (in S' units) is a zero probability
 
   // K and V fragments (B operands) of this lane's two keys: staged (whole rows by LDS-DMA into the images of this wave's keys, read
   // back after the prologue's wait; keys past N arrive as zeros -- their scores are masked) or straight from global
@@ -304,7 +308,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   };
   // SELF: this wave's 8 rows of the step in the slot at `so` -> -L/scale (in place of the raw L) and -delta.  Eight lanes per row, each
   // one 16-byte piece of the O and dO images (same slot of both: the images share the swizzle), a butterfly over the eight.
-  const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY, nis_c = -1.f / a.scale;
+  const float nis_c = -1.f / a.scale;
   struct StatIn { u32x4 dov, ov; float Lr; };
   const int prow = 8 * w + (l >> 3);
   auto stats_read = [&](const uint32_t so) {  // (three LDS reads; their values are needed several gaps later)
@@ -390,10 +394,23 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
   stA = lds0 + ring0 + (uint32_t)(SELF ? 3 * IMG + 16 * hi : 2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +DLOFF+32g (-delta)
   asm volatile("" : "+v"(stA));
-  // DENSE: the transposing-read addresses of this wave's bias image (slot / 16-row offsets are immediates): btr[j2][kb] + 2048 t gives the lane the bias of
-  // rows 16 t + 8 j2 + 4 hi + (0..3) at its key of block kb -- the four registers 4 (2 t + j2) .. + 3 of its score tile, two per word (low half first)
+  // DENSE: the transposing-read addresses of this wave's bias image (slot / 16-row offsets are immediates): btr[j2][kb] + 2048 t2 gives the lane the bias of
+  // rows 16 t2 + 8 j2 + 4 hi + (0..3) at its key of block kb: k-slots 4 j2 .. 4 j2 + 3 of the B operand (t2, kb) -- and the selector operands E(t2)
   [[maybe_unused]] uint32_t btr[2][2] = {{0u, 0u}, {0u, 0u}};
+  [[maybe_unused]] u32x4 selA[2];
   if constexpr (DENSE) {
+    const uint32_t inv = __float_as_uint(1.f / a.scale) >> 16;  // (exactly 1/scale: the dispatcher takes this body for such scales only)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      uint32_t wv[4];
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);  // rows of k-slots 2 j2, 2 j2 + 1
+        wv[j2] = (r0 == lq ? inv : 0u) | (r0 + 1 == lq ? inv << 16 : 0u);
+      }
+      selA[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      asm volatile("" : "+v"(selA[t2]));
+    }
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
@@ -434,7 +451,6 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // address of that window (both formed one iteration ahead), and this lane's addressing of its padded table copy: entry of row mb + crow(r, hi), r = 4 gg + i, is component
   // 3 - i of the 16 bytes at tab_addr(kb, mb) - 32 gg (the window runs DOWN with the row; see softmax_generic)
   u32x4 TN0;
-  [[maybe_unused]] u32x2 TN0d = {0u, 0u};
   uint32_t tadr0 = 0u;
   uint32_t tabB[2] = {0u, 0u};
   int tpos[2] = {0, 0};
@@ -453,8 +469,18 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // their layout (one v_dot2c_f32_bf16 per word instead measured 9 % of this kernel)
   [[maybe_unused]] f32x4 facc4 = {0.f, 0.f, 0.f, 0.f};
 
-  // scores of the step in the slot at byte offset `so`
-  auto score_step = [&](const uint32_t so, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
+  // The causal mask as part of the score MFMAs' C operand (round 5; bias none / dense -- with the T5 bias the table carries it): S' = Q K^T + C with
+  // C = -L/scale of the row, or -inf (+inf for a negative scale) where the key is masked: exp2(-inf) = 0 makes p and dS exact zeros, so a step on the
+  // causal diagonal runs the PIPELINED iteration (one compare + one select per element of the C operand) instead of the unpipelined general one --
+  // half of all steps of a 256-key workgroup at 1024 keys.  Key k0 + lane is visible to row mb + c(r) + 4 hi iff c(r) >= t with t = key - P - mb - 4 hi.
+  constexpr bool CMASK = BIAS != FAT5_BIAS_RPE1D;
+  const int tbase = kw0 + lq - P - 4 * hi;
+  auto mask_c = [&](const f32x16& nl, const int t, f32x16& out) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = ((r & 3) + 8 * (r >> 2) < t) ? ninf_c : nl[r];
+  };
+  // scores of the step (query rows mb ..) in the slot at byte offset `so`
+  auto score_step = [&](const uint32_t so, f32x16 (&Sx)[2], f32x16 (&DPx)[2], const int mb) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -462,6 +488,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         put4(Sx[kb], g, rd_f4(stA + so + (uint32_t)(32 * g)));
         put4(DPx[kb], g, rd_f4(stA + so + (uint32_t)(Cfg::DLOFF + 32 * g)));
       }
+    if (CMASK && a.causal) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mask_c(Sx[kb], tbase + 32 * kb - mb, Sx[kb]);
+    }
     u32x4 qa[KK], da[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -472,6 +502,12 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sx[kb]);
+    if constexpr (DENSE) {  // + bias / scale (see Bwd64Cfg)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(selA[t2], lds_rd_tr(btr[0][kb] + so + (uint32_t)(2048 * t2), btr[1][kb] + so + (uint32_t)(2048 * t2)), Sx[kb]);
+    }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -500,14 +536,9 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       const f32x16& dp = DP[kb];
       const int k0 = kw0 + 32 * kb, krow = k0 + lq;
       if constexpr (DENSE) {
+        // (the scores arrive with the bias inside: score_step / the pipelined iteration add it on the matrix pipe)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const u32x2 bw = lds_rd_tr_half(btr[gg & 1][kb] + so + (uint32_t)((gg >> 1) * 16 * 2 * D));
-          s[4 * gg + 0] = fmaf(s[4 * gg + 0], c2, cvt_lo<BF16>(bw[0]) * kLog2e);
-          s[4 * gg + 1] = fmaf(s[4 * gg + 1], c2, cvt_hi<BF16>(bw[0]) * kLog2e);
-          s[4 * gg + 2] = fmaf(s[4 * gg + 2], c2, cvt_lo<BF16>(bw[1]) * kLog2e);
-          s[4 * gg + 3] = fmaf(s[4 * gg + 3], c2, cvt_hi<BF16>(bw[1]) * kLog2e);
-        }
+        for (int r = 0; r < 16; ++r) s[r] *= c2;
       } else if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         // far, edge and band blocks alike: four aligned 16-byte reads of this lane's padded table copy, window clamped (attn_common.h)
         const int R = a.R;
@@ -565,7 +596,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     sync_step(j, o_prev);
     if constexpr (SELF) produce_stats(j + 2, (uint32_t)(((j + 2) & 3) * SLOT));
     f32x16 Sn[2], DPn[2];
-    score_step(o_next, Sn, DPn);
+    score_step(o_next, Sn, DPn, (mt0 + j + 1) * 32);
     softmax_generic((mt0 + j) * 32, o_cur);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -591,16 +622,16 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // addend, read from this lane's padded table copy (attn_common.h) -- four 16-byte reads per key block, each issued three gaps ahead of
   // its FMAs (the first one during the previous iteration: TN0) -- and the per-diagonal sums of the step's rounded dS follow the
   // iteration as a block (diag_sums on DS).  A band step was the general, unpipelined iteration before: ~2.9x a pipelined step.
-  // DN (round 5): the same iteration with a DENSE bias: the element's bias comes out of the wave's bias image of the step (eight transposing reads,
-  // placed like BAND's table reads; the first one -- key block 0, rows 0..3 -- during the previous iteration: TN0d), one shift / mask, one multiply
-  // by log2(e) and the FMA per element (the table entries of BAND mode are stored pre-scaled; a 16-bit bias tile cannot be)
-  auto fast_iter = [&]<int SL, bool BAND, bool DN = false>(const int j, const float cst) {
+  // DN (round 5): the same iteration with a DENSE bias: the scores of step j+1 get + bias / scale from four more MFMAs (Bwd64Cfg) -- gaps 20..23 hold two
+  // MFMAs each, strictly alternating between the two key blocks' accumulators --, their B operands from eight transposing reads of the wave's bias image
+  // of step j+1 in gaps 13..21; the softmax stage is the one without bias
+  // MK (round 5): the scores of step j+1 are formed with the causal mask in their C operand (mask_c): a trip on the diagonal
+  auto fast_iter = [&]<int SL, bool BAND, bool DN = false, bool MK = false>(const int j, const float cst) {
     constexpr uint32_t o_prev = ((SL + 3) & 3) * SLOT, o_cur = SL * SLOT, o_next = ((SL + 1) & 3) * SLOT;
     u32x4 T[2][4];
-    [[maybe_unused]] u32x2 TD[2][4];
+    [[maybe_unused]] u32x2 bbh[2][2][2];  // [kb][t2][half]: B operands of the bias MFMAs
     uint32_t tadr1 = 0u;
     if constexpr (BAND) T[0][0] = TN0;
-    if constexpr (DN) TD[0][0] = TN0d;
     // BAND: the step's dS onto its diagonals (diag_sum.h), element e three gaps after its exponent argument: one rotating add for
     // everything, one rotating multiply-add by the borrow mask (both read Dv[e], written one gap earlier: no DPP hazard)
     [[maybe_unused]] DiagStep dst[2];
@@ -612,6 +643,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     [[maybe_unused]] float sval_ = 0.f;
     f32x16 Sn[2], DPn[2];
     [[maybe_unused]] f32x16 NL, DL;
+    [[maybe_unused]] f32x16 NLm[2];
+    [[maybe_unused]] int tm[2] = {0, 0};
     u32x4 PBn[2][2], DSn[2][2], qa[KK], da[KK];
     u32x2 trh[4][2][2], tnd[2], tnq[2];
     float X[32], Pv[32], Dv[32];
@@ -636,9 +669,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else fr = u32x4{trh[p][wh][0][0], trh[p][wh][0][1], trh[p][wh][1][0], trh[p][wh][1][1]};
         if constexpr (wh == 0) mfma_acc_agpr<BF16>(dv[kb][db], fr, PB[kb][t2]);
         else mfma_acc_agpr<BF16>(dk[kb][db], fr, DS[kb][t2]);
+      } else if constexpr (g < 24 && DN && g >= 20) {
+        // (the first of the gap's two MFMAs: key block 0; the second one follows the gap's LDS section)
+        if constexpr (g < 22) Sn[0] = mfma32<BF16>(qa[g - 18], kf[0][g - 18], Sn[0]);
+        else Sn[0] = mfma32<BF16>(selA[g - 22], u32x4{bbh[0][g - 22][0][0], bbh[0][g - 22][0][1], bbh[0][g - 22][1][0], bbh[0][g - 22][1][1]}, Sn[0]);
       } else if constexpr (g < 24) {
         constexpr int kk = (g - 16) >> 1, kb = g & 1;
-        if constexpr (kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], NL);
+        if constexpr (kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], MK ? NLm[kb] : NL);
         else Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sn[kb]);  // (accumulator preloaded with -L/scale)
       } else {
         constexpr int kk = (g - 24) >> 1, kb = g & 1;
@@ -652,6 +689,18 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       if constexpr (SELF && g == 23 && !(FAT5_ABL & 64)) sval_ = stats_value(sin_, j + 2);
       if constexpr (SELF && g == 27 && !(FAT5_ABL & 64)) stats_write(sval_, ((SL + 2) & 3) * SLOT);
       if constexpr (g == 19) asm volatile("" ::"v"(NL));  // (keeps NL's registers out of reach of the VALU ops of gaps 16..18)
+      if constexpr (MK && g == 20) asm volatile("" ::"v"(NLm[0]), "v"(NLm[1]));
+      if constexpr (MK) {  // the masked C operands of step j+1's scores: key block 0 in gaps 13, 14 (first MFMA: gap 16), key block 1 in gaps 15, 16 (gap 17)
+        if constexpr (g == 13) {
+          tm[0] = tbase - (mt0 + j + 1) * 32;
+          tm[1] = tm[0] + 32;
+        }
+        if constexpr (g >= 13 && g <= 16) {
+          constexpr int kb = (g - 13) >> 1, r0 = 8 * ((g - 13) & 1);
+#pragma unroll
+          for (int r = r0; r < r0 + 8; ++r) NLm[kb][r] = ((r & 3) + 8 * (r >> 2) < tm[kb]) ? ninf_c : NL[r];
+        }
+      }
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
       // ---- barrier + DMA ----
       if constexpr (g == 12) sync_step(j, o_prev);
@@ -678,27 +727,29 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         if constexpr (g < 30) tnd[half] = lds_rd_tr_half(trA[half][0] + o_cur + (uint32_t)IMG);
         else tnq[half] = lds_rd_tr_half(trA[half][0] + o_cur);
       }
+      if constexpr (DN) {
+        // bias fragments of step j+1 (its tile has landed since E(j)): (kb, t2, half) -- (0,0) in gaps 13, 14; (1,0): 15, 16; (0,1): 18; (1,1): 20, 21
+        if constexpr (g == 13 || g == 14) bbh[0][0][g - 13] = lds_rd_tr_half(btr[g - 13][0] + o_next);
+        else if constexpr (g == 15 || g == 16) bbh[1][0][g - 15] = lds_rd_tr_half(btr[g - 15][1] + o_next);
+        else if constexpr (g == 18) {
+          bbh[0][1][0] = lds_rd_tr_half(btr[0][0] + o_next + 2048u);
+          bbh[0][1][1] = lds_rd_tr_half(btr[1][0] + o_next + 2048u);
+        } else if constexpr (g == 20 || g == 21) bbh[1][1][g - 20] = lds_rd_tr_half(btr[g - 20][1] + o_next + 2048u);
+        // the gap's second MFMA: key block 1
+        if constexpr (g >= 20 && g < 24) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g < 22) Sn[1] = mfma32<BF16>(qa[g - 18], kf[1][g - 18], Sn[1]);
+          else Sn[1] = mfma32<BF16>(selA[g - 22], u32x4{bbh[1][g - 22][0][0], bbh[1][g - 22][0][1], bbh[1][g - 22][1][0], bbh[1][g - 22][1][1]}, Sn[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       // ---- VALU ----
       {
       if constexpr (g >= 4 && (g & 1) == 0) pack_pair.template operator()<g - 4>();
       if constexpr (g >= 2) Dv[g - 2] = asm_mul(Pv[g - 2], DP[(g - 2) >> 4][(g - 2) & 15]);
       if constexpr (g >= 1) Pv[g - 1] = asm_exp2(X[g - 1]);
-      if constexpr (DN) {
-        const uint32_t wd = TD[g >> 4][(g & 15) >> 2][(g & 3) >> 1];
-        const float u = (g & 1) ? asm_and_hi(wd) : asm_shl16(wd);
-        X[g] = asm_fma(S[g >> 4][g & 15], c2, asm_mulf(u, kLog2e));
-      } else if constexpr (BAND && !(FAT5_ABL & 4)) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
+      if constexpr (BAND && !(FAT5_ABL & 4)) X[g] = asm_fma(S[g >> 4][g & 15], c2, __uint_as_float(T[g >> 4][(g & 15) >> 2][3 - (g & 3)]));
       else X[g] = asm_fma(S[g >> 4][g & 15], c2, cst);
-      if constexpr (DN) {  // bias words: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
-        if constexpr (g == 1) TD[0][1] = lds_rd_tr_half(btr[1][0] + o_cur);
-        else if constexpr (g == 5) TD[0][2] = lds_rd_tr_half(btr[0][0] + o_cur + 2048u);
-        else if constexpr (g == 9) TD[0][3] = lds_rd_tr_half(btr[1][0] + o_cur + 2048u);
-        else if constexpr (g == 13) TD[1][0] = lds_rd_tr_half(btr[0][1] + o_cur);
-        else if constexpr (g == 18) TD[1][1] = lds_rd_tr_half(btr[1][1] + o_cur);
-        else if constexpr (g == 21) TD[1][2] = lds_rd_tr_half(btr[0][1] + o_cur + 2048u);
-        else if constexpr (g == 25) TD[1][3] = lds_rd_tr_half(btr[1][1] + o_cur + 2048u);
-        else if constexpr (g == 29) TN0d = lds_rd_tr_half(btr[0][0] + o_next);  // (the next step's tile has landed since E(j))
-      }
       if constexpr (BAND && !(FAT5_ABL & 4)) {  // table entries: key block kb, rows 4 gg .. 4 gg + 3 are first used in gap 16 kb + 4 gg
         if constexpr (g == 1) T[0][1] = lds_rd128(tadr0 - 32u);
         else if constexpr (g == 5) T[0][2] = lds_rd128(tadr0 - 64u);
@@ -760,7 +811,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 
   if (nsteps > 0) {
     // fill: scores of the first step, nothing pending
-    score_step(0u, S, DP);
+    score_step(0u, S, DP, mt0 * 32);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -787,16 +838,20 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     // (single-body inner loops, not one loop over `class ? A : B`: the register allocator keeps one assignment per loop and pays its
     //  copies only at the few transitions)
     int j = 0;
-    if constexpr (DENSE) {
+    if constexpr (BIAS != FAT5_BIAS_RPE1D) {
       while (j < nsteps) {
         // trips of four steps that see every key run the pipelined dense iteration (visibility is monotone in j); everything else -- the causal
         // diagonal, a key tail, the remainder of the sweep -- the general one
-        while (j + 4 <= nsteps && (j & 3) == 0 && all_visible(j)) {
-          TN0d = lds_rd_tr_half(btr[0][0]);
-          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false, true>(j + decltype(si)::value, 0.f); });
+        // (causal: trips on the diagonal first -- the mask rides in the score MFMAs' C operand --, then the all-visible ones; a key tail stays general)
+        while (j + 4 <= nsteps && (j & 3) == 0 && kw0 + 64 <= N && !all_visible(j)) {
+          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false, DENSE, true>(j + decltype(si)::value, 0.f); });
           j += 4;
         }
-        if (j < nsteps && !(j + 4 <= nsteps && (j & 3) == 0 && all_visible(j))) {
+        while (j + 4 <= nsteps && (j & 3) == 0 && all_visible(j)) {
+          static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false, DENSE>(j + decltype(si)::value, 0.f); });
+          j += 4;
+        }
+        if (j < nsteps && !(j + 4 <= nsteps && (j & 3) == 0 && kw0 + 64 <= N)) {
           generic_iter(j);
           ++j;
         }

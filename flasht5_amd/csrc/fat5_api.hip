@@ -305,7 +305,14 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   // dense bias (round 5): the 256-key form of the 64-key body with the step's bias tile as one more LDS image per wave (attn_bwd64.h, DENSE): bf16,
   // bias rows 16-byte aligned (LDS-DMA)
   const bool dense = p->bias_mode == FAT5_BIAS_DENSE;
-  const bool dense_kv_ok = dense && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
+  // (the body adds bias / scale on the matrix pipe: exact only when 1 / scale is itself a bf16 value -- 1 (T5: no scaling), 8 (the default 1/sqrt(64)), ...)
+  uint32_t inv_bits;
+  {
+    const float inv = p->sm_scale != 0.f ? 1.f / p->sm_scale : 0.f;
+    memcpy(&inv_bits, &inv, 4);
+  }
+  const bool scale_exact = p->sm_scale != 0.f && (inv_bits & 0xffffu) == 0 && std::isfinite(1.f / p->sm_scale);
+  const bool dense_kv_ok = dense && scale_exact && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
                            (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) &&
                            ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
   L.kv64_half = !dense && (kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full));
@@ -487,13 +494,15 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
 // The layout is asked for two or three times per backward call (workspace size, stages, launches) and its mixed-launch model is a
 // search: the last answer is kept per thread, keyed on every argument the function reads.
 static int bwd_layout(const fat5_attn_params* p, BwdLayout& L) {
+  uint32_t sm_bits;
+  memcpy(&sm_bits, &p->sm_scale, 4);
   struct Key {
     int64_t v[24];
     bool operator==(const Key& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
   };
   const Key k = {{p->B, p->H, p->M, p->N, p->D, p->bias_mode, p->causal, (int64_t)p->variant, p->rpe_radius, p->dbias_batch, p->dbias_heads,
                   p->bias_stride[0], p->bias_stride[1], p->unit_count, p->total_q, p->cu_seqlens_q != nullptr, p->dbias != nullptr,
-                  p->drpe1d != nullptr, p->drpe_table != nullptr, p->dtype, p->bias_stride[2], (int64_t)(reinterpret_cast<uintptr_t>(p->bias) & 15), 0, 0}};
+                  p->drpe1d != nullptr, p->drpe_table != nullptr, p->dtype, p->bias_stride[2], (int64_t)(reinterpret_cast<uintptr_t>(p->bias) & 15), (int64_t)sm_bits, 0}};
   thread_local Key last_k;
   thread_local BwdLayout last_L;
   thread_local int last_rc = -1;
