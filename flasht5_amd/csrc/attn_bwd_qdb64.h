@@ -17,6 +17,11 @@
 //    16-bit values of two waves in fp32, 64 pipe cycles per step instead of 60 VALU operations per lane -- rounds once and stores 32-byte row pieces
 //    of dbias (fp32 partial sums per group of four batch elements when B > 4; `dbias_partial_reduce_kernel` adds the groups in a fixed order).
 //    Deterministic: fixed summation order, no atomics.  The reference's sum (fp32 accumulation of bf16-rounded dS, one final rounding) is reproduced.
+//  * The bias is added ON THE MATRIX PIPE (as in the dense form of the 64-key dK/dV body, attn_bwd64.h: Bwd64Cfg): S^T = K Q^T + B^T E with B^T the bias tile read
+//    as a transposed operand fragment (lane = key slot, k-slot = query row; ds_read_b64_tr_b16 on the tile: its suppliers point at the 4-key groups of
+//    the key permutation below) and E[k][row] = 1/scale where k-slot k is that row: four more MFMAs per step instead of 96 VALU instructions per lane.
+//    Exact for a 1/scale that is a 16-bit value itself (the dispatcher checks).  The causal mask rides in the C operand of the same MFMAs (-inf where the
+//    key is masked: the steps on the diagonal run the pipelined iteration, and a causal sweep is padded to whole trips of four steps with fully masked ones).
 //  * Keys are PERMUTED inside a step (LDS row rho of the K / V images holds key pi(rho), qdb_pi below): the MFMA k-slot <-> key mapping is free as
 //    long as both operands agree, and with this one a lane's 16 score registers of a query block are the 16 keys 16 hi .. 16 hi + 15 of its row --
 //    its bias values are 32 contiguous bytes -- in the order {0-3, 8-11 | 4-7, 12-15}: the two packed operand fragments of its rounded dS are, as they
@@ -83,6 +88,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     const int item = x * base + min(x, rem) + idx;
     pair = fast_div(item, a.n_mblk, a.mg_mblk);
     mblk = item - pair * a.n_mblk;
+    if (a.causal) mblk = a.n_mblk - 1 - mblk;  // (the row blocks that see the most keys first: the short ones fill the tail of the launch)
   }
   const int h = pair / ngrp, grp = pair - h * ngrp;
   const int b_ = 4 * grp + w;
@@ -101,7 +107,10 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   const int P = N - M;
   int n_end = N;
   if (a.causal) n_end = min(N, m0 + Cfg::BM + P);
-  const int nt = n_end > 0 ? (n_end + 31) / 32 : 0;
+  int nt = n_end > 0 ? (n_end + 31) / 32 : 0;
+  // causal: whole trips of the pipelined loop -- the steps added lie above the diagonal (every probability an exact zero through the mask in the score
+  // MFMAs' C operand; their dbias tiles are written as the zeros they are) and cost a third of the general iterations they replace
+  if (a.causal && nt > 0 && ((nt + 3) & ~3) * 32 <= N) nt = (nt + 3) & ~3;
   const int qw0 = m0;  // (every wave the same 64 rows)
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -265,8 +274,35 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   uint32_t tA[2];  // byte offset inside a tile of chunk 2 hi + i of row lq (query block qb: + 2048)
 #pragma unroll
   for (int i = 0; i < 2; ++i) tA[i] = (uint32_t)(lq * 64 + (((2 * hi + i) ^ fsw) << 4));
-  uint32_t bA[2] = {lds0 + (uint32_t)Cfg::BOFF + tA[0], lds0 + (uint32_t)Cfg::BOFF + tA[1]};
-  asm volatile("" : "+v"(bA[0]), "+v"(bA[1]));
+  // bias fragments (A operands of the bias MFMAs): ds_read_b64_tr_b16 with this lane as SUPPLIER of row 16 t2 + 8 j2 + 4 hi + (i >> 2) (i = l & 15), keys
+  // 16 (c & 1) + 8 (c >> 1) + 4 g .. + 3 (c = i & 3, g = (l >> 4) & 1): the 4-key group whose slots 16 g + 4 c .. + 3 the receiving lanes of its 16 hold
+  uint32_t btA[2];  // [j2]; query block qb: + 2048, t2: + 1024, ring slot: + BT s
+  {
+    const int i = l & 15, c = i & 3, g = (l >> 4) & 1;
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+      const int row = 8 * j2 + 4 * hi + (i >> 2);
+      btA[j2] = lds0 + (uint32_t)(Cfg::BOFF + row * 64 + (((2 * (c & 1) + (c >> 1)) ^ ((2 * j2 + hi) & 3)) << 4) + 8 * g);
+      asm volatile("" : "+v"(btA[j2]));
+    }
+  }
+  // selector operands E(t2) (B: lane = query row lq, k-slot (hi, j) <-> row 16 t2 + 8 (j >> 2) + 4 hi + (j & 3)): 1/scale where that is the lane's own row
+  u32x4 selB[2];
+  {
+    const uint32_t inv = __float_as_uint(1.f / a.scale) >> 16;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      uint32_t wv[4];
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);
+        wv[j2] = (r0 == lq ? inv : 0u) | (r0 + 1 == lq ? inv << 16 : 0u);
+      }
+      selB[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      asm volatile("" : "+v"(selB[t2]));
+    }
+  }
+  const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY;  // a raw score this large is a zero probability
   // exchange: this wave's tile of buffer 0 (writes).  A lane's 16 rounded dS values of a query block (keys 16 hi + 0 .. 15) go out as chunk 2 hi = keys
   // {0-3, 8-11} and chunk 2 hi + 1 = keys {4-7, 12-15} of its row: with that interleave the reduction leaves every lane 8 CONSECUTIVE keys (one 16-byte
   // dbias store per lane and step, whole 64-byte row pieces per four lanes).  The reader's side: lane (n = l & 15, gq = l >> 4) sums row 16 w + n; for
@@ -307,26 +343,46 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   // Pipeline state between two iterations (iteration i = key step i is in its softmax stage):
   //   S, DP     S^T = K Q^T and dP'^T = V dO^T - delta of step i (lane = query row, register r <-> key 32 i + 16 hi + r)
   //   DSB       dS^T of step i-1 rounded to the bias dtype (:720): B operands of the dQ products AND the words the batch sum is made of
-  //   TRK       the K^T fragments (t2 = 0; db = 0, 1) of step i-1;   TN0  the first bias words (query block 0, keys 0..7 of the lane) of step i
+  //   TRK       the K^T fragments (t2 = 0; db = 0, 1) of step i-1
   f32x16 S[2], DP[2];
-  u32x4 DSB[2][2], TRK[2], TN0;
+  u32x4 DSB[2][2], TRK[2];
 
   auto rd_tr = [&](uint32_t off, int t2, int db) {
     const uint32_t o = off + (uint32_t)(16 * t2 * 2 * D);
     return lds_rd_tr(trA[0][db] + o, trA[1][db] + o);
   };
   // scores of the step whose K image sits at byte offset ko of the wave's K ring and whose V image at VOFF + vo
-  auto score_step = [&](const uint32_t ko, const uint32_t vo, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
+  // the causal mask as the score MFMAs' C operand: register r of query block qb holds key nb + qdb_key(r, hi) -- masked where that exceeds row + P
+  const int lim0 = qw0 + lq + P - 16 * hi;  // (query block 1: + 32)
+  auto mask_c = [&](const int nb, f32x16 (&out)[2]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int lm = lim0 + 32 * qb - nb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[qb][r] = (qdb_key(r, 0) > lm) ? ninf_c : 0.f;
+    }
+  };
+  // scores of the step at key nb: its K image at byte offset ko of the wave's K ring, its V image at VOFF + vo, its bias tile at BOFF + bo
+  auto score_step = [&](const uint32_t ko, const uint32_t vo, const uint32_t bo, const int nb, f32x16 (&Sx)[2], f32x16 (&DPx)[2]) {
     u32x4 kf[KK], vf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       kf[kk] = lds_rd128(rmA[kk] + ko);
       vf[kk] = lds_rd128(rmA[kk] + (uint32_t)Cfg::VOFF + vo);
     }
+    if (a.causal) mask_c(nb, Sx);
+    else { Sx[0] = zero16; Sx[1] = zero16; }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) Sx[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], kk == 0 ? zero16 : Sx[qb]);
+      for (int qb = 0; qb < 2; ++qb) Sx[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sx[qb]);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const uint32_t o = bo + (uint32_t)(qb * 2048 + t2 * 1024);
+        Sx[qb] = mfma32<BF16>(lds_rd_tr(btA[0] + o, btA[1] + o), selB[t2], Sx[qb]);
+      }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -378,21 +434,16 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     if constexpr (!(FAT5_QDB_ABL & 1)) x_store(acc, ok ? dvo : 0x80000000u, so);
   };
   // general softmax stage of the key step at nb (key tail / causal diagonal): S, DP -> DSB
-  auto softmax_generic = [&](const int nb, const uint32_t bo) {
+  auto softmax_generic = [&](const int nb) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16& s = S[qb];
       const f32x16& dp = DP[qb];
       const int qrow = qw0 + 32 * qb + lq;
       const float nl = nL2[qb];
-      u32x4 bw[2];
+      // (the scores arrive with bias / scale inside)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) bw[i] = lds_rd128(bA[i] + bo + (uint32_t)(qb * 2048));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t wd = bw[qdb_word(r) >> 2][qdb_word(r) & 3];
-        s[r] = fmaf(s[r], c2, fmaf((qdb_key(r, 0) & 1) ? cvt_hi<BF16>(wd) : cvt_lo<BF16>(wd), kLog2e, nl));
-      }
+      for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, nl);
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];  // dS = P (dP - delta)   (:713)
       const int lim = a.causal ? min(N - 1, qrow + P) : N - 1;
@@ -413,9 +464,9 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     x_reduce_store(xpar, t - 1, (t - 1) * 32 + 32 <= N);
     xpar ^= (uint32_t)Cfg::XB;
     f32x16 Sn[2], DPn[2];
-    score_step(kn, vnext, Sn, DPn);
+    score_step(kn, vnext, (uint32_t)(((t + 1) & 3) * BT), (t + 1) * 32, Sn, DPn);
     vnext = vnext == (uint32_t)(2 * IMG) ? 0u : vnext + (uint32_t)IMG;
-    softmax_generic(t * 32, (uint32_t)((t & 3) * BT));
+    softmax_generic(t * 32);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       S[qb] = Sn[qb];
@@ -423,46 +474,38 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     }
     TRK[0] = rd_tr(kc, 0, 0);
     TRK[1] = rd_tr(kc, 0, 1);
-    TN0 = lds_rd128(bA[0] + (uint32_t)(((t + 1) & 3) * BT));
   };
 
   // One pipelined iteration = 24 MFMA gaps (attn_bwd64.h: attn_bwd_q64_body::fast_iter) + the dense bias + the exchange:
-  //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1; 8..15: S^T[qb] of step i+1; 16..23: dP'^T[qb] (C = -delta on the first k-step)
+  //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1; 8..15: S^T[qb] of step i+1 -- gaps 8..11 one k-step each, gaps 12..15 TWO MFMAs
+  //          each (query block 0 at the head of the gap, query block 1 behind its LDS section; the two accumulators alternate strictly): k-steps 2, 3, then
+  //          + bias / scale (t2 = 0, 1); 16..23: dP'^T[qb] (C = -delta on the first k-step)
   //   MFMA16 gaps 7..10: the batch sum of step i-1's dS quarter (two accumulators x two wave pairs)
-  //   VALU   32 elements per lane opened evenly over gaps 0 .. 20: u = the element's bias (one shift / mask of its packed word) | tn = u * log2e - L2 |
-  //          x = s * c2 + tn | one gap later p = exp2(x) | one more: ds = p * dp' | pairs packed once both halves exist
-  //   LDS    gaps 0..3: the K^T fragments (t2 = 1) of step i-1 and this wave's four exchange writes; gap 4: the barrier E(i) + the DMA of step i+2;
-  //          gaps 4..7 the K, 12..15 the V row-major fragments of step i+1; 5, 6: the four exchange reads; gaps 1, 6, 11: bias words of step i
-  //          (the first ones were read in gap 18 of the previous iteration), gap 12: the dbias stores of step i-1; gaps 20..23 the K^T fragments (t2 = 0) of step i
+  //   VALU   32 elements per lane opened evenly over gaps 0 .. 20: x = s * c2 - L2 | one gap later p = exp2(x) | one more: ds = p * dp' | pairs packed
+  //          once both halves exist.  MK: the C operands of step i+1's scores (mask_c) in gaps 5..7
+  //   LDS    gaps 0..3: the K^T fragments (t2 = 1) of step i-1 and this wave's four exchange writes; gap 4: the barrier E(i); gaps 5..13 the nine DMA
+  //          pieces of step i+3; gaps 4..7 the K, 12..15 the V row-major fragments of step i+1; 5, 6: the four exchange reads; gaps 8..11: the bias
+  //          fragments of step i+1 (two transposing reads each); gap 14: the dbias store of step i-1; gaps 20..23 the K^T fragments (t2 = 0) of step i
   constexpr int NG = 24;
-  auto fast_iter = [&]<int SL>(const int t) {
-    constexpr uint32_t o_prev = ((SL + 3) & 3) * IMG, o_cur = SL * IMG, o_next = ((SL + 1) & 3) * IMG, b_cur = SL * BT, b_next = ((SL + 1) & 3) * BT;
+  auto fast_iter = [&]<int SL, bool MK>(const int t) {
+    constexpr uint32_t o_prev = ((SL + 3) & 3) * IMG, o_cur = SL * IMG, o_next = ((SL + 1) & 3) * IMG, b_next = ((SL + 1) & 3) * BT;
     const uint32_t v_next = (uint32_t)Cfg::VOFF + vnext;  // (the V ring has three slots: its offset is a run-time value, uniform)
     const uint32_t tt3 = (uint32_t)__builtin_amdgcn_readfirstlane(t + 3);
     f32x16 Sn[2], DPn[2];
-    u32x4 DSn[2][2], kf[KK], vf[KK], T[2][2], XR[2][2];
-    u32x2 th[2][2], tn[2][2];
+    [[maybe_unused]] int lm[2] = {0, 0};
+    u32x4 DSn[2][2], kf[KK], vf[KK], XR[2][2];
+    u32x2 th[2][2], tn[2][2], bf[2][2][2];  // bf[qb][t2][j2]
     float X[32], Pv[32], Dv[32];
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const uint32_t xo = xpar;
-    T[0][0] = TN0;
-    auto stA_ = [&]<int E>() {
-      constexpr int qb = E >> 4, r = E & 15;
-      if constexpr (FAT5_QDB_ABL & 4) {
-        X[E] = asm_fma(S[qb][r], c2, nL2[qb]);
-      } else {
-        const uint32_t wd = T[qb][qdb_word(r) >> 2][qdb_word(r) & 3];
-        const float u = (qdb_key(r, 0) & 1) ? asm_and_hi(wd) : asm_shl16(wd);
-        const float tn_ = asm_fma(u, kLog2e, nL2[qb]);
-        X[E] = asm_fma(S[qb][r], c2, tn_);
-      }
-    };
+    auto stA_ = [&]<int E>() { X[E] = asm_fma(S[E >> 4][E & 15], c2, nL2[E >> 4]); };
     auto stB_ = [&]<int E>() { Pv[E] = asm_exp2(X[E]); };
     auto stC_ = [&]<int E>() { Dv[E] = asm_mul(Pv[E], DP[E >> 4][E & 15]); };
     auto stD_ = [&]<int E0>() {
       constexpr int qb = E0 >> 4, r0 = E0 & 15;
       DSn[qb][r0 >> 3][(r0 & 7) >> 1] = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
     };
+    auto bfrag = [&](const int qb, const int t2) { return u32x4{bf[qb][t2][0][0], bf[qb][t2][0][1], bf[qb][t2][1][0], bf[qb][t2][1][1]}; };
     static_for<NG>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       // ---- MFMA ----
@@ -472,10 +515,14 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
         if constexpr (t2 == 0) fr = TRK[db];
         else fr = u32x4{th[db][0][0], th[db][0][1], th[db][1][0], th[db][1][1]};
         mfma_acc_agpr<BF16>(dq[qb][db], fr, DSB[qb][t2]);
-      } else if constexpr (g < 16) {
+      } else if constexpr (g < 12) {
         constexpr int kk = (g - 8) >> 1, qb = g & 1;
-        if constexpr (kk == 0) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
-        else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);
+        if constexpr (kk == 0 && !MK) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
+        else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);  // (MK: Sn holds the mask, formed in gaps 5..7)
+      } else if constexpr (g < 14) {
+        Sn[0] = mfma32<BF16>(kf[g - 10], qf[0][g - 10], Sn[0]);
+      } else if constexpr (g < 16) {
+        Sn[0] = mfma32<BF16>(bfrag(0, g - 14), selB[g - 14], Sn[0]);
       } else {
         constexpr int kk = (g - 16) >> 1, qb = g & 1;
         if constexpr (kk == 0) DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], nd16[qb]);  // (nd16 lives for the whole loop: no WAR window)
@@ -489,13 +536,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       }
       // ---- barrier + DMA ----
       if constexpr (g == 4) wait_step();
-      if constexpr (FAT5_QDB_ABL & 256) {
-        if constexpr (g >= 5 && g < 5 + 2 * Cfg::PIECES) {
-          if (((g - 5) & 1) == (w & 1)) dma_piece(tt3, (g - 5) >> 1);
-        }
-      } else {
       if constexpr (g >= 5 && g < 5 + Cfg::PIECES) dma_piece(tt3, g - 5);  // (step i+3 into the slots the barrier has released, one piece per gap)
-      }
       // ---- LDS ----
       if constexpr (g < 4) {
         constexpr int db = g >> 1, half = g & 1;
@@ -508,21 +549,41 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
           XR[g - 5][0] = lds_rd128(xr[0] + xo + (uint32_t)((g - 5) * 2 * BT));
           XR[g - 5][1] = lds_rd128(xr[1] + xo + (uint32_t)((g - 5) * 2 * BT));
         }
-      } else if constexpr (g >= 12 && g < 16) {
+      } else if constexpr (g < 12) {
+        // bias fragments of step i+1 (its tile is visible since E(i)): (qb, t2) = (0,0), (1,0), (0,1), (1,1)
+        constexpr int qb = g & 1, t2 = (g - 8) >> 1;
+        constexpr uint32_t o = b_next + (uint32_t)(qb * 2048 + t2 * 1024);
+        bf[qb][t2][0] = lds_rd_tr_half(btA[0] + o);
+        bf[qb][t2][1] = lds_rd_tr_half(btA[1] + o);
+      } else if constexpr (g < 16) {
         vf[g - 12] = lds_rd128(rmA[g - 12] + v_next);
       } else if constexpr (g >= NG - 4) {
         constexpr int db = (g - (NG - 4)) >> 1, half = g & 1;
         tn[db][half] = lds_rd_tr_half(trA[half][db] + o_cur);
       }
-      if constexpr (!(FAT5_QDB_ABL & 4)) {
-        if constexpr (g == 0) T[0][1] = lds_rd128(bA[1] + b_cur);       // (first used by element 4, gap 2)
-        else if constexpr (g == 7) T[1][0] = lds_rd128(bA[0] + b_cur + 2048u);  // (element 16, gap 10)
-        else if constexpr (g == 9) T[1][1] = lds_rd128(bA[1] + b_cur + 2048u);  // (element 20, gap 13)
-        else if constexpr (g == 18) TN0 = lds_rd128(bA[0] + b_next);  // (the next step's tile is visible since E(i))
+      // ---- the gap's second MFMA (query block 1) ----
+      if constexpr (g >= 12 && g < 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 14) Sn[1] = mfma32<BF16>(kf[g - 10], qf[1][g - 10], Sn[1]);
+        else Sn[1] = mfma32<BF16>(bfrag(1, g - 14), selB[g - 14], Sn[1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the dbias tile of step i-1 leaves ----
       if constexpr (g == 14 && !(FAT5_QDB_ABL & 1)) x_store(acc, row_ok ? dvo : 0x80000000u, t >= 1 ? (uint32_t)((t - 1) * 32 * ESZ) : dbrec);
       // ---- VALU ----
+      if constexpr (MK) {  // the masked C operands of step i+1's scores: query block 0 in gaps 5, 6 (first MFMA: gap 8), query block 1 in gaps 6, 7 (gap 9)
+        if constexpr (g == 5) {
+          lm[0] = lim0 - (t + 1) * 32;
+          lm[1] = lm[0] + 32;
+        }
+        if constexpr (g >= 5 && g <= 7) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if ((g == 5 && r < 8) || (g == 6 && r >= 8)) Sn[0][r] = (qdb_key(r, 0) > lm[0]) ? ninf_c : 0.f;
+            if ((g == 6 && r < 8) || (g == 7 && r >= 8)) Sn[1][r] = (qdb_key(r, 0) > lm[1]) ? ninf_c : 0.f;
+          }
+        }
+      }
       {
         constexpr auto lo = [](int gg) { return gg <= 0 ? 0 : (gg >= NG - 3 ? 32 : (32 * gg) / (NG - 3)); };
         static_for<lo(g - 2) - lo(g - 3)>([&](auto ei) {
@@ -557,25 +618,30 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   };
 
   if (nt > 0) {
-    score_step(0u, 0u, S, DP);
+    score_step(0u, 0u, 0u, 0, S, DP);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = zero4;
     TRK[0] = zero4;
     TRK[1] = zero4;
-    TN0 = lds_rd128(bA[0]);
-    // every key of the step visible to all 64 rows (no key tail, no causal mask)?  The same for every wave: they share their rows
-    auto fast = [&](const int t) { return t * 32 + 32 <= N && (!a.causal || t * 32 + 31 <= qw0 + P); };
+    // every key of step u exists (no key tail)? / is visible to all 64 rows?  The same for every wave: they share their rows
+    auto full = [&](const int u) { return u * 32 + 32 <= N; };
+    auto vis = [&](const int u) { return !a.causal || u * 32 + 31 <= qw0 + P; };
     int t = 0;
     while (t < nt) {
-      // steady state: four steps (K / bias ring slots 0..3) per trip, straight-line; visibility is monotone, so the last step of a trip decides
-      while ((t & 3) == 0 && t + 4 <= nt && fast(t + 3)) {
-        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value>(t + decltype(si)::value); });
+      // steady state: four steps (K / bias ring slots 0..3) per trip, straight-line.  Iteration u forms the scores of step u + 1: while step t + 4 is
+      // visible to every row no mask is needed; after that the trips carry the mask in the score MFMAs' C operand (visibility is monotone)
+      while ((t & 3) == 0 && t + 4 <= nt && full(t + 3) && vis(t + 4)) {
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(t + decltype(si)::value); });
         t += 4;
       }
-      // (the masked tail of the sweep, and whatever does not fill an aligned trip)
-      while (t < nt && !((t & 3) == 0 && t + 4 <= nt && fast(t + 3))) {
+      while ((t & 3) == 0 && t + 4 <= nt && full(t + 3) && !vis(t + 4)) {
+        static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, true>(t + decltype(si)::value); });
+        t += 4;
+      }
+      // (a key tail, and whatever does not fill an aligned trip)
+      if (t < nt && !((t & 3) == 0 && t + 4 <= nt && full(t + 3))) {
         generic_iter(t);
         ++t;
       }

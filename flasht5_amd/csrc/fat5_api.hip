@@ -371,8 +371,11 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   //  64-key mixed 292 vs 326 us, (8,12,2048) 154 vs 169 -> from 2048 keys on)
   const bool ctab_kv = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
   const bool kv64_causal_ok = !p->causal || p->N >= (ctab_kv ? 2048 : 4096);
+  // (dense, round 5 -- bias on the matrix pipe, causal mask in the C operand; 64-key vs 32-key body, us: (4,12,2048) 137 vs 164, (4,12,8192) 1700 vs 2208;
+  //  causal (16,12,512) 52.5 vs 54.1, (16,12,1024) 121 vs 133, (16,12,2048) 344 vs 392 -> from 192 workgroups on)
+  const bool dense_rule = dense && wg256 >= 192;
   L.kv64 = p->D == 64 && (!dense || dense_kv_ok) && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || ((wg256 >= (fills ? 320 : 512) ||
+           (b64_env == 1 || dense_rule || ((wg256 >= (fills ? 320 : 512) ||
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
                               //  (4,12,8192x1024) 190 vs 234; with the T5 bias 117 vs 146 and 213 vs 274)
                               (wg256 >= 160 && p->M >= 4096 && !p->causal)) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
@@ -449,12 +452,13 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // sum of dS in ONE kernel (attn_bwd_qdb64.h): no (B, H, M, N) staging tensor, no third recomputation of S / dP.
     const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
     const int ngrp = (p->B + 3) / 4;
-    const bool legal = p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
+    const bool legal = scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
                        p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
                        (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
                        (int64_t)p->M * p->N * (ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
                        ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
-    if (legal && qdb_env != 0 && (qdb_env == 1 || p->B >= 2)) {
+    // (a call that asks for one of the older dbias paths by variant bit keeps it)
+    if (legal && qdb_env != 0 && (qdb_env == 1 || (p->B >= 2 && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
       L.qdb64 = true;
       L.qdb_groups = ngrp;
       L.q64 = false;
