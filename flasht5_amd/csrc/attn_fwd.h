@@ -161,6 +161,31 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 
   FragAddr<D> fa;
   fa.init(l);
+  // Round 5: the dense bias added ON THE MATRIX PIPE (attn_bwd64.h: Bwd64Cfg): S^T = K Q^T + B^T E with B^T the bias tile read as a transposed operand
+  // fragment (lane = key, k-slot = query row: the tile in LDS is source-swizzled like a D = 64 image, so FragAddr<64>'s transposing reads apply) and
+  // E[k][row] = 1/scale where k-slot k is that row -- two more MFMAs per 32-key block instead of a conversion, a multiply and an add per element, and,
+  // the point, a dense tile without masked keys then IS a constant-bias tile: it runs the FAST / optimistic tile body.  Exact for a 1/scale that is
+  // a bf16 value (1: T5, 8: the default 1/sqrt(64)); other scales, fp16 and tiles that cannot travel by DMA keep the per-element form.  A row whose
+  // keys are ALL masked by finfo.min entries (`use_masking`; a uniform softmax in the reference) ends with l = 0 and sends its workgroup through the
+  // second pass, which runs the per-element form with its clamp.
+  FragAddr<64> fab;
+  fab.init(l);
+  u32x4 selB[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  bool bmm = false;
+  if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
+    const uint32_t invb = __float_as_uint(1.f / a.scale);
+    bmm = bias_dma && a.scale != 0.f && (invb & 0xffffu) == 0u && (invb & 0x7f800000u) != 0x7f800000u;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      uint32_t wv[4];
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);  // query rows of k-slots 2 j2, 2 j2 + 1
+        wv[j2] = (r0 == lq ? invb >> 16 : 0u) | (r0 + 1 == lq ? (invb >> 16) << 16 : 0u);
+      }
+      selB[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+    }
+  }
 
   // Optimistic softmax (bf16 only).  FlashAttention's reference point m need not be the running row maximum: ANY m
   // gives the exact result as long as exp2(x - m) neither overflows nor is flushed.  bf16 P and the fp32
@@ -170,7 +195,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // renormalises O, l by an exact power of two when l >= 2^40.  A score more than ~87 nats above everything seen before
   // would overflow inside one pair: l becomes inf/NaN, the workgroup notices at the end and redoes its tile with the
   // exact algorithm (second pass).  fp16 P would overflow at 2^16, so fp16 always runs the exact pass.
-  constexpr bool OPT = FAT5_OPTIMISTIC && BF16 && BIAS != FAT5_BIAS_DENSE;
+  constexpr bool OPT = FAT5_OPTIMISTIC && BF16;  // (dense bias: only the tiles whose bias sits inside the scores -- bmm -- run it)
   if (OPT && tid == 0) *sFlag = 0;
 
   f32x16 oacc[DB];
@@ -212,6 +237,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // One K/V tile.  FAST: no key of the tile is masked for any row of the workgroup and the bias is one
   // constant `cst` (none, or an all-far RPE tile): raw scores stay in registers, scale and constant are folded
   // into the exponent FMA.  Otherwise the generic body handles masks / per-element bias per 32-key block.
+  bool use_bmm = bmm;  // (false in the second pass)
   auto tile = [&]<int MODE, int BUF>(int t, float cst) {  // MODE 0 generic, 1 FAST, 2 FAST optimistic
     constexpr bool FAST = MODE != 0;
     const int n0 = t * BN;
@@ -241,6 +267,12 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         for (int kk = 0; kk < KK; ++kk) kf[kk] = ld_rm<D>(sKb, fa, kb, kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
+        if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
+          if (FAST || use_bmm) {  // + bias / scale: the wave's 32 rows x the block's 32 keys of the tile, transposed
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) s = mfma32<BF16>(ld_tr<64>(sB + BUF * Cfg::BIASB, fab, qg, t2, kbr), selB[t2], s);
+          }
+        }
       }
 
       float mul, add, mcand;
@@ -254,7 +286,13 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       } else {
         bool folded = fold_ok;
         float cb = 0.f;
-        if constexpr (BIAS == FAT5_BIAS_DENSE) {
+        if (BIAS == FAT5_BIAS_DENSE && use_bmm) {
+          // (the bias is inside the scores)
+          if (!folded) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] *= c2;
+          }
+        } else if constexpr (BIAS == FAT5_BIAS_DENSE) {
           folded = false;
           float bv[16];
           if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kbr, bv);
@@ -356,7 +394,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   //   [tb1, nt)    generic (N tail, causal diagonal)
   int ta = 0, tb0 = 0, tb1 = 0;
   float cst_a = 0.f, cst_b = 0.f;
-  if (fold_ok && BIAS != FAT5_BIAS_DENSE) {
+  if (fold_ok && (BIAS != FAT5_BIAS_DENSE || bmm)) {
     int t_full = N / BN;                                            // tiles without an N tail
     if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));  // n0 + BN - 1 <= m0 + P
     t_full = min(t_full, nt);
@@ -393,7 +431,11 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   };
 
   for (int pass = 0;; ++pass) {
-    const bool opt = OPT && pass == 0;
+    const bool opt = OPT && pass == 0 && (BIAS != FAT5_BIAS_DENSE || bmm);
+    if (BIAS == FAT5_BIAS_DENSE && pass > 0) {  // the second pass of a dense problem: per-element bias with its clamp, every tile general
+      use_bmm = false;
+      ta = tb0 = tb1 = 0;
+    }
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -452,6 +494,11 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     } else {
       if (!opt) break;
       if (!(l_run[0] + l_run[1] < 0x1p120f)) *sFlag = 1;
+      if constexpr (BIAS == FAT5_BIAS_DENSE) {
+        // a row that sees keys (by the causal rule) but summed to nothing: every key masked by the bias itself (see above)
+        const float lt = pair_sum(l_run[0] + l_run[1]);
+        if (qrow < M && lt == 0.f && (!a.causal || qrow + P >= 0)) *sFlag = 1;
+      }
       __syncthreads();
       if (*sFlag == 0) break;
     }
@@ -500,13 +547,15 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   }
 }
 
+// (dense bias: the two tile buffers + two bias tiles are 48 .. 96 KB of LDS -- at most two waves per SIMD fit anyway, so the allocator gets their registers:
+//  at the three-wave cap the dense instantiations spill 176 .. 252 bytes per lane)
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
 void attn_fwd_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, false, BDMA>(a);
 }
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
 void attn_fwd_split_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, true, BDMA>(a);
 }
