@@ -53,8 +53,9 @@ namespace fat5 {
 // covered by its own counted vmcnt: no barrier).  The bias is added ON THE MATRIX PIPE: S' = Q K^T + E B - L/scale with B the bias tile read as a
 // transposed operand fragment (lane = key, k-slot = row: the ds_read_b64_tr_b16 addressing of the Q^T / dO^T fragments) and E[row][k] = 1/scale where
 // k-slot k is that row -- two more 32x32x16 MFMAs per key block and step (+12.5 % pipe time, inside the slack of the VALU-bound gaps) instead of a
-// shift / mask, a multiply by log2(e) and an add per element (+64 VALU instructions per step: measured +32 % on the kernel).  Exact: a 16-bit bias
-// times a 1/scale that is itself a 16-bit value (1, 8: T5's and the default scale; the dispatcher checks) accumulates in fp32 without rounding.
+// shift / mask, a multiply by log2(e) and an add per element (+64 VALU instructions per step: measured +32 % on the kernel).  1/scale enters as TWO
+// 16-bit terms (hi + lo, 2^-17 relative: the reference benchmarks at sm_scale 1.3) in two k-slots that both see the same bias row: a fragment holds
+// one 8-byte transposing read twice, one MFMA covers 8 rows -- four per key block and step, eight reads as before.
 template <int D, bool HALF = false, bool SELF = false, bool DENSE = false>
 struct Bwd64Cfg {
   static_assert(!(HALF && SELF), "the self-sufficient variant exists for 256-key workgroups only");
@@ -395,21 +396,25 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   stA = lds0 + ring0 + (uint32_t)(SELF ? 3 * IMG + 16 * hi : 2 * IMG + wp * 1024 + 16 * hi);  // this lane's rows 8g + 4hi ..+3: float4 g at +32g (-L/scale), +DLOFF+32g (-delta)
   asm volatile("" : "+v"(stA));
   // DENSE: the transposing-read addresses of this wave's bias image (slot / 16-row offsets are immediates): btr[j2][kb] + 2048 t2 gives the lane the bias of
-  // rows 16 t2 + 8 j2 + 4 hi + (0..3) at its key of block kb: k-slots 4 j2 .. 4 j2 + 3 of the B operand (t2, kb) -- and the selector operands E(t2)
+  // rows 8 jj + 4 hi + (0..3), jj = 2 t2 + j2, at its key of block kb: that read, twice, is the B operand (jj, kb) -- and the selector operands E(jj)
   [[maybe_unused]] uint32_t btr[2][2] = {{0u, 0u}, {0u, 0u}};
-  [[maybe_unused]] u32x4 selA[2];
+  [[maybe_unused]] u32x4 selA[4];
   if constexpr (DENSE) {
-    const uint32_t inv = __float_as_uint(1.f / a.scale) >> 16;  // (exactly 1/scale: the dispatcher takes this body for such scales only)
+    // E(jj): A operand, lane = row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3), holding 1/scale's leading 16 bits for j < 4 and the next 16 for j >= 4
+    const float invf = 1.f / a.scale;
+    const uint32_t ih = __float_as_uint(invf) >> 16;
+    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
+    for (int jj = 0; jj < 4; ++jj) {
       uint32_t wv[4];
 #pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) {
-        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);  // rows of k-slots 2 j2, 2 j2 + 1
-        wv[j2] = (r0 == lq ? inv : 0u) | (r0 + 1 == lq ? inv << 16 : 0u);
+      for (int j2 = 0; j2 < 4; ++j2) {  // word j2 = k-slots 2 j2, 2 j2 + 1
+        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
+        const uint32_t val = j2 < 2 ? ih : il;
+        wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
       }
-      selA[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
-      asm volatile("" : "+v"(selA[t2]));
+      selA[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      asm volatile("" : "+v"(selA[jj]));
     }
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2)
@@ -504,9 +509,12 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sx[kb]);
     if constexpr (DENSE) {  // + bias / scale (see Bwd64Cfg)
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
+      for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(selA[t2], lds_rd_tr(btr[0][kb] + so + (uint32_t)(2048 * t2), btr[1][kb] + so + (uint32_t)(2048 * t2)), Sx[kb]);
+        for (int kb = 0; kb < 2; ++kb) {
+          const u32x2 bh_ = lds_rd_tr_half(btr[jj & 1][kb] + so + (uint32_t)(2048 * (jj >> 1)));
+          Sx[kb] = mfma32<BF16>(selA[jj], u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, Sx[kb]);
+        }
     }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
@@ -622,14 +630,15 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // addend, read from this lane's padded table copy (attn_common.h) -- four 16-byte reads per key block, each issued three gaps ahead of
   // its FMAs (the first one during the previous iteration: TN0) -- and the per-diagonal sums of the step's rounded dS follow the
   // iteration as a block (diag_sums on DS).  A band step was the general, unpipelined iteration before: ~2.9x a pipelined step.
-  // DN (round 5): the same iteration with a DENSE bias: the scores of step j+1 get + bias / scale from four more MFMAs (Bwd64Cfg) -- gaps 20..23 hold two
-  // MFMAs each, strictly alternating between the two key blocks' accumulators --, their B operands from eight transposing reads of the wave's bias image
-  // of step j+1 in gaps 13..21; the softmax stage is the one without bias
+  // DN (round 5): the same iteration with a DENSE bias: the scores of step j+1 get + bias / scale from eight more MFMAs (Bwd64Cfg) -- gaps 16..23 hold two
+  // MFMAs each, key block 0 at the head of the gap and key block 1 behind its LDS section (the two accumulators alternate strictly): k-steps 0..3, then
+  // the four 8-row groups of the bias --, their B operands from eight transposing reads of the wave's bias image of step j+1 in gaps 13..19; the softmax
+  // stage is the one without bias
   // MK (round 5): the scores of step j+1 are formed with the causal mask in their C operand (mask_c): a trip on the diagonal
   auto fast_iter = [&]<int SL, bool BAND, bool DN = false, bool MK = false>(const int j, const float cst) {
     constexpr uint32_t o_prev = ((SL + 3) & 3) * SLOT, o_cur = SL * SLOT, o_next = ((SL + 1) & 3) * SLOT;
     u32x4 T[2][4];
-    [[maybe_unused]] u32x2 bbh[2][2][2];  // [kb][t2][half]: B operands of the bias MFMAs
+    [[maybe_unused]] u32x2 bbh[2][4];  // [kb][jj]: B operands of the bias MFMAs (each read serves both halves of its operand)
     uint32_t tadr1 = 0u;
     if constexpr (BAND) T[0][0] = TN0;
     // BAND: the step's dS onto its diagonals (diag_sum.h), element e three gaps after its exponent argument: one rotating add for
@@ -669,10 +678,11 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else fr = u32x4{trh[p][wh][0][0], trh[p][wh][0][1], trh[p][wh][1][0], trh[p][wh][1][1]};
         if constexpr (wh == 0) mfma_acc_agpr<BF16>(dv[kb][db], fr, PB[kb][t2]);
         else mfma_acc_agpr<BF16>(dk[kb][db], fr, DS[kb][t2]);
-      } else if constexpr (g < 24 && DN && g >= 20) {
+      } else if constexpr (g < 24 && DN) {
         // (the first of the gap's two MFMAs: key block 0; the second one follows the gap's LDS section)
-        if constexpr (g < 22) Sn[0] = mfma32<BF16>(qa[g - 18], kf[0][g - 18], Sn[0]);
-        else Sn[0] = mfma32<BF16>(selA[g - 22], u32x4{bbh[0][g - 22][0][0], bbh[0][g - 22][0][1], bbh[0][g - 22][1][0], bbh[0][g - 22][1][1]}, Sn[0]);
+        if constexpr (g == 16) Sn[0] = mfma32<BF16>(qa[0], kf[0][0], MK ? NLm[0] : NL);
+        else if constexpr (g < 20) Sn[0] = mfma32<BF16>(qa[g - 16], kf[0][g - 16], Sn[0]);
+        else Sn[0] = mfma32<BF16>(selA[g - 20], u32x4{bbh[0][g - 20][0], bbh[0][g - 20][1], bbh[0][g - 20][0], bbh[0][g - 20][1]}, Sn[0]);
       } else if constexpr (g < 24) {
         constexpr int kk = (g - 16) >> 1, kb = g & 1;
         if constexpr (kk == 0) Sn[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], MK ? NLm[kb] : NL);
@@ -695,7 +705,15 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
           tm[0] = tbase - (mt0 + j + 1) * 32;
           tm[1] = tm[0] + 32;
         }
-        if constexpr (g >= 13 && g <= 16) {
+        if constexpr (DN) {  // (two MFMAs per gap from gap 16 on: both masks by then)
+          if constexpr (g >= 13 && g <= 15) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if ((g == 13 && r < 8) || (g == 14 && r >= 8)) NLm[0][r] = ((r & 3) + 8 * (r >> 2) < tm[0]) ? ninf_c : NL[r];
+              if ((g == 14 && r < 8) || (g == 15 && r >= 8)) NLm[1][r] = ((r & 3) + 8 * (r >> 2) < tm[1]) ? ninf_c : NL[r];
+            }
+          }
+        } else if constexpr (g >= 13 && g <= 16) {
           constexpr int kb = (g - 13) >> 1, r0 = 8 * ((g - 13) & 1);
 #pragma unroll
           for (int r = r0; r < r0 + 8; ++r) NLm[kb][r] = ((r & 3) + 8 * (r >> 2) < tm[kb]) ? ninf_c : NL[r];
@@ -728,18 +746,22 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else tnq[half] = lds_rd_tr_half(trA[half][0] + o_cur);
       }
       if constexpr (DN) {
-        // bias fragments of step j+1 (its tile has landed since E(j)): (kb, t2, half) -- (0,0) in gaps 13, 14; (1,0): 15, 16; (0,1): 18; (1,1): 20, 21
-        if constexpr (g == 13 || g == 14) bbh[0][0][g - 13] = lds_rd_tr_half(btr[g - 13][0] + o_next);
-        else if constexpr (g == 15 || g == 16) bbh[1][0][g - 15] = lds_rd_tr_half(btr[g - 15][1] + o_next);
-        else if constexpr (g == 18) {
-          bbh[0][1][0] = lds_rd_tr_half(btr[0][0] + o_next + 2048u);
-          bbh[0][1][1] = lds_rd_tr_half(btr[1][0] + o_next + 2048u);
-        } else if constexpr (g == 20 || g == 21) bbh[1][1][g - 20] = lds_rd_tr_half(btr[g - 20][1] + o_next + 2048u);
+        // bias fragments of step j+1 (its tile has landed since E(j)): row group jj of key block kb -- kb 0 in gaps 13, 14, 16, 17; kb 1 in 14, 15, 18, 19
+        if constexpr (g == 13) bbh[0][0] = lds_rd_tr_half(btr[0][0] + o_next);
+        else if constexpr (g == 14) {
+          bbh[0][1] = lds_rd_tr_half(btr[1][0] + o_next);
+          bbh[1][0] = lds_rd_tr_half(btr[0][1] + o_next);
+        } else if constexpr (g == 15) bbh[1][1] = lds_rd_tr_half(btr[1][1] + o_next);
+        else if constexpr (g == 16) bbh[0][2] = lds_rd_tr_half(btr[0][0] + o_next + 2048u);
+        else if constexpr (g == 17) bbh[0][3] = lds_rd_tr_half(btr[1][0] + o_next + 2048u);
+        else if constexpr (g == 18) bbh[1][2] = lds_rd_tr_half(btr[0][1] + o_next + 2048u);
+        else if constexpr (g == 19) bbh[1][3] = lds_rd_tr_half(btr[1][1] + o_next + 2048u);
         // the gap's second MFMA: key block 1
-        if constexpr (g >= 20 && g < 24) {
+        if constexpr (g >= 16 && g < 24) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (g < 22) Sn[1] = mfma32<BF16>(qa[g - 18], kf[1][g - 18], Sn[1]);
-          else Sn[1] = mfma32<BF16>(selA[g - 22], u32x4{bbh[1][g - 22][0][0], bbh[1][g - 22][0][1], bbh[1][g - 22][1][0], bbh[1][g - 22][1][1]}, Sn[1]);
+          if constexpr (g == 16) Sn[1] = mfma32<BF16>(qa[0], kf[1][0], MK ? NLm[1] : NL);
+          else if constexpr (g < 20) Sn[1] = mfma32<BF16>(qa[g - 16], kf[1][g - 16], Sn[1]);
+          else Sn[1] = mfma32<BF16>(selA[g - 20], u32x4{bbh[1][g - 20][0], bbh[1][g - 20][1], bbh[1][g - 20][0], bbh[1][g - 20][1]}, Sn[1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }

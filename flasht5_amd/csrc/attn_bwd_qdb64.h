@@ -19,8 +19,9 @@
 //    Deterministic: fixed summation order, no atomics.  The reference's sum (fp32 accumulation of bf16-rounded dS, one final rounding) is reproduced.
 //  * The bias is added ON THE MATRIX PIPE (as in the dense form of the 64-key dK/dV body, attn_bwd64.h: Bwd64Cfg): S^T = K Q^T + B^T E with B^T the bias tile read
 //    as a transposed operand fragment (lane = key slot, k-slot = query row; ds_read_b64_tr_b16 on the tile: its suppliers point at the 4-key groups of
-//    the key permutation below) and E[k][row] = 1/scale where k-slot k is that row: four more MFMAs per step instead of 96 VALU instructions per lane.
-//    Exact for a 1/scale that is a 16-bit value itself (the dispatcher checks).  The causal mask rides in the C operand of the same MFMAs (-inf where the
+//    the key permutation below) and E[k][row] = 1/scale where k-slot k is that row -- as two 16-bit terms (hi + lo) in two k-slots that see the same bias
+//    row, so a fragment holds one 8-byte transposing read twice and one MFMA covers 8 rows: eight more MFMAs per step instead of 96 VALU instructions
+//    per lane.  The causal mask rides in the C operand of the same MFMAs (-inf where the
 //    key is masked: the steps on the diagonal run the pipelined iteration, and a causal sweep is padded to whole trips of four steps with fully masked ones).
 //  * Keys are PERMUTED inside a step (LDS row rho of the K / V images holds key pi(rho), qdb_pi below): the MFMA k-slot <-> key mapping is free as
 //    long as both operands agree, and with this one a lane's 16 score registers of a query block are the 16 keys 16 hi .. 16 hi + 15 of its row --
@@ -276,7 +277,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   for (int i = 0; i < 2; ++i) tA[i] = (uint32_t)(lq * 64 + (((2 * hi + i) ^ fsw) << 4));
   // bias fragments (A operands of the bias MFMAs): ds_read_b64_tr_b16 with this lane as SUPPLIER of row 16 t2 + 8 j2 + 4 hi + (i >> 2) (i = l & 15), keys
   // 16 (c & 1) + 8 (c >> 1) + 4 g .. + 3 (c = i & 3, g = (l >> 4) & 1): the 4-key group whose slots 16 g + 4 c .. + 3 the receiving lanes of its 16 hold
-  uint32_t btA[2];  // [j2]; query block qb: + 2048, t2: + 1024, ring slot: + BT s
+  uint32_t btA[2];  // [jj & 1]; query block qb: + 2048, jj >> 1: + 1024, ring slot: + BT s
   {
     const int i = l & 15, c = i & 3, g = (l >> 4) & 1;
 #pragma unroll
@@ -286,20 +287,23 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       asm volatile("" : "+v"(btA[j2]));
     }
   }
-  // selector operands E(t2) (B: lane = query row lq, k-slot (hi, j) <-> row 16 t2 + 8 (j >> 2) + 4 hi + (j & 3)): 1/scale where that is the lane's own row
-  u32x4 selB[2];
+  // selector operands E(jj) (B: lane = query row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3), 1/scale's leading 16 bits for j < 4, the next 16 for j >= 4)
+  u32x4 selB[4];
   {
-    const uint32_t inv = __float_as_uint(1.f / a.scale) >> 16;
+    const float invf = 1.f / a.scale;
+    const uint32_t ih = __float_as_uint(invf) >> 16;
+    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
+    for (int jj = 0; jj < 4; ++jj) {
       uint32_t wv[4];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
-        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);
-        wv[j2] = (r0 == lq ? inv : 0u) | (r0 + 1 == lq ? inv << 16 : 0u);
+        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
+        const uint32_t val = j2 < 2 ? ih : il;
+        wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
       }
-      selB[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
-      asm volatile("" : "+v"(selB[t2]));
+      selB[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      asm volatile("" : "+v"(selB[jj]));
     }
   }
   const float ninf_c = a.scale > 0.f ? -INFINITY : INFINITY;  // a raw score this large is a zero probability
@@ -377,11 +381,11 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) Sx[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sx[qb]);
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        const uint32_t o = bo + (uint32_t)(qb * 2048 + t2 * 1024);
-        Sx[qb] = mfma32<BF16>(lds_rd_tr(btA[0] + o, btA[1] + o), selB[t2], Sx[qb]);
+        const u32x2 bh_ = lds_rd_tr_half(btA[jj & 1] + bo + (uint32_t)(qb * 2048 + (jj >> 1) * 1024));
+        Sx[qb] = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], Sx[qb]);
       }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
@@ -477,9 +481,9 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   };
 
   // One pipelined iteration = 24 MFMA gaps (attn_bwd64.h: attn_bwd_q64_body::fast_iter) + the dense bias + the exchange:
-  //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1; 8..15: S^T[qb] of step i+1 -- gaps 8..11 one k-step each, gaps 12..15 TWO MFMAs
-  //          each (query block 0 at the head of the gap, query block 1 behind its LDS section; the two accumulators alternate strictly): k-steps 2, 3, then
-  //          + bias / scale (t2 = 0, 1); 16..23: dP'^T[qb] (C = -delta on the first k-step)
+  //   MFMA   g < 8: dQ^T[qb][db] += K^T(t2, db) . dS^T[qb][t2] of step i-1; 8..15: S^T[qb] of step i+1, TWO MFMAs per gap (query block 0 at the head of
+  //          the gap, query block 1 behind its LDS section; the two accumulators alternate strictly): k-steps 0..3, then + bias / scale (the four 8-row
+  //          groups); 16..23: dP'^T[qb] (C = -delta on the first k-step)
   //   MFMA16 gaps 7..10: the batch sum of step i-1's dS quarter (two accumulators x two wave pairs)
   //   VALU   32 elements per lane opened evenly over gaps 0 .. 20: x = s * c2 - L2 | one gap later p = exp2(x) | one more: ds = p * dp' | pairs packed
   //          once both halves exist.  MK: the C operands of step i+1's scores (mask_c) in gaps 5..7
@@ -494,7 +498,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     f32x16 Sn[2], DPn[2];
     [[maybe_unused]] int lm[2] = {0, 0};
     u32x4 DSn[2][2], kf[KK], vf[KK], XR[2][2];
-    u32x2 th[2][2], tn[2][2], bf[2][2][2];  // bf[qb][t2][j2]
+    u32x2 th[2][2], tn[2][2], bf[2][4];  // bf[qb][jj]: bias fragments (each read serves both halves of its operand)
     float X[32], Pv[32], Dv[32];
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const uint32_t xo = xpar;
@@ -505,7 +509,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       constexpr int qb = E0 >> 4, r0 = E0 & 15;
       DSn[qb][r0 >> 3][(r0 & 7) >> 1] = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
     };
-    auto bfrag = [&](const int qb, const int t2) { return u32x4{bf[qb][t2][0][0], bf[qb][t2][0][1], bf[qb][t2][1][0], bf[qb][t2][1][1]}; };
+    auto bfrag = [&](const int qb, const int jj) { return u32x4{bf[qb][jj][0], bf[qb][jj][1], bf[qb][jj][0], bf[qb][jj][1]}; };
     static_for<NG>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       // ---- MFMA ----
@@ -516,13 +520,11 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
         else fr = u32x4{th[db][0][0], th[db][0][1], th[db][1][0], th[db][1][1]};
         mfma_acc_agpr<BF16>(dq[qb][db], fr, DSB[qb][t2]);
       } else if constexpr (g < 12) {
-        constexpr int kk = (g - 8) >> 1, qb = g & 1;
-        if constexpr (kk == 0 && !MK) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
-        else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);  // (MK: Sn holds the mask, formed in gaps 5..7)
-      } else if constexpr (g < 14) {
-        Sn[0] = mfma32<BF16>(kf[g - 10], qf[0][g - 10], Sn[0]);
+        // (gaps 8..15: two MFMAs each -- query block 0 here, query block 1 behind the gap's LDS section)
+        if constexpr (g == 8 && !MK) Sn[0] = mfma32<BF16>(kf[0], qf[0][0], zero16);
+        else Sn[0] = mfma32<BF16>(kf[g - 8], qf[0][g - 8], Sn[0]);  // (MK: Sn holds the mask, formed in gaps 5..7)
       } else if constexpr (g < 16) {
-        Sn[0] = mfma32<BF16>(bfrag(0, g - 14), selB[g - 14], Sn[0]);
+        Sn[0] = mfma32<BF16>(bfrag(0, g - 12), selB[g - 12], Sn[0]);
       } else {
         constexpr int kk = (g - 16) >> 1, qb = g & 1;
         if constexpr (kk == 0) DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], nd16[qb]);  // (nd16 lives for the whole loop: no WAR window)
@@ -550,11 +552,11 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
           XR[g - 5][1] = lds_rd128(xr[1] + xo + (uint32_t)((g - 5) * 2 * BT));
         }
       } else if constexpr (g < 12) {
-        // bias fragments of step i+1 (its tile is visible since E(i)): (qb, t2) = (0,0), (1,0), (0,1), (1,1)
-        constexpr int qb = g & 1, t2 = (g - 8) >> 1;
-        constexpr uint32_t o = b_next + (uint32_t)(qb * 2048 + t2 * 1024);
-        bf[qb][t2][0] = lds_rd_tr_half(btA[0] + o);
-        bf[qb][t2][1] = lds_rd_tr_half(btA[1] + o);
+        // bias fragments of step i+1 (its tile is visible since E(i)): row groups jj = g - 8 of both query blocks
+        constexpr int jj = g - 8;
+        constexpr uint32_t o = b_next + (uint32_t)((jj >> 1) * 1024);
+        bf[0][jj] = lds_rd_tr_half(btA[jj & 1] + o);
+        bf[1][jj] = lds_rd_tr_half(btA[jj & 1] + o + 2048u);
       } else if constexpr (g < 16) {
         vf[g - 12] = lds_rd128(rmA[g - 12] + v_next);
       } else if constexpr (g >= NG - 4) {
@@ -562,10 +564,11 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
         tn[db][half] = lds_rd_tr_half(trA[half][db] + o_cur);
       }
       // ---- the gap's second MFMA (query block 1) ----
-      if constexpr (g >= 12 && g < 16) {
+      if constexpr (g >= 8 && g < 16) {
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (g < 14) Sn[1] = mfma32<BF16>(kf[g - 10], qf[1][g - 10], Sn[1]);
-        else Sn[1] = mfma32<BF16>(bfrag(1, g - 14), selB[g - 14], Sn[1]);
+        if constexpr (g == 8 && !MK) Sn[1] = mfma32<BF16>(kf[0], qf[1][0], zero16);
+        else if constexpr (g < 12) Sn[1] = mfma32<BF16>(kf[g - 8], qf[1][g - 8], Sn[1]);
+        else Sn[1] = mfma32<BF16>(bfrag(1, g - 12), selB[g - 12], Sn[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the dbias tile of step i-1 leaves ----

@@ -163,27 +163,32 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   fa.init(l);
   // Round 5: the dense bias added ON THE MATRIX PIPE (attn_bwd64.h: Bwd64Cfg): S^T = K Q^T + B^T E with B^T the bias tile read as a transposed operand
   // fragment (lane = key, k-slot = query row: the tile in LDS is source-swizzled like a D = 64 image, so FragAddr<64>'s transposing reads apply) and
-  // E[k][row] = 1/scale where k-slot k is that row -- two more MFMAs per 32-key block instead of a conversion, a multiply and an add per element, and,
-  // the point, a dense tile without masked keys then IS a constant-bias tile: it runs the FAST / optimistic tile body.  Exact for a 1/scale that is
-  // a bf16 value (1: T5, 8: the default 1/sqrt(64)); other scales, fp16 and tiles that cannot travel by DMA keep the per-element form.  A row whose
+  // E[k][row] = 1/scale where k-slot k is that row -- four more MFMAs per 32-key block instead of a conversion, a multiply and an add per element, and,
+  // the point, a dense tile without masked keys then IS a constant-bias tile: it runs the FAST / optimistic tile body.  fp16 and tiles that cannot
+  // travel by DMA keep the per-element form.  A row whose
   // keys are ALL masked by finfo.min entries (`use_masking`; a uniform softmax in the reference) ends with l = 0 and sends its workgroup through the
   // second pass, which runs the per-element form with its clamp.
   FragAddr<64> fab;
   fab.init(l);
-  u32x4 selB[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  // selector operands E(jj) (B: lane = query row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3) of the wave's 32, holding 1/scale's leading 16 bits
+  // for j < 4 and the next 16 for j >= 4: hi + lo, 2^-17 relative -- the reference benchmarks at sm_scale 1.3)
+  u32x4 selB[4];
   bool bmm = false;
   if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
-    const uint32_t invb = __float_as_uint(1.f / a.scale);
-    bmm = bias_dma && a.scale != 0.f && (invb & 0xffffu) == 0u && (invb & 0x7f800000u) != 0x7f800000u;
+    const float invf = 1.f / a.scale;
+    const uint32_t ih = __float_as_uint(invf) >> 16;
+    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
+    bmm = bias_dma && a.scale != 0.f && (__float_as_uint(invf) & 0x7f800000u) != 0x7f800000u;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
+    for (int jj = 0; jj < 4; ++jj) {
       uint32_t wv[4];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
-        const int r0 = 16 * t2 + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3);  // query rows of k-slots 2 j2, 2 j2 + 1
-        wv[j2] = (r0 == lq ? invb >> 16 : 0u) | (r0 + 1 == lq ? (invb >> 16) << 16 : 0u);
+        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
+        const uint32_t val = j2 < 2 ? ih : il;
+        wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
       }
-      selB[t2] = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      selB[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
     }
   }
 
@@ -268,9 +273,14 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
         if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
-          if (FAST || use_bmm) {  // + bias / scale: the wave's 32 rows x the block's 32 keys of the tile, transposed
+          if (FAST || use_bmm) {  // + bias / scale: the wave's 32 rows x the block's 32 keys of the tile, transposed (one 8-byte read, twice, per 8-row group)
+            typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) s = mfma32<BF16>(ld_tr<64>(sB + BUF * Cfg::BIASB, fab, qg, t2, kbr), selB[t2], s);
+            for (int jj = 0; jj < 4; ++jj) {
+              const char* pp = sB + BUF * Cfg::BIASB + fab.tr[jj & 1][kbr] + (32 * qg + 16 * (jj >> 1)) * 128;
+              const u32x2 bh_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)pp));
+              s = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], s);
+            }
           }
         }
       }

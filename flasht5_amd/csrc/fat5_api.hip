@@ -305,13 +305,8 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   // dense bias (round 5): the 256-key form of the 64-key body with the step's bias tile as one more LDS image per wave (attn_bwd64.h, DENSE): bf16,
   // bias rows 16-byte aligned (LDS-DMA)
   const bool dense = p->bias_mode == FAT5_BIAS_DENSE;
-  // (the body adds bias / scale on the matrix pipe: exact only when 1 / scale is itself a bf16 value -- 1 (T5: no scaling), 8 (the default 1/sqrt(64)), ...)
-  uint32_t inv_bits;
-  {
-    const float inv = p->sm_scale != 0.f ? 1.f / p->sm_scale : 0.f;
-    memcpy(&inv_bits, &inv, 4);
-  }
-  const bool scale_exact = p->sm_scale != 0.f && (inv_bits & 0xffffu) == 0 && std::isfinite(1.f / p->sm_scale);
+  // (the bodies add bias / scale on the matrix pipe, 1 / scale as two 16-bit terms: a zero scale keeps the older bodies)
+  const bool scale_exact = p->sm_scale != 0.f && std::isfinite(1.f / p->sm_scale) && std::isfinite(p->sm_scale);
   const bool dense_kv_ok = dense && scale_exact && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
                            (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) &&
                            ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);

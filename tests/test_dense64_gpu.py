@@ -126,3 +126,25 @@ def test_kv64_dense_matches_oracle_and_the_32key_body(B, H, M, N, causal, kind):
         assert maxdiff(new[i], old[i]) <= 2.0 ** -6 * max(1.0, float(old[i].float().abs().max()))
     nred = (B if b.shape[0] == 1 else 1) * (H if b.shape[1] == 1 else 1)
     assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + nred)
+
+
+@pytest.mark.parametrize("scale", [1.3, 0.0884, -0.5, 1.0])
+@pytest.mark.parametrize("B,H,M,N,causal", [(4, 2, 512, 512, True), (3, 2, 300, 560, False)])
+def test_dense_bodies_at_scales_that_are_not_powers_of_two(B, H, M, N, causal, scale):
+    """The bias rides into the scores as bias * (1 / scale) on the matrix pipe, 1 / scale as two 16-bit terms: the reference benchmarks at sm_scale 1.3
+    (benchmarks/bench_fa2_bias.py), 1 / sqrt(128) = 0.0884, a negative scale, and T5's 1.0 -- forward, dQ + dbias (qdb64) and the 64-key dK/dV body."""
+    from flasht5_amd import _lib
+    dtype = torch.bfloat16
+    q, k, v, b, do = make_inputs(B, H, M, N, 64, dtype, "1h", seed=B * M + N + 1, strided=True)
+    if abs(scale) > 1.0:  # (keep the logits in a sane range, as the reference's benchmark inputs do)
+        q = (q.float() * 0.5).to(dtype)
+    ref = oracle_all(q, k, v, b, do, scale, causal)
+    pn, new = _plan(q, k, v, do, b, causal, scale, _lib.V_QDB64_ON | _lib.V_KV64_ON)
+    assert pn.describe()["dq"] == "64row-batch4" and pn.describe()["dkdv"] == "64key"
+    assert maxdiff(pn.o, ref["o"]) <= bound(ref["o"], dtype)
+    fin = torch.isfinite(ref["L"])
+    assert maxdiff(pn.lse[fin], ref["L"][fin]) <= 1e-3 * max(1.0, float(ref["L"][fin].abs().max()))
+    for got, key in zip(new[:3], ("dq", "dk", "dv")):
+        assert torch.isfinite(got.float()).all(), key
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
