@@ -222,6 +222,34 @@ def reference_shape_bench(device):
     return out
 
 
+def dense_by_seq_bench(device):
+    """The reference's own operator at the metric's sizes: (4,12,S,64) bf16, non-causal, a dense (1,12,S,S) bias shared by the batch + its gradient
+    (flash_attention_v2_bias(q, k, v, bias); modeling_flash_t5.py:280-285).  FLOPs as everywhere (benchmarks/bench_fa2_bias.py:10-13)."""
+    out = {}
+    for S in (512, 2048, 8192):
+        plan = make_plan(S, "dense", device, seed=0)[0]
+        it = 50 if S <= 2048 else 10
+        sf = event_stats(plan.forward, it, reps=3)
+        plan.forward()
+        sb = event_stats(plan.backward, it, reps=3)
+        stages = {}
+        for name, st in (("dq_dbias", 1), ("dkdv", 2), ("reduce", 4)):
+            stages[name + "_ms"] = round(event_time(lambda st=st: plan.backward(st), max(5, it // 2), warmup=1, prewarm_s=0.05), 4)
+        f = fwd_flops(S)
+        tf, tb = sf["median"], sb["median"]
+        bias_b = H * S * S * 2
+        alg_bwd = 2 * D * 2 * B * H * (S + S) * 2 + 8 * B * H * S + 2 * bias_b  # SURVEY 8(d): q, k, v, o, do read, dq, dk, dv written, L / delta, bias read + dbias written
+        out[str(S)] = {"fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4), "fwd_tflops": round(f / tf / 1e9, 1), "bwd_tflops": round(2.5 * f / tb / 1e9, 1),
+                       "fwd_bwd_tflops": round(3.5 * f / (tf + tb) / 1e9, 1), "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4),
+                       "bwd_frac_of_peak": round(2.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4), "bwd_stages": stages, "kernels": plan.describe(),
+                       "bwd_alg_bytes": alg_bwd, "bwd_alg_GBs": round(alg_bwd / tb / 1e6, 1),
+                       "bwd_traffic": {k_: load_traffic(k_, S, "dense") for k_ in ("attn_bwd_dq", "attn_bwd_dkdv")}}
+        del plan
+        torch.cuda.empty_cache()
+    out["what"] = "(4,12,S,64) bf16, non-causal, dense (1,12,S,S) bias + dbias, sm_scale 0.125, (B,S,H,D)-strided inputs; median of 3 event-timed batches"
+    return out
+
+
 def event_time(fn, iters, warmup=3, prewarm_s=0.2):
     """average ms per call of fn(), measured with HIP events on the current stream, at steady-state clocks: a
     wall-clock pre-warm first (after an idle gap -- plan construction, the previous measurement's teardown -- the GPU
@@ -257,7 +285,11 @@ def seq_rooflines(S, mode, plan, iters):
     f = fwd_flops(S)
     plan.forward()
     plan.backward()
-    stages = {"attn_fwd": (plan.forward, f), "attn_bwd_dq": (lambda: plan.backward(1), 0.5 * f), "attn_bwd_dkdv": (lambda: plan.backward(2), 2.0 * f)}
+    if plan.bwd_launches() == 1:
+        # the step's backward is ONE launch holding both halves (the stand-alone dq / dkdv stages are not what runs)
+        stages = {"attn_fwd": (plan.forward, f), "attn_bwd_fused": (lambda: plan.backward(3), 2.5 * f)}
+    else:
+        stages = {"attn_fwd": (plan.forward, f), "attn_bwd_dq": (lambda: plan.backward(1), 0.5 * f), "attn_bwd_dkdv": (lambda: plan.backward(2), 2.0 * f)}
     out = {}
     for name, (fn, fl) in stages.items():
         st = event_stats(fn, iters, reps=3)
@@ -266,7 +298,8 @@ def seq_rooflines(S, mode, plan, iters):
                      "traffic": load_traffic(name, S, mode)}
     dom = max(out, key=lambda n: out[n]["us_median"])
     return {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "dominant": dom, "achieved": out[dom]["achieved"],
-            "frac": out[dom]["frac"], "avg_launch_us": out[dom]["us_median"], "traffic": out[dom]["traffic"], "stages": out}
+            "frac": out[dom]["frac"], "avg_launch_us": out[dom]["us_median"], "traffic": out[dom]["traffic"], "stages": out,
+            "kernels": plan.describe()}
 
 
 def cfg5_step_flops(cfg, B, S, T):
@@ -473,13 +506,21 @@ def cpu_baseline(S=512, reps=5):
     # a pinned thread count (the intra-op pool's default follows the box: 0.038 -> 1.13 TFLOP/s over three driver runs of the same
     # code in rounds 1-3) and the MEDIAN of the runs after one untimed warm-up (allocator, thread pool start-up); the min beside it
     threads = min(64, os.cpu_count() or 1)
+    aff = None
+    try:  # keep the pool on `threads` CPUs of this process's set (worker threads started from here inherit the mask): no migration across the whole host
+        aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(aff)[:threads]))
+    except (AttributeError, OSError):
+        aff = None
     torch.set_num_threads(threads)
-    _cpu_attn_time(B, H, S, 1)
-    med, best = _cpu_attn_time(B, H, S, reps)
+    _cpu_attn_time(B, H, S, 3)  # untimed warm-up: allocator, thread-pool start-up, page faults of the 50 MB score tensors
+    med, best = _cpu_attn_time(B, H, S, max(reps, 9))
+    reps = max(reps, 9)
     out = {"value": 3.5 * fwd_flops(S) / med / 1e12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
-           "host_cpus": os.cpu_count(), "kind": "port", "value_min_time": 3.5 * fwd_flops(S) / best / 1e12,
+           "host_cpus": os.cpu_count(), "kind": "port", "value_is": "median of the timed runs (a shared host: the minimum is beside it, DESIGN 0 quotes both)",
+           "value_min_time": 3.5 * fwd_flops(S) / best / 1e12, "median_over_min": round(med / best, 2),
            "sample": f"eager fp32 attention fwd+bwd (oracle.attn_ref + autograd), full (4,12,{S},64) batch with dense "
-                     f"(1,12,{S},{S}) bias, {threads} threads (torch.set_num_threads), median of {reps} runs after one warm-up: {med*1e3:.1f} ms (min {best*1e3:.1f} ms)"}
+                     f"(1,12,{S},{S}) bias, {threads} threads (torch.set_num_threads) on {threads} CPUs of the process's affinity set, median of {reps} runs after three warm-ups: {med*1e3:.1f} ms (min {best*1e3:.1f} ms)"}
     try:
         import oracle
         q1, k1, v1 = (torch.randn(2, 8, 128, D) for _ in range(3))
@@ -499,6 +540,11 @@ def cpu_baseline(S=512, reps=5):
                              "sample": f"(1,2,8192,64) slice of cfg3, one run, {t3:.2f} s; full cfg3 = x24 = {24*t3:.0f} s at this rate"}
     except Exception as e:  # noqa: BLE001  (host memory)
         out["cfg3_slice"] = {"error": str(e)[:100]}
+    if aff is not None:
+        try:
+            os.sched_setaffinity(0, aff)
+        except OSError:
+            pass
     return out
 
 
@@ -822,6 +868,7 @@ def main():
                 out["eager_autograd"] = eager_autograd(S, device)
                 out["rowwise"] = rowwise_bench(device)
                 out["reference_shape"] = reference_shape_bench(device)
+                out["dense_by_seq"] = dense_by_seq_bench(device)
                 out["n3_fusions"] = n3_bench(device)
                 out["cpu_baseline"] = cpu_baseline(512)
         print(json.dumps(out), flush=True)

@@ -244,12 +244,13 @@ def kernel_ready(t):
     return (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % 8 == 0 for s in t.stride()[:-1]))
 
 
-def describe(B, H, M, N, D=64, dtype=FAT5_BF16, causal=False, bias_mode=0, radius=0, need_dbias=False, variant=0):
+def describe(B, H, M, N, D=64, dtype=FAT5_BF16, causal=False, bias_mode=0, radius=0, need_dbias=False, variant=0, sm_scale=None):
     """Which kernel bodies the library would run for a problem -- {"fwd": "64row-ksplit", "dq": "32row", "dkdv": "64key-mixed:4",
     "fused": "0", "dbias": "direct"} -- from shapes alone (fat5_attn_describe: host-only, works without a GPU)."""
     p = AttnParams()
     p.B, p.H, p.M, p.N, p.D = B, H, M, N, D
     p.dtype, p.causal, p.bias_mode, p.rpe_radius, p.variant = dtype, int(causal), bias_mode, radius, variant
+    p.sm_scale = float(D) ** -0.5 if sm_scale is None else float(sm_scale)  # (a zero scale keeps the dense bias off the matrix pipe)
     if bias_mode == BIAS_DENSE:
         p.bias = 16  # (never followed)
         p.bias_stride[0], p.bias_stride[1], p.bias_stride[2] = 0, M * N, N  # the model's (1, H, M, N) bias, shared by the batch

@@ -60,13 +60,30 @@ struct BwdLayout {
   int nw_q, nw_kv;
 };
 
+// Compute units of the device the dispatch rules were measured on (MI355X: 256 in 8 XCDs) and of the device in use: the rules' workgroup-count
+// thresholds are rounds of the chip, so they scale with its size.  Read once per process from hipDeviceProp (no hard-coded 256 / 32);
+// without a device -- the host-only dispatch tests -- the reference chip is assumed.
+static int chip_cus() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) {
+      (void)hipGetLastError();
+      return 256;
+    }
+    return pr.multiProcessorCount;
+  }();
+  return n;
+}
+static inline long cu_scaled(long wgs_at_256) { return wgs_at_256 * chip_cus() / 256; }  // a workgroup-count threshold measured on 256 CUs
+
 // head_dim 16 runs the D = 32 instantiations with AttnArgs::dvalid = 16: columns 16..31 are read as zeros (out-of-range DMA pieces, masked
 // fragment loads) and never written -- no padded copies of q / k / v / do in HBM (the reference's kernels take 16 natively, flash_attention_v2_bias.py:233-234)
 static inline int effD(const fat5_attn_params* p) { return p->D == 16 ? 32 : p->D; }
 
 int pick_nw(long ctas_at_nw4) {
   // measured at S = 512: the 4-wave tile wins down to ~0.75 workgroups per CU
-  return ctas_at_nw4 < 160 ? 2 : 4;
+  return ctas_at_nw4 < cu_scaled(160) ? 2 : 4;
 }
 
 int check_common(const fat5_attn_params* p) {
@@ -167,7 +184,7 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   // short sequences: with 4-wave tiles the grid is smaller than the chip and every wave walks all keys alone -> two
   // waves per 32 query rows, each taking one 32-key block of every tile (attn_fwd_split_kernel)
   const long ctas4 = bh * ((p->M + 127) / 128);
-  if (!(p->variant & FAT5_V_NO_SPLIT) && ctas4 <= 256 && bh * ((p->M + 63) / 64) >= 96 && p->N >= 128) {
+  if (!(p->variant & FAT5_V_NO_SPLIT) && ctas4 <= chip_cus() && bh * ((p->M + 63) / 64) >= cu_scaled(96) && p->N >= 128) {
     nw = -4;
     c.n_mblk = (p->M + 63) / 64;
   }
@@ -181,7 +198,7 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   const bool dense64 = p->D == 64 && p->bias_mode == FAT5_BIAS_DENSE && p->dtype == FAT5_BF16 && !p->cu_seqlens_q && f64_env != 0 &&
                        ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) && (p->bias_stride[1] % 8 == 0) &&
                        (p->bias_stride[2] % 8 == 0) && smem_fwd64_d64(0, FAT5_BIAS_DENSE) <= 160 * 1024 &&
-                       (f64_env == 1 || (waves64 >= 3072 && p->N >= 4096 && !p->causal));  // (measured, us, 64-row vs 32-row body: (4,12,8192) 1217 vs 1371; (4,12,2048) 102 vs 95; (16,12,1024) causal 95 vs 77)
+                       (f64_env == 1 || (!p->causal && ((waves64 >= cu_scaled(3072) && p->N >= 4096) || (waves64 >= cu_scaled(6144) && p->N >= 2048))));  // (round 5: (16,12,2048) 324 vs 360 us)  // (measured, us, 64-row vs 32-row body: (4,12,8192) 1217 vs 1371; (4,12,2048) 102 vs 95; (16,12,1024) causal 95 vs 77)
   if (dense64) {
     c.fwd64 = true;
     c.ksplit = false;
@@ -192,7 +209,7 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
       // (fp16, round 4: the pipelined sweep with the first tile's row maxima as reference point -- (4,12,8192) 739 us against 913 for the
       //  32-row body, (4,12,2048) 64.3 vs 69.4)
-      (f64_env == 1 || (waves64 >= (p->dtype == FAT5_BF16 ? kFwd64MinWaves : 1536) &&
+      (f64_env == 1 || (waves64 >= cu_scaled(p->dtype == FAT5_BF16 ? kFwd64MinWaves : 1536) &&
                         // (512 keys are 8 tiles: too few for the pipeline's prologue to pay when half of them sit on the causal diagonal --
                         //  tools/dispatch_audit.py: (4,12,512) causal 10.0 vs 11.2 us, (8,12,512) causal 15.7 vs 17.5 -- or in the 1.5-waves-per-SIMD
                         //  range where the 64-row waves fill the chip unevenly: (16,12,512) 22.2 vs 24.8; (16,12,1024x512) and (16,12,2048x512),
@@ -215,8 +232,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     // (round-4 audit: also between 512 and 1024 waves -- (4,12,1024) T5 bias 20.7 vs 22.6 us, none 19.4 vs 19.9; (8,12,512) 14.3 vs 16.1, 12.9 vs 13.5)
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && (waves64 < 2048 ||
-                                                        (p->causal && waves64 <= 8192 && p->N < 2 * p->M)));
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && (waves64 < cu_scaled(2048) ||
+                                                        (p->causal && waves64 <= cu_scaled(8192) && p->N < 2 * p->M)));
     // (round-4 audit: without bias as well -- (16,12,1024) causal 51.1 split vs 55.1 us, (16,12,2048) 138.7 vs 151.5: the split form's Q / O now travel as whole rows)
     // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
@@ -233,7 +250,7 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // kind, but the half-length waves -- one block per tile barrier -- take as long as the full-length ones beside them (86 k vs 77 k cycles).
     const int mx_env = vsel(p->variant, FAT5_V_FWD64_MIX_ON, FAT5_V_FWD64_MIX_OFF);
     if (mx_env != 0 && bh % 8 == 0 && p->M >= 384 && !p->causal && ks_env == -1 &&
-        (mx_env == 1 || (waves64 * 10 >= 6 * 256 * 9 && waves64 * 10 <= 6 * 256 * 11 && p->N >= 1024))) {
+        (mx_env == 1 || (waves64 * 10 >= 6L * chip_cus() * 9 && waves64 * 10 <= 6L * chip_cus() * 11 && p->N >= 1024))) {
       const long npx = bh / 8;                                   // pairs per XCD
       long na_x = (waves64 + 24) / 48;                           // 256-row workgroups per XCD (waves64 / 6 in total)
       na_x = std::max(na_x, npx);                                // (at least one per pair)
@@ -301,7 +318,8 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const long wg256 = bh * ((p->N + 255) / 256);
   const int kvh_env = vsel(p->variant, FAT5_V_KV64_HALF_ON, FAT5_V_KV64_HALF_OFF);
   const int mix_env = vsel(p->variant, FAT5_V_KV64_MIX_ON, FAT5_V_KV64_MIX_OFF);
-  const double r_full = (double)((wg256 + 255) / 256), r_half = 0.5 * 1.04 * (double)((2 * wg256 + 255) / 256);
+  const long ncu = chip_cus();
+  const double r_full = (double)((wg256 + ncu - 1) / ncu), r_half = 0.5 * 1.04 * (double)((2 * wg256 + ncu - 1) / ncu);
   // dense bias (round 5): the 256-key form of the 64-key body with the step's bias tile as one more LDS image per wave (attn_bwd64.h, DENSE): bf16,
   // bias rows 16-byte aligned (LDS-DMA)
   const bool dense = p->bias_mode == FAT5_BIAS_DENSE;
@@ -325,7 +343,8 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // these start slots in increasing order, so the makespan is (Hn-th smallest start) + rh -- O(Hn / 32) steps per candidate.
     auto makespan = [&](int pf) {
       const long F = (long)pf * ntf, Hn = (long)(per - pf) * nth;
-      const long a = F / 32, rem = F % 32, n_lo = 32 - rem, n_hi = rem;
+      const long cx = chip_cus() / 8 > 0 ? chip_cus() / 8 : 1;  // CUs of one XCD
+      const long a = F / cx, rem = F % cx, n_lo = cx - rem, n_hi = rem;
       const double base = (double)(a + (rem ? 1 : 0));
       if (Hn == 0) return base;
       long jl = 0, jh = 0, count = 0;
@@ -365,15 +384,17 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   // (round 4: with the T5 bias and the diagonal inside the band the table carries the mask and the diagonal steps are pipelined band steps: (16,12,2048) causal
   //  64-key mixed 292 vs 326 us, (8,12,2048) 154 vs 169 -> from 2048 keys on)
   const bool ctab_kv = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
-  const bool kv64_causal_ok = !p->causal || p->N >= (ctab_kv ? 2048 : 4096);
+  // (round 5: without bias the mask rides in the score MFMAs' C operand -- (4,12,2048) causal 73.7 (half-length) vs 82.7 us, (16,12,2048) 261 vs 269;
+  //  (16,12,1024) 102 vs 95 -> from 2048 keys on as well; dense: see dense_rule)
+  const bool kv64_causal_ok = !p->causal || p->N >= ((ctab_kv || p->bias_mode == FAT5_BIAS_NONE) ? 2048 : 4096);
   // (dense, round 5 -- bias on the matrix pipe, causal mask in the C operand; 64-key vs 32-key body, us: (4,12,2048) 137 vs 164, (4,12,8192) 1700 vs 2208;
   //  causal (16,12,512) 52.5 vs 54.1, (16,12,1024) 121 vs 133, (16,12,2048) 344 vs 392 -> from 192 workgroups on)
-  const bool dense_rule = dense && wg256 >= 192;
+  const bool dense_rule = dense && wg256 >= cu_scaled(192) && (int64_t)bh * p->M * p->N >= (int64_t(1) << 25);
   L.kv64 = p->D == 64 && (!dense || dense_kv_ok) && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || dense_rule || ((wg256 >= (fills ? 320 : 512) ||
+           (b64_env == 1 || dense_rule || ((wg256 >= cu_scaled(fills ? 320 : 512) ||
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
                               //  (4,12,8192x1024) 190 vs 234; with the T5 bias 117 vs 146 and 213 vs 274)
-                              (wg256 >= 160 && p->M >= 4096 && !p->causal)) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
+                              (wg256 >= cu_scaled(160) && p->M >= 4096 && !p->causal)) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;
   if (L.kv64 && L.kv64_mix_pf > 0) {
     L.kv64_half = false;
     L.nw_kv = 3;  // (launch_bwd_kv64: 3 selects the mixed launch)
@@ -391,8 +412,8 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   //  32-row body: non-causal (16,12,1024) 92 vs 85 us, (4,12,8192) 1115 vs ~1250; causal (4,12,4096) 215 vs 189, (16,12,2048) 262 vs 202,
   //  (4,12,8192) 661-701 vs 623-653 -> non-causal from 2048 keys on, causal never below 16384 rows)
   L.q64 = p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && q64_env != 0 &&
-          (q64_env == 1 || ((bh * ((p->M + 255) / 256) >= 512 || (bh * ((p->M + 255) / 256) >= 160 && p->N >= 8192)) &&  // ((4,12,1024x8192): 153 vs 166 us)
-                            p->N >= ((p->bias_mode == FAT5_BIAS_RPE1D && bh * ((p->M + 255) / 256) < 1024) ? 4096 : 2048) && (!p->causal || p->M >= 16384)));  // ((16,12,2048) T5 bias, 1536 workgroups: 309 vs 325 us)  // (T5 bias, band steps in the pipelined iteration since round 4:
+          (q64_env == 1 || ((bh * ((p->M + 255) / 256) >= cu_scaled(512) || (bh * ((p->M + 255) / 256) >= cu_scaled(160) && p->N >= 8192)) &&  // ((4,12,1024x8192): 153 vs 166 us)
+                            p->N >= ((p->bias_mode == FAT5_BIAS_RPE1D && bh * ((p->M + 255) / 256) < cu_scaled(1024)) ? 4096 : 2048) && (!p->causal || p->M >= 16384)));  // ((16,12,2048) T5 bias, 1536 workgroups: 309 vs 325 us)  // (T5 bias, band steps in the pipelined iteration since round 4:
                                                               //  (4,12,4096) 284-295 vs 298 us, (4,12,8192) 1089 vs 1107; (4,12,2048), 1.5 rounds: 97 vs 83 -> from 4096 keys on)
   // Both 64-wide bodies in ONE launch (attn_bwd_fused64_kernel; the dK/dV half forms its row statistics itself): one workgroup per CU
   // either way, so the two grids fill each other's empty last rounds -- and at cfg2 (96 + 96 workgroups) run side by side.
@@ -409,7 +430,7 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     //   (1,12,4096) 214 vs 202 (the one miss inside the rule) -> up to 1152 workgroups (4.5 rounds) on roughly square problems;
     //   causal (4,12,512) 39.0 vs 33.7, (4,12,1024) 83.6 vs 61.7: the diagonal steps of the 64-wide bodies are unpipelined -> never.
     const long wq = bh * ((p->M + 255) / 256), tot = wg256 + wq;
-    constexpr long FUSED64_MAX_WG = 1152;
+    const long FUSED64_MAX_WG = cu_scaled(1152);
     // (a call that forces or forbids one of the 64-wide bodies / launch forms keeps that choice)
     const bool squarish = 2 * (p->M < p->N ? p->M : p->N) >= (p->M < p->N ? p->N : p->M);
     // causal with the T5 bias and the diagonal inside the band (-R <= N - M < R): the bias table in LDS carries the mask (-inf above the diagonal), the
@@ -417,9 +438,12 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // (4,12,1024) 64.6 vs 60.8, (4,12,2048) 156.0 vs 174.5, (4,12,4096) 433.7 vs 428.1, (16,12,512) 76.5 vs 94.2, (16,12,1024) 208.0 vs 210.1
     const bool ctab = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
     // (round-4 audit: (2,12,2048) causal 80.9 vs 92.9 us -- the 384-workgroup exception holds at <= 1024 keys only; (8,12,2048) causal, 1536 workgroups: 269.8 vs 283.4)
-    const long max_wg = (ctab && p->N <= 2048) ? 1536 : FUSED64_MAX_WG;
-    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= 256 || tot >= 512 || p->N >= 2048));
-    const bool rule = causal_ok && (tot <= 384 || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    const long max_wg = (ctab && p->N <= 2048) ? cu_scaled(1536) : FUSED64_MAX_WG;
+    // (round 5, no bias: the dK/dV half's diagonal steps are pipelined (mask in the C operand) -- (16,12,512) causal 65.7 vs 72.1 us, (4,12,512) 21.7 vs 22.6;
+    //  (4,12,1024) 45.9 either way -> up to 512 keys)
+    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= chip_cus() || tot >= cu_scaled(512) || p->N >= 2048)) ||
+                           (p->bias_mode == FAT5_BIAS_NONE && squarish && p->N <= 512);
+    const bool rule = causal_ok && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }
   if (L.fused64) {
@@ -453,7 +477,11 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
                        (int64_t)p->M * p->N * (ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
                        ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
     // (a call that asks for one of the older dbias paths by variant bit keeps it)
-    if (legal && qdb_env != 0 && (qdb_env == 1 || (p->B >= 2 && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
+    // (measured, whole backward, us, against the round-4 paths -- profiles/r05_dispatch_audit_none_dense_H12.log: (4,12,512) 49.4 vs 45.3, causal 55.1 vs 42.2: the one
+    //  32-wide launch + staged dS stays ahead on the smallest problems; (4,12,1024) 81.8 vs 166.9, (16,12,512) 110.8 vs 118.9, (4,12,2048) 284 vs 436, (16,12,1024)
+    //  causal 285 vs 330, (16,12,4096) 5014 vs 9162 -> from 2^25 scores per call on)
+    const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 25);
+    if (legal && qdb_env != 0 && (qdb_env == 1 || (qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
       L.qdb64 = true;
       L.qdb_groups = ngrp;
       L.q64 = false;
@@ -527,7 +555,7 @@ size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p) {
 
 static bool bwd_fusable(const BwdLayout& L, long grid_q, long grid_kv, int D, int variant) {
   if (D > 64) return false;  // (the D = 128 dK/dV body runs one wave per SIMD: no room for a co-resident dQ workgroup)
-  const long fuse_max = 4L * 256;  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
+  const long fuse_max = 4L * chip_cus();  // measured: S=1024 (768 workgroups) +4 %, S=2048 (1536) -3 %
   return !(variant & FAT5_V_NO_FUSE) && !L.kv64 && !L.q64 && !L.qdb64 && L.nw_q == 4 && L.nw_kv == 4 && grid_q + grid_kv <= fuse_max;
 }
 
@@ -727,7 +755,7 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     // key tiles of a strip are independent: split them over workgroups until the grid covers the chip about twice
     const long strips = (long)p->H * ab.n_mblk, ntile = (p->N + 63) / 64;
     long nsplit = 1;
-    while (strips * nsplit < 512 && nsplit * 2 <= ntile) nsplit *= 2;
+    while (strips * nsplit < cu_scaled(512) && nsplit * 2 <= ntile) nsplit *= 2;
     ab.n_nblk = (int)nsplit;
     const long grid = strips * nsplit;
     typedef hipError_t (*dbias_fn)(const AttnArgs&, int, void*, float*, int, hipStream_t);

@@ -297,7 +297,8 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
         (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="32row")),                          # (384 workgroups: the measured exception)
-        (dict(B=4, H=12, M=512, N=512, causal=True), dict(dq="32row", dkdv="32key", fused="1")),          # causal without bias: the 32-wide bodies side by side
+        (dict(B=4, H=12, M=512, N=512, causal=True), dict(dq="64row", dkdv="64key", fused="1")),          # causal without bias, up to 512 keys (round 5): the mask rides in the dK/dV half's score MFMAs -- the one-launch 64-wide form (21.7 vs 22.6 us; (16,12,512): 65.7 vs 72.1)
+        (dict(B=4, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),                   # ... not beyond (45.9 us either way)
         (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-mixed", dq="64row", dkdv="64key", fused="1")),   # 1.5 64-row waves per SIMD: 256-row and key-split workgroups in one launch
         (dict(B=4, H=12, M=2048, N=2048, variant=L.V_FWD64_MIX_OFF, **rpe), dict(fwd="64row-ksplit")),
         (dict(B=4, H=12, M=3072, N=3072, **rpe), dict(dq="64row", dkdv="64key", fused="1")),     # (1152 workgroups: the last size that takes the one-launch form)
@@ -310,7 +311,8 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="64row", dkdv="64key")),            # T5 bias: band steps pipelined since round 4
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
-        (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="32key")),
+        (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:20")),         # (round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
+        (dict(B=4, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:4")),
         (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
         (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
@@ -326,9 +328,16 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=1024, N=8192), dict(dq="64row")),
         # dense bias: the 64-row forward (two-tile bias ring, one wave per SIMD) from 4096 keys on (round 4), the 32-wide backward bodies;
         # the batch-shared gradient is formed in-kernel once the staging tensor would be large
-        (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="64row", dq="32row", dkdv="32key", dbias="inkernel")),
-        (dict(B=4, H=12, M=2048, N=2048, **dense), dict(fwd="32row")),
-        (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dbias="staged")),
+        # round 5: dQ + the batch-reduced dbias in one kernel (four batch elements per workgroup), the 64-key dK/dV body with the bias on the matrix pipe -- from 2^25
+        # scores per call on (profiles/r05_dispatch_audit_none_dense_H12.log); fp32 slabs + ordered reduction beyond four batch elements
+        (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="64row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel")),
+        (dict(B=4, H=12, M=2048, N=2048, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel")),
+        (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel+partials")),
+        (dict(B=16, H=12, M=2048, N=2048, **dense), dict(fwd="64row")),                                  # (324 vs 360 us)
+        (dict(B=4, H=12, M=512, N=512, **dense), dict(dq="32row", dkdv="32key", fused="1", dbias="staged")),   # the smallest problems: one 32-wide launch + staged dS (45.3 vs 49.4 us)
+        (dict(B=1, H=12, M=2048, N=2048, **dense), dict(dq="32row", dbias="direct")),                    # nothing to reduce over
+        (dict(B=4, H=12, M=1024, N=1024, sm_scale=0.0, **dense), dict(dq="32row", dkdv="32key")),        # a zero scale: 1 / scale does not exist -- the per-element bodies
+        (dict(B=4, H=12, M=2048, N=2048, variant=L.V_DBIAS_STAGED, **dense), dict(dq="32row", dbias="staged")),  # the older paths stay selectable
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="32row", dq="32row", dkdv="32key")),
         # forced per call

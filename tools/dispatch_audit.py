@@ -21,6 +21,7 @@ a = ap.parse_args()
 FWD = {"default": 0, "32row": L.V_FWD64_OFF, "64row": L.V_FWD64_ON | L.V_FWD64_KSPLIT_OFF, "64row-ksplit": L.V_FWD64_ON | L.V_FWD64_KSPLIT_ON | L.V_FWD64_MIX_OFF,
        "64row-mixed": L.V_FWD64_ON | L.V_FWD64_MIX_ON}
 DQ = {"default": 0, "32row": L.V_Q64_OFF, "64row": L.V_Q64_ON}
+DQ_DENSE = {"default": 0, "32row+staged/inkernel": L.V_QDB64_OFF, "64row-batch4": L.V_QDB64_ON}  # dense (1,H,M,N) bias: dQ + dbias (+ reduction) as one stage
 BWD = {"default": 0, "separate": L.V_FUSED64_OFF, "fused64": L.V_FUSED64_ON}  # (round 4: dQ + dK/dV of one call, the library's choice against the one-launch 64-wide form forced / forbidden)
 KV = {"default": 0, "32key": L.V_KV64_OFF, "64key": L.V_KV64_ON | L.V_KV64_HALF_OFF | L.V_KV64_MIX_OFF, "64key-half": L.V_KV64_ON | L.V_KV64_HALF_ON,
       "64key-mixed": L.V_KV64_ON | L.V_KV64_MIX_ON}
@@ -56,12 +57,17 @@ for bh in a.bh.split(","):
                 q, k, v, _, do = make_inputs(B, H, M, S, 64, torch.bfloat16, None, seed=1, strided=True)
                 table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
                 kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128) if mode == "rpe" else {}
+                if mode == "dense":
+                    kw = dict(bias=pe.compute_bias(table, M, S).to(torch.bfloat16).contiguous())
                 plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=0.125, **kw)
                 plan.forward(); plan.backward(); torch.cuda.synchronize()
                 it = max(2, min(20, int(2e10 / (B * H * float(M) * S))))
                 line = f"({B:2d},{H},{M:5d}x{S:5d}) {'causal' if causal else 'full  '} {mode:4s}"
                 fused = plan.bwd_launches() == 1  # (short problems: dQ and dK/dV share ONE launch -- the stage timings below are not the real path)
-                for stage, table_, fn in (("fwd", FWD, plan.forward), ("dq", DQ, lambda: plan.backward(1)), ("dkdv", KV, lambda: plan.backward(2))):
+                dense = mode == "dense"
+                kvt = {k_: v_ for k_, v_ in KV.items() if not (dense and k_ in ("64key-half", "64key-mixed"))}
+                for stage, table_, fn in (("fwd", FWD if not dense else {k_: v_ for k_, v_ in FWD.items() if k_ in ("default", "32row", "64row")}, plan.forward),
+                                          ("dq", DQ_DENSE if dense else DQ, (lambda: plan.backward(5)) if dense else (lambda: plan.backward(1))), ("dkdv", kvt, lambda: plan.backward(2))):
                     if fused and stage != "fwd":
                         line += f" | {stage}: (fused launch)"
                         continue
@@ -76,9 +82,9 @@ for bh in a.bh.split(","):
                     if bad:
                         flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
                 res = {}
-                for name, bits in BWD.items():
+                for name, bits in (BWD.items() if not dense else {"default": 0, "round4": L.V_QDB64_OFF | L.V_KV64_OFF}.items()):
                     plan.set_variant(bits)
-                    res[name] = gpu_time(lambda: plan.backward(3), it)
+                    res[name] = gpu_time(lambda: plan.backward(7 if dense else 3), it)
                 plan.set_variant(0)
                 best = min((t, n) for n, t in res.items() if n != "default")
                 bad = res["default"] > 1.05 * best[0]
