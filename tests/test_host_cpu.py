@@ -338,6 +338,12 @@ def test_dispatch_rules_are_pinned():
         (dict(B=1, H=12, M=2048, N=2048, **dense), dict(dq="32row", dbias="direct")),                    # nothing to reduce over
         (dict(B=4, H=12, M=1024, N=1024, sm_scale=0.0, **dense), dict(dq="32row", dkdv="32key")),        # a zero scale: 1 / scale does not exist -- the per-element bodies
         (dict(B=4, H=12, M=2048, N=2048, variant=L.V_DBIAS_STAGED, **dense), dict(dq="32row", dbias="staged")),  # the older paths stay selectable
+        # off the H = 12 line (round 5: profiles/r05_dispatch_audit_H8_16_32.log -- T5-small's 8 heads, 16 and 32 heads, a (batch, head) count that is no multiple of 8; 1 miss of 36, fixed)
+        (dict(B=4, H=8, M=512, N=512, **rpe), dict(fwd="32row-split", dq="64row", dkdv="64key", fused="1")),
+        (dict(B=4, H=16, M=2048, N=2048, **rpe), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),
+        (dict(B=3, H=5, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),         # an under-filled chip (240 workgroups), causal without bias: the one-launch form (56.5 vs 70.9 us)
+        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
+        (dict(B=2, H=8, M=128, N=128), dict(fwd="32row", fused="1")),                                     # config 1's shape
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="32row", dq="32row", dkdv="32key")),
         # forced per call
