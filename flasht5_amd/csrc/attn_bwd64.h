@@ -290,22 +290,29 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     bias_lds = __builtin_amdgcn_readfirstlane(lds0 + ring0 + (uint32_t)(Cfg::BIASO + wp * IMG));
     bstride_b = (uint32_t)a.bs[2] * 2u;
   }
+  // The LDS-DMA pieces of one step, in request order (the counted waits below rely on it): [DENSE: 4 bias pieces] PER x (Q, dO [, O]) | statistics.
+  // The pipelined iterations issue them ONE PER MFMA GAP (round 5): the pieces of the four waves, requested together right behind the step's barrier,
+  // queue up in front of the CU's one texture-address unit (~16 cycles each) and every in-order wave waits for its last one.
+  constexpr int NPIECE = (DENSE ? 4 : 0) + Dma::PER * (SELF ? 3 : 2) + 1;
+  auto dma_piece = [&](const uint32_t mt, const uint32_t slot_off, const int k) {
+    constexpr int NB = DENSE ? 4 : 0, NI = SELF ? 3 : 2;
+    if (k < NB) {
+      if constexpr (DENSE) dma16_asm(brs, bias_lds + slot_off + (uint32_t)(k * 1024), bst.voff[k % 2], mt * 32u * bstride_b + (uint32_t)kw0 * 2u + bst.piece_step * (uint32_t)(k / 2));
+    } else if (k < NB + Dma::PER * NI) {
+      const int i = (k - NB) / NI, which = (k - NB) % NI;
+      if (which == 0) dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
+      else if (which == 1) dma16_asm(dors, wave_lds + slot_off + (uint32_t)(IMG + i * 2048), dost.voff[0], mt * 32u * dostride_b + dost.piece_step * i);
+      else dma16_asm(ors, wave_lds + slot_off + (uint32_t)(2 * IMG + i * 2048), ost.voff[0], mt * 32u * ostride_b + ost.piece_step * i);
+    } else {
+      if constexpr (SELF) dma16_asm(strs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + ring0)) + slot_off + (uint32_t)(3 * IMG), svoff, mt * 128u);  // (every wave the same 128 bytes into the shared piece)
+      else dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
+    }
+  };
   auto dma_step = [&](int j, uint32_t slot_off_) {
     const uint32_t mt = (uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j);
     const uint32_t slot_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_off_);  // (provably wave-uniform: it feeds M0)
-    if constexpr (DENSE) {
 #pragma unroll
-      for (int i = 0; i < BDma::PER; ++i)
-        dma16_asm(brs, bias_lds + slot_off + (uint32_t)(i * 1024), bst.voff[i % 2], mt * 32u * bstride_b + (uint32_t)kw0 * 2u + bst.piece_step * (uint32_t)(i / 2));
-    }
-#pragma unroll
-    for (int i = 0; i < Dma::PER; ++i) {
-      dma16_asm(qrs, wave_lds + slot_off + (uint32_t)(i * 2048), qst.voff[0], mt * 32u * qstride_b + qst.piece_step * i);
-      dma16_asm(dors, wave_lds + slot_off + (uint32_t)(IMG + i * 2048), dost.voff[0], mt * 32u * dostride_b + dost.piece_step * i);
-      if constexpr (SELF) dma16_asm(ors, wave_lds + slot_off + (uint32_t)(2 * IMG + i * 2048), ost.voff[0], mt * 32u * ostride_b + ost.piece_step * i);
-    }
-    if constexpr (SELF) dma16_asm(strs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + ring0)) + slot_off + (uint32_t)(3 * IMG), svoff, mt * 128u);  // (every wave the same 128 bytes into the shared piece)
-    else dma16_asm(strs, wave_lds + slot_off + (uint32_t)(2 * IMG), svoff, mt * 256u);
+    for (int k = 0; k < NPIECE; ++k) dma_piece(mt, slot_off, k);
   };
   // SELF: this wave's 8 rows of the step in the slot at `so` -> -L/scale (in place of the raw L) and -delta.  Eight lanes per row, each
   // one 16-byte piece of the O and dO images (same slot of both: the images share the swizzle), a butterfly over the eight.
@@ -339,10 +346,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   };
   auto produce_stats = [&](const int j, const uint32_t so) { stats_write(stats_value(stats_read(so), j), so); };
   // E(j): step j+1 (SELF: j+2) has landed and is visible to every wave; every wave is done with step j-1, whose slot takes step j+3
-  auto sync_step = [&](int j, uint32_t slot3_off) {
-    if ((!SELF || (FAT5_ABL & 128)) && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SELF ? 3 : 2) * Dma::PER + 1 + (DENSE ? 4 : 0)) : "memory");
+  auto sync_wait = [&](int j) {
+    if ((!SELF || (FAT5_ABL & 128)) && j + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
     else wait_dma_all();
     __syncthreads();
+  };
+  auto sync_step = [&](int j, uint32_t slot3_off) {
+    sync_wait(j);
     if (j + 3 < nsteps) dma_step(j + 3, slot3_off);
   };
 
@@ -720,8 +730,11 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         }
       }
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
-      // ---- barrier + DMA ----
-      if constexpr (g == 12) sync_step(j, o_prev);
+      // ---- barrier + DMA (step j+3 into the slot of step j-1, one piece per gap) ----
+      if constexpr (g == 12) sync_wait(j);
+      if constexpr (g > 12 && g - 13 < NPIECE) {
+        if (j + 3 < nsteps) dma_piece((uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j + 3), o_prev, g - 13);
+      }
       // ---- LDS ----
       if constexpr (g < 12) {
         constexpr int pp = (g >> 2) + 1, t2 = pp >> 1, db = pp & 1, wh = (g >> 1) & 1, half = g & 1;
@@ -1224,10 +1237,13 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     dma16_asm(vrs, dst + (uint32_t)IMG, vst.voff[0], tt * 32u * vstride_b);
   };
   // E(t): step t+1 has landed and is visible to every wave; every wave is done with step t-1, whose slot takes step t+3
-  auto sync_step = [&](int t, uint32_t slot3_off) {
+  auto sync_wait = [&](int t) {
     if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else wait_dma_all();
     __syncthreads();
+  };
+  auto sync_step = [&](int t, uint32_t slot3_off) {
+    sync_wait(t);
     if (t + 3 < nt) dma_step(t + 3, slot3_off);
   };
 #pragma unroll
@@ -1448,8 +1464,16 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         else DPn[qb] = mfma32<BF16>(vf[kk], dof[qb][kk], DPn[qb]);
       }
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap: without this it may sink below the gap's VALU work and pair up with the next one)
-      // ---- barrier + DMA ----
-      if constexpr (g == 4) sync_step(t, o_prev);
+      // ---- barrier + DMA (the K and the V piece of step i+3 in gaps of their own: see the dK/dV body) ----
+      if constexpr (g == 4) sync_wait(t);
+      if constexpr (g == 5 || g == 6) {
+        if (t + 3 < nt) {
+          const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane(t + 3);
+          const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + o_prev));
+          if constexpr (g == 5) dma16_asm(krs, dst, kst.voff[0], tt * 32u * kstride_b);
+          else dma16_asm(vrs, dst + (uint32_t)IMG, vst.voff[0], tt * 32u * vstride_b);
+        }
+      }
       // ---- LDS ----
       if constexpr (g < 4) {
         constexpr int db = g >> 1, half = g & 1;

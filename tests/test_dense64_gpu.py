@@ -66,9 +66,9 @@ def test_qdb64_matches_oracle_and_the_staged_path(B, H, M, N, causal):
 
 def test_qdb64_deterministic_and_default_dispatch():
     from flasht5_amd import _lib
-    q, k, v, b, do = make_inputs(4, 4, 512, 512, 64, torch.bfloat16, "1h", seed=9, strided=True)
+    q, k, v, b, do = make_inputs(4, 12, 1024, 1024, 64, torch.bfloat16, "1h", seed=9, strided=True)
     p0, a = _plan(q, k, v, do, b, False, 0.125, 0)
-    assert p0.describe()["dq"] == "64row-batch4"  # the library's own choice for the model's case
+    assert p0.describe()["dq"] == "64row-batch4" and p0.describe()["dkdv"] == "64key"  # the library's own choice for the model's case (from 2^25 scores per call on)
     _, c = _plan(q, k, v, do, b, False, 0.125, 0)
     for x, y in zip(a, c):
         assert torch.equal(x, y)
