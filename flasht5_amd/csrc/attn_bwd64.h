@@ -1003,10 +1003,18 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         }
   }
   const float scale = a.scale;
-  if (stg) {
+  // DENSE (round 5): the ring with the bias images leaves no room for staging images behind it -- the outputs leave through the (drained) ring
+  // itself, behind one more barrier (another wave's last product reads may still be in flight)
+  const bool stg_out = stg || DENSE;
+  if (DENSE && !stg) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (stg_out) {
     // dK | dV through the images of this wave's keys (their fragments have long been read; HALF: the other pair returned above and its
     // last LDS access is behind the hand-over's barrier): 8-byte pieces into the swizzled row-major images, out again as whole rows
-    char* img = smem + Cfg::RINGB + wp * 2 * Cfg::STG_T;
+    char* img = smem + (stg ? Cfg::RINGB : 0) + wp * 2 * Cfg::STG_T;
+    static_assert(!DENSE || Cfg::NW * 2 * Cfg::STG_T <= Cfg::RING, "the output images fit the ring");
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int row = 32 * kb + lq;

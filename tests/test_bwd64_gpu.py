@@ -75,7 +75,10 @@ def _table_truth(q, k, v, bias, o, L, do, scale, causal, table, M, N, bidir, md)
     (1, 2, 1000, 1100, True, "rpe", 128),     # ... 0 < P = N - M < R: the cut at a non-zero table offset, ragged rows / keys
     (1, 2, 1100, 1000, True, "rpe", 128),     # ... -R <= P < 0: dead rows (L = -inf) meet -inf table entries
     (1, 2, 2048, 1952, True, "rpe", 128),     # ... P = -96, whole steps
-    (1, 2, 2048, 2048, True, "none", 128),
+    (1, 2, 2048, 2048, True, "none", 128),    # causal without bias (round 5): the mask rides in the score MFMAs' C operand, diagonal steps pipelined
+    (1, 2, 1000, 1100, True, "none", 128),    # ... bottom-right with N - M = 100, ragged rows / keys (a key-tail wave stays general)
+    (1, 2, 300, 2500, True, "none", 128),     # ... M << N
+    (1, 2, 1100, 1000, True, "none", 128),    # ... N < M: dead rows meet masked scores
     (1, 2, 1000, 1100, False, "rpe", 128),    # ragged: last step padded (rows past M), key tail workgroup (all general)
     (1, 2, 300, 2500, True, "rpe", 128),      # M << N, bottom-right causal
     (1, 2, 2500, 300, True, "none", 128),     # M >> N: dead rows (lse = -inf) in the pipelined range
@@ -262,6 +265,8 @@ def test_bwd64_mixed_launch_matches_the_256_key_launch(B, H, M, N, causal, mode)
     (4, 12, 512, 512, False, "rpe", 128),     # cfg2: 96 + 96 workgroups side by side
     (4, 12, 1536, 1536, False, "rpe", 128),   # 576 workgroups on 256 CUs: dQ workgroups queue behind the dK/dV ones
     (2, 3, 1024, 1024, False, "none", 128),
+    (2, 3, 512, 512, True, "none", 128),      # causal without bias in the one-launch form (round 5: the library's choice up to 512 keys): mask in the dK/dV half's C operand
+    (1, 2, 1000, 1100, True, "none", 128),
     (1, 2, 2048, 2048, True, "rpe", 128),     # causal: masked (general) steps produce their statistics the same way
     (1, 2, 1000, 1100, True, "rpe", 128),     # causal with the mask in the table at a non-zero offset (0 < N - M < R)
     (1, 2, 1100, 1000, True, "rpe", 128),     # ... N - M < 0: dead rows whose statistics the dK/dV half forms itself
