@@ -28,6 +28,11 @@
 #define FAT5_ABL 0  // developer ablations of the dK/dV body (timing only, wrong results): 1 no diagonal ops, 2 no finish / hand-over, 4 no table reads, 8 no table fill / zeroing in the prologue, 16 no partial sums in the epilogue, 32 no far-bin MFMAs, 64 SELF: no statistics production in the pipelined iteration, 128 SELF: counted vmcnt (step j+1 landed) instead of vmcnt(0)
 #endif
 
+#ifndef FAT5_DMA_SPREAD
+#define FAT5_DMA_SPREAD 0  // 1: the pipelined iterations issue the LDS-DMA pieces of a step one per MFMA gap instead of all behind the step's barrier.  What pays in
+                           // attn_bwd_qdb64.h (nine pieces per wave and step: -130 us of 2.1 ms) LOSES here at two to seven pieces (tools/build_variant.py A/B, twice:
+                           // cfg2 backward 32.5 vs 30.3 us, (4,12,2048) 201 vs 195, (4,12,8192) 2520 vs 2475): a uniform branch and a readfirstlane per piece in the gaps
+#endif
 #ifndef FAT5_TRACE
 #define FAT5_TRACE 0  // developer build: thread 0 of every workgroup stamps s_memtime at its phase boundaries into the delta scratch (tools/trace64.py)
 #endif
@@ -291,8 +296,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     bstride_b = (uint32_t)a.bs[2] * 2u;
   }
   // The LDS-DMA pieces of one step, in request order (the counted waits below rely on it): [DENSE: 4 bias pieces] PER x (Q, dO [, O]) | statistics.
-  // The pipelined iterations issue them ONE PER MFMA GAP (round 5): the pieces of the four waves, requested together right behind the step's barrier,
-  // queue up in front of the CU's one texture-address unit (~16 cycles each) and every in-order wave waits for its last one.
+  // (FAT5_DMA_SPREAD: issued one per MFMA gap by the pipelined iterations -- measured, not kept: see the macro)
   constexpr int NPIECE = (DENSE ? 4 : 0) + Dma::PER * (SELF ? 3 : 2) + 1;
   auto dma_piece = [&](const uint32_t mt, const uint32_t slot_off, const int k) {
     constexpr int NB = DENSE ? 4 : 0, NI = SELF ? 3 : 2;
@@ -731,8 +735,11 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       }
       if constexpr (g == 27) asm volatile("" ::"v"(DL));
       // ---- barrier + DMA (step j+3 into the slot of step j-1, one piece per gap) ----
-      if constexpr (g == 12) sync_wait(j);
-      if constexpr (g > 12 && g - 13 < NPIECE) {
+      if constexpr (g == 12) {
+        if constexpr (FAT5_DMA_SPREAD) sync_wait(j);
+        else sync_step(j, o_prev);
+      }
+      if constexpr (FAT5_DMA_SPREAD && g > 12 && g - 13 < NPIECE) {
         if (j + 3 < nsteps) dma_piece((uint32_t)__builtin_amdgcn_readfirstlane(mt0 + j + 3), o_prev, g - 13);
       }
       // ---- LDS ----
@@ -1473,8 +1480,11 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
       __builtin_amdgcn_sched_barrier(0);  // (the MFMA opens its gap: without this it may sink below the gap's VALU work and pair up with the next one)
       // ---- barrier + DMA (the K and the V piece of step i+3 in gaps of their own: see the dK/dV body) ----
-      if constexpr (g == 4) sync_wait(t);
-      if constexpr (g == 5 || g == 6) {
+      if constexpr (g == 4) {
+        if constexpr (FAT5_DMA_SPREAD) sync_wait(t);
+        else sync_step(t, o_prev);
+      }
+      if constexpr (FAT5_DMA_SPREAD && (g == 5 || g == 6)) {
         if (t + 3 < nt) {
           const uint32_t tt = (uint32_t)__builtin_amdgcn_readfirstlane(t + 3);
           const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_lds + o_prev));

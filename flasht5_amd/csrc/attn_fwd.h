@@ -161,36 +161,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
 
   FragAddr<D> fa;
   fa.init(l);
-  // Round 5: the dense bias added ON THE MATRIX PIPE (attn_bwd64.h: Bwd64Cfg): S^T = K Q^T + B^T E with B^T the bias tile read as a transposed operand
-  // fragment (lane = key, k-slot = query row: the tile in LDS is source-swizzled like a D = 64 image, so FragAddr<64>'s transposing reads apply) and
-  // E[k][row] = 1/scale where k-slot k is that row -- four more MFMAs per 32-key block instead of a conversion, a multiply and an add per element, and,
-  // the point, a dense tile without masked keys then IS a constant-bias tile: it runs the FAST / optimistic tile body.  fp16 and tiles that cannot
-  // travel by DMA keep the per-element form.  A row whose
-  // keys are ALL masked by finfo.min entries (`use_masking`; a uniform softmax in the reference) ends with l = 0 and sends its workgroup through the
-  // second pass, which runs the per-element form with its clamp.
-  FragAddr<64> fab;
-  fab.init(l);
-  // selector operands E(jj) (B: lane = query row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3) of the wave's 32, holding 1/scale's leading 16 bits
-  // for j < 4 and the next 16 for j >= 4: hi + lo, 2^-17 relative -- the reference benchmarks at sm_scale 1.3)
-  u32x4 selB[4];
-  bool bmm = false;
-  if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
-    const float invf = 1.f / a.scale;
-    const uint32_t ih = __float_as_uint(invf) >> 16;
-    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
-    bmm = bias_dma && a.scale != 0.f && (__float_as_uint(invf) & 0x7f800000u) != 0x7f800000u;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      uint32_t wv[4];
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) {
-        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
-        const uint32_t val = j2 < 2 ? ih : il;
-        wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
-      }
-      selB[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
-    }
-  }
 
   // Optimistic softmax (bf16 only).  FlashAttention's reference point m need not be the running row maximum: ANY m
   // gives the exact result as long as exp2(x - m) neither overflows nor is flushed.  bf16 P and the fp32
@@ -200,7 +170,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // renormalises O, l by an exact power of two when l >= 2^40.  A score more than ~87 nats above everything seen before
   // would overflow inside one pair: l becomes inf/NaN, the workgroup notices at the end and redoes its tile with the
   // exact algorithm (second pass).  fp16 P would overflow at 2^16, so fp16 always runs the exact pass.
-  constexpr bool OPT = FAT5_OPTIMISTIC && BF16;  // (dense bias: only the tiles whose bias sits inside the scores -- bmm -- run it)
+  constexpr bool OPT = FAT5_OPTIMISTIC && BF16 && BIAS != FAT5_BIAS_DENSE;
   if (OPT && tid == 0) *sFlag = 0;
 
   f32x16 oacc[DB];
@@ -242,7 +212,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // One K/V tile.  FAST: no key of the tile is masked for any row of the workgroup and the bias is one
   // constant `cst` (none, or an all-far RPE tile): raw scores stay in registers, scale and constant are folded
   // into the exponent FMA.  Otherwise the generic body handles masks / per-element bias per 32-key block.
-  bool use_bmm = bmm;  // (false in the second pass)
   auto tile = [&]<int MODE, int BUF>(int t, float cst) {  // MODE 0 generic, 1 FAST, 2 FAST optimistic
     constexpr bool FAST = MODE != 0;
     const int n0 = t * BN;
@@ -272,17 +241,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
         for (int kk = 0; kk < KK; ++kk) kf[kk] = ld_rm<D>(sKb, fa, kb, kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = mfma32<BF16>(kf[kk], qf[kk], kk == 0 ? zero16 : s);
-        if constexpr (BIAS == FAT5_BIAS_DENSE && BF16) {
-          if (FAST || use_bmm) {  // + bias / scale: the wave's 32 rows x the block's 32 keys of the tile, transposed (one 8-byte read, twice, per 8-row group)
-            typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const char* pp = sB + BUF * Cfg::BIASB + fab.tr[jj & 1][kbr] + (32 * qg + 16 * (jj >> 1)) * 128;
-              const u32x2 bh_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(uint32_t)(uintptr_t)pp));
-              s = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], s);
-            }
-          }
-        }
       }
 
       float mul, add, mcand;
@@ -296,13 +254,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       } else {
         bool folded = fold_ok;
         float cb = 0.f;
-        if (BIAS == FAT5_BIAS_DENSE && use_bmm) {
-          // (the bias is inside the scores)
-          if (!folded) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] *= c2;
-          }
-        } else if constexpr (BIAS == FAT5_BIAS_DENSE) {
+        if constexpr (BIAS == FAT5_BIAS_DENSE) {
           folded = false;
           float bv[16];
           if (bias_dma) brd.template load<BF16>(sB + BUF * Cfg::BIASB, kbr, bv);
@@ -404,7 +356,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   //   [tb1, nt)    generic (N tail, causal diagonal)
   int ta = 0, tb0 = 0, tb1 = 0;
   float cst_a = 0.f, cst_b = 0.f;
-  if (fold_ok && (BIAS != FAT5_BIAS_DENSE || bmm)) {
+  if (fold_ok && BIAS != FAT5_BIAS_DENSE) {
     int t_full = N / BN;                                            // tiles without an N tail
     if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));  // n0 + BN - 1 <= m0 + P
     t_full = min(t_full, nt);
@@ -441,11 +393,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   };
 
   for (int pass = 0;; ++pass) {
-    const bool opt = OPT && pass == 0 && (BIAS != FAT5_BIAS_DENSE || bmm);
-    if (BIAS == FAT5_BIAS_DENSE && pass > 0) {  // the second pass of a dense problem: per-element bias with its clamp, every tile general
-      use_bmm = false;
-      ta = tb0 = tb1 = 0;
-    }
+    const bool opt = OPT && pass == 0;
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -504,11 +452,6 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
     } else {
       if (!opt) break;
       if (!(l_run[0] + l_run[1] < 0x1p120f)) *sFlag = 1;
-      if constexpr (BIAS == FAT5_BIAS_DENSE) {
-        // a row that sees keys (by the causal rule) but summed to nothing: every key masked by the bias itself (see above)
-        const float lt = pair_sum(l_run[0] + l_run[1]);
-        if (qrow < M && lt == 0.f && (!a.causal || qrow + P >= 0)) *sFlag = 1;
-      }
       __syncthreads();
       if (*sFlag == 0) break;
     }
@@ -557,15 +500,13 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   }
 }
 
-// (dense bias: the two tile buffers + two bias tiles are 48 .. 96 KB of LDS -- at most two waves per SIMD fit anyway, so the allocator gets their registers:
-//  at the three-wave cap the dense instantiations spill 176 .. 252 bytes per lane)
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
 void attn_fwd_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, false, BDMA>(a);
 }
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
 void attn_fwd_split_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, true, BDMA>(a);
 }
