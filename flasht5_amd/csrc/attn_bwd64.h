@@ -112,7 +112,9 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 // (b, h, nblk): the key block of this workgroup; part_row: its row among the a.part_stride partial diagonal-sum rows of (b, h);
 // part_zero_next: the row behind it is nobody's and has to read zero (a 256-key workgroup of a launch that counts rows in
 // 128-key units: attn_bwd_kv64_mixed_kernel)
-template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false>
+// ONE (DENSE only): 1 / scale is itself a 16-bit value (1: T5, 8: the default 1 / sqrt(64)) -- one selector term, 16 bias rows per MFMA: two bias MFMAs per key
+// block and step instead of four (the launcher checks the scale; +5 % on the kernel for the general two-term form)
+template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false, bool ONE = false>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
   static_assert(D == 64, "gap schedule written for D = 64");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
@@ -419,12 +421,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     const uint32_t ih = __float_as_uint(invf) >> 16;
     const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < (ONE ? 2 : 4); ++jj) {
       uint32_t wv[4];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {  // word j2 = k-slots 2 j2, 2 j2 + 1
-        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
-        const uint32_t val = j2 < 2 ? ih : il;
+        // (ONE: operand jj = t2 covers rows 16 t2 + 8 (j >> 2) + 4 hi + (j & 3), every slot 1 / scale)
+        const int r0 = ONE ? 16 * jj + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3) : 8 * jj + 4 * hi + ((2 * j2) & 3);
+        const uint32_t val = (ONE || j2 < 2) ? ih : il;
         wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
       }
       selA[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
@@ -522,13 +525,20 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(qa[kk], kf[kb][kk], Sx[kb]);
     if constexpr (DENSE) {  // + bias / scale (see Bwd64Cfg)
+      if constexpr (ONE) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const u32x2 bh_ = lds_rd_tr_half(btr[jj & 1][kb] + so + (uint32_t)(2048 * (jj >> 1)));
-          Sx[kb] = mfma32<BF16>(selA[jj], u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, Sx[kb]);
-        }
+          for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(selA[t2], lds_rd_tr(btr[0][kb] + so + (uint32_t)(2048 * t2), btr[1][kb] + so + (uint32_t)(2048 * t2)), Sx[kb]);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const u32x2 bh_ = lds_rd_tr_half(btr[jj & 1][kb] + so + (uint32_t)(2048 * (jj >> 1)));
+            Sx[kb] = mfma32<BF16>(selA[jj], u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, Sx[kb]);
+          }
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
@@ -692,7 +702,11 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else fr = u32x4{trh[p][wh][0][0], trh[p][wh][0][1], trh[p][wh][1][0], trh[p][wh][1][1]};
         if constexpr (wh == 0) mfma_acc_agpr<BF16>(dv[kb][db], fr, PB[kb][t2]);
         else mfma_acc_agpr<BF16>(dk[kb][db], fr, DS[kb][t2]);
-      } else if constexpr (g < 24 && DN) {
+      } else if constexpr (g < 24 && DN && ONE && g >= 20) {
+        // (ONE: gaps 16..19 one k-step each, like the no-bias iteration; gaps 20..23 two MFMAs: k-steps 2, 3, then the two 16-row bias operands)
+        if constexpr (g < 22) Sn[0] = mfma32<BF16>(qa[g - 18], kf[0][g - 18], Sn[0]);
+        else Sn[0] = mfma32<BF16>(selA[g - 22], u32x4{bbh[0][2 * (g - 22)][0], bbh[0][2 * (g - 22)][1], bbh[0][2 * (g - 22) + 1][0], bbh[0][2 * (g - 22) + 1][1]}, Sn[0]);
+      } else if constexpr (g < 24 && DN && !ONE) {
         // (the first of the gap's two MFMAs: key block 0; the second one follows the gap's LDS section)
         if constexpr (g == 16) Sn[0] = mfma32<BF16>(qa[0], kf[0][0], MK ? NLm[0] : NL);
         else if constexpr (g < 20) Sn[0] = mfma32<BF16>(qa[g - 16], kf[0][g - 16], Sn[0]);
@@ -777,11 +791,17 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else if constexpr (g == 18) bbh[1][2] = lds_rd_tr_half(btr[0][1] + o_next + 2048u);
         else if constexpr (g == 19) bbh[1][3] = lds_rd_tr_half(btr[1][1] + o_next + 2048u);
         // the gap's second MFMA: key block 1
-        if constexpr (g >= 16 && g < 24) {
+        if constexpr (!ONE && g >= 16 && g < 24) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (g == 16) Sn[1] = mfma32<BF16>(qa[0], kf[1][0], MK ? NLm[1] : NL);
           else if constexpr (g < 20) Sn[1] = mfma32<BF16>(qa[g - 16], kf[1][g - 16], Sn[1]);
           else Sn[1] = mfma32<BF16>(selA[g - 20], u32x4{bbh[1][g - 20][0], bbh[1][g - 20][1], bbh[1][g - 20][0], bbh[1][g - 20][1]}, Sn[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (ONE && g >= 20 && g < 24) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (g < 22) Sn[1] = mfma32<BF16>(qa[g - 18], kf[1][g - 18], Sn[1]);
+          else Sn[1] = mfma32<BF16>(selA[g - 22], u32x4{bbh[1][2 * (g - 22)][0], bbh[1][2 * (g - 22)][1], bbh[1][2 * (g - 22) + 1][0], bbh[1][2 * (g - 22) + 1][1]}, Sn[1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1678,14 +1698,14 @@ void attn_bwd_fused64_kernel(const AttnArgs a) {
   }
 }
 
-template <int D, bool BF16, int BIAS, bool HALF>
+template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_kv64_kernel(const AttnArgs a) {
   int b, h, nblk;
   decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
   // (part_rows2: a 256-key launch over some units of a problem whose other units run half-length -- a unit range of a mixed launch)
   const bool two = !HALF && a.part_rows2;
-  attn_bwd_kv64_body<D, BF16, BIAS, HALF>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);
+  attn_bwd_kv64_body<D, BF16, BIAS, HALF, false, ONE>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);
 }
 
 // Both variants in one launch.  One workgroup per CU (512 registers per lane): `w` 256-key workgroups take ceil(w / 256) rounds, the

@@ -2,6 +2,7 @@
 #include "attn_bwd64.h"
 #include "attn_launch.h"
 #include <algorithm>
+#include <cstring>
 
 #ifndef FAT5_INST_D
 #error "FAT5_INST_D must be defined"
@@ -11,7 +12,14 @@
 
 namespace fat5 {
 
-template <int D, bool BF16, int BIAS, bool HALF>
+// 1 / scale representable in 16 bits (bf16): the one-term selector of the dense body
+static inline bool inv_scale_is_bf16(float scale) {
+  const float inv = 1.f / scale;
+  uint32_t bits;
+  memcpy(&bits, &inv, 4);
+  return (bits & 0xffffu) == 0u;
+}
+template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   // (operands / outputs through LDS images whenever the workgroup's LDS allows: see BwdQ64Cfg)
   AttnArgs as = a;
@@ -19,7 +27,7 @@ static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   using Cfg = Bwd64Cfg<D, HALF, false, BIAS == FAT5_BIAS_DENSE>;
   as.lds_stage = Cfg::smem(a.R, BIAS, true) <= 160 * 1024;
   const size_t smem = Cfg::smem(a.R, BIAS, as.lds_stage != 0);
-  auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF>;
+  auto kern = attn_bwd_kv64_kernel<D, BF16, BIAS, HALF, ONE>;
   if (smem > 48 * 1024) {  // (idempotent driver call; the library keeps no state of its own)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -52,7 +60,11 @@ hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int b
 template <bool HALF>
 static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
   if constexpr (!HALF) {  // (dense bias, round 5: 256-key workgroups, bf16)
-    if (bias == FAT5_BIAS_DENSE) return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false>(a, grid, s) : hipErrorInvalidValue;
+    if (bias == FAT5_BIAS_DENSE) {
+      if (!bf16) return hipErrorInvalidValue;
+      return inv_scale_is_bf16(a.scale) ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, true>(a, grid, s)
+                                        : launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, false>(a, grid, s);
+    }
   }
   if (bias == FAT5_BIAS_RPE1D)
     return bf16 ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_RPE1D, HALF>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_RPE1D, HALF>(a, grid, s);

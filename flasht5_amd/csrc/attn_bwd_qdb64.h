@@ -66,7 +66,8 @@ FAT5_DEV constexpr int qdb_key(int r, int hi) { return 16 * hi + (r & 3) + 8 * (
 FAT5_DEV constexpr int qdb_word(int r) { return qdb_key(r, 0) >> 1; }
 
 // PARTIAL: the sums go out as fp32 (one (H, M, N) slab per group of four batch elements) instead of the final 16-bit dbias
-template <int D, bool BF16, bool PARTIAL>
+// ONE: 1 / scale is itself a 16-bit value (1: T5, 8: the default) -- one selector term, 16 bias rows per MFMA: four bias MFMAs per step instead of eight
+template <int D, bool BF16, bool PARTIAL, bool ONE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   static_assert(D == 64 && BF16, "gap schedule written for D = 64, bf16");
@@ -294,12 +295,13 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     const uint32_t ih = __float_as_uint(invf) >> 16;
     const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < (ONE ? 2 : 4); ++jj) {
       uint32_t wv[4];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
-        const int r0 = 8 * jj + 4 * hi + ((2 * j2) & 3);
-        const uint32_t val = j2 < 2 ? ih : il;
+        // (ONE: operand jj = t2 covers rows 16 t2 + 8 (j >> 2) + 4 hi + (j & 3), every slot 1 / scale)
+        const int r0 = ONE ? 16 * jj + 8 * ((2 * j2) >> 2) + 4 * hi + ((2 * j2) & 3) : 8 * jj + 4 * hi + ((2 * j2) & 3);
+        const uint32_t val = (ONE || j2 < 2) ? ih : il;
         wv[j2] = (r0 == lq ? val : 0u) | (r0 + 1 == lq ? val << 16 : 0u);
       }
       selB[jj] = u32x4{wv[0], wv[1], wv[2], wv[3]};
@@ -380,13 +382,23 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) Sx[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sx[qb]);
+    if constexpr (ONE) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const u32x2 bh_ = lds_rd_tr_half(btA[jj & 1] + bo + (uint32_t)(qb * 2048 + (jj >> 1) * 1024));
-        Sx[qb] = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], Sx[qb]);
-      }
+        for (int qb = 0; qb < 2; ++qb) {
+          const uint32_t o = bo + (uint32_t)(qb * 2048 + t2 * 1024);
+          Sx[qb] = mfma32<BF16>(lds_rd_tr(btA[0] + o, btA[1] + o), selB[t2], Sx[qb]);
+        }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const u32x2 bh_ = lds_rd_tr_half(btA[jj & 1] + bo + (uint32_t)(qb * 2048 + (jj >> 1) * 1024));
+          Sx[qb] = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], Sx[qb]);
+        }
+    }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -510,6 +522,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       DSn[qb][r0 >> 3][(r0 & 7) >> 1] = asm_cvt_pk<BF16>(Dv[E0], Dv[E0 + 1]);
     };
     auto bfrag = [&](const int qb, const int jj) { return u32x4{bf[qb][jj][0], bf[qb][jj][1], bf[qb][jj][0], bf[qb][jj][1]}; };
+    auto bfrag1 = [&](const int qb, const int t2) { return u32x4{bf[qb][2 * t2][0], bf[qb][2 * t2][1], bf[qb][2 * t2 + 1][0], bf[qb][2 * t2 + 1][1]}; };  // ONE: 16 rows
     static_for<NG>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       // ---- MFMA ----
@@ -519,6 +532,14 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
         if constexpr (t2 == 0) fr = TRK[db];
         else fr = u32x4{th[db][0][0], th[db][0][1], th[db][1][0], th[db][1][1]};
         mfma_acc_agpr<BF16>(dq[qb][db], fr, DSB[qb][t2]);
+      } else if constexpr (ONE && g < 12) {
+        // (ONE: gaps 8..11 one k-step each, like the no-bias iteration; gaps 12..15 two MFMAs: k-steps 2, 3, then the two 16-row bias operands)
+        constexpr int kk = (g - 8) >> 1, qb = g & 1;
+        if constexpr (kk == 0 && !MK) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
+        else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);
+      } else if constexpr (ONE && g < 16) {
+        if constexpr (g < 14) Sn[0] = mfma32<BF16>(kf[g - 10], qf[0][g - 10], Sn[0]);
+        else Sn[0] = mfma32<BF16>(bfrag1(0, g - 14), selB[g - 14], Sn[0]);
       } else if constexpr (g < 12) {
         // (gaps 8..15: two MFMAs each -- query block 0 here, query block 1 behind the gap's LDS section)
         if constexpr (g == 8 && !MK) Sn[0] = mfma32<BF16>(kf[0], qf[0][0], zero16);
@@ -564,11 +585,17 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
         tn[db][half] = lds_rd_tr_half(trA[half][db] + o_cur);
       }
       // ---- the gap's second MFMA (query block 1) ----
-      if constexpr (g >= 8 && g < 16) {
+      if constexpr (!ONE && g >= 8 && g < 16) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (g == 8 && !MK) Sn[1] = mfma32<BF16>(kf[0], qf[1][0], zero16);
         else if constexpr (g < 12) Sn[1] = mfma32<BF16>(kf[g - 8], qf[1][g - 8], Sn[1]);
         else Sn[1] = mfma32<BF16>(bfrag(1, g - 12), selB[g - 12], Sn[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (ONE && g >= 12 && g < 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 14) Sn[1] = mfma32<BF16>(kf[g - 10], qf[1][g - 10], Sn[1]);
+        else Sn[1] = mfma32<BF16>(bfrag1(1, g - 14), selB[g - 14], Sn[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- the dbias tile of step i-1 leaves ----

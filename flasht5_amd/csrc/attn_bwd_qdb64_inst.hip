@@ -1,6 +1,7 @@
 // Instantiations of the dense-bias dQ + batch-reduced dBias body (attn_bwd_qdb64.h), D = 64, bf16.
 #include "attn_bwd_qdb64.h"
 #include "attn_launch.h"
+#include <cstring>
 
 namespace fat5 {
 
@@ -12,18 +13,19 @@ hipError_t launch_bwd_qdb64_d64(const AttnArgs& a, int bf16, void* dbias_out, in
   as.mg_mblk = div_magic(as.n_mblk, grid);
   grid = (grid + 7) / 8 * 8;  // (eight contiguous chunks of work items, one per XCD: see the kernel)
   constexpr int smem = BwdQdb64Cfg<64>::SMEM;
-  if (partial) {
-    auto kern = attn_bwd_qdb64_kernel<64, true, true>;
+  // (1 / scale a 16-bit value itself -- 1, 8, ...: the one-term selector, four bias MFMAs per step instead of eight)
+  const float inv = 1.f / a.scale;
+  uint32_t bits;
+  memcpy(&bits, &inv, 4);
+  const bool one = (bits & 0xffffu) == 0u;
+  auto go = [&](auto kern) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as, dbias_out);
-  } else {
-    auto kern = attn_bwd_qdb64_kernel<64, true, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as, dbias_out);
-  }
-  return hipGetLastError();
+    return hipGetLastError();
+  };
+  if (partial) return one ? go(attn_bwd_qdb64_kernel<64, true, true, true>) : go(attn_bwd_qdb64_kernel<64, true, true, false>);
+  return one ? go(attn_bwd_qdb64_kernel<64, true, false, true>) : go(attn_bwd_qdb64_kernel<64, true, false, false>);
 }
 
 hipError_t launch_dbias_partial_reduce(const float* part, void* out, int bf16, int ngrp, int H, int M, int N, int causal, hipStream_t s) {
