@@ -170,7 +170,9 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   // renormalises O, l by an exact power of two when l >= 2^40.  A score more than ~87 nats above everything seen before
   // would overflow inside one pair: l becomes inf/NaN, the workgroup notices at the end and redoes its tile with the
   // exact algorithm (second pass).  fp16 P would overflow at 2^16, so fp16 always runs the exact pass.
-  constexpr bool OPT = FAT5_OPTIMISTIC && BF16 && BIAS != FAT5_BIAS_DENSE;
+  // (round 5: dense tiles without masked keys run the FAST / optimistic body too, their bias added per element in front of it -- the round-3 experiment
+  //  that spilled at the three-wave register cap; the dense instantiations have two waves per SIMD now: their LDS allows no more anyway)
+  constexpr bool OPT = FAT5_OPTIMISTIC && BF16;
   if (OPT && tid == 0) *sFlag = 0;
 
   f32x16 oacc[DB];
@@ -244,7 +246,17 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
       }
 
       float mul, add, mcand;
-      if constexpr (MODE == 2) {
+      if constexpr (FAST && BIAS == FAT5_BIAS_DENSE) {
+        // dense tile, every key visible: x = s * c2 + bias * log2(e) per element, then the constant-bias body (reference point: running maximum in the
+        // exact tiles, the stale one in the optimistic tiles)
+        float bv[16];
+        brd.template load<BF16>(sB + BUF * Cfg::BIASB, kbr, bv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fmaf(s[r], c2, bias_log2(bv[r]));
+        mul = 1.f;
+        add = 0.f;
+        if constexpr (MODE != 2) mcand = max16(s);
+      } else if constexpr (MODE == 2) {
         mul = c2;
         add = cst;
       } else if constexpr (FAST) {
@@ -356,7 +368,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   //   [tb1, nt)    generic (N tail, causal diagonal)
   int ta = 0, tb0 = 0, tb1 = 0;
   float cst_a = 0.f, cst_b = 0.f;
-  if (fold_ok && BIAS != FAT5_BIAS_DENSE) {
+  if (fold_ok && (BIAS != FAT5_BIAS_DENSE || bias_dma)) {
     int t_full = N / BN;                                            // tiles without an N tail
     if (a.causal) t_full = min(t_full, max(0, (m0 + P + 1) / BN));  // n0 + BN - 1 <= m0 + P
     t_full = min(t_full, nt);
@@ -500,13 +512,14 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   }
 }
 
+// (dense bias: the two tile buffers + two bias tiles are 48 .. 96 KB of LDS -- at most two waves per SIMD fit anyway, so the allocator gets their registers)
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
 void attn_fwd_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, false, BDMA>(a);
 }
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_FWD_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 && BIAS != FAT5_BIAS_DENSE ? FAT5_FWD_MINW : 2)))
 void attn_fwd_split_kernel(const AttnArgs a) {
   attn_fwd_body<D, BF16, BIAS, NW, true, BDMA>(a);
 }
