@@ -14,6 +14,9 @@ namespace fat5 {
 template <int D, bool BF16, int BIAS, int NW, bool BDMA = false>
 static hipError_t launch_one(const AttnArgs& a, int grid, hipStream_t s) {
   size_t smem = FwdCfg<D, NW>::smem(a.R, BIAS);
+#ifdef FAT5_FWD_PAD_LDS  // developer experiment: the no-bias forward at the dense instantiations' LDS footprint (occupancy)
+  if (BIAS == FAT5_BIAS_NONE) smem += FAT5_FWD_PAD_LDS;
+#endif
   auto kern = attn_fwd_kernel<D, BF16, BIAS, NW, BDMA>;
   static size_t configured = 0;  // per instantiation; benign race (idempotent call)
   if (smem > 48 * 1024 && smem > configured) {
