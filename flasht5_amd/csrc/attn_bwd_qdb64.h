@@ -684,6 +684,16 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
     __syncthreads();
     x_reduce_store(xpar, nt - 1, (nt - 1) * 32 + 32 <= N);
   }
+  // causal: the key steps this row block never visits lie above the diagonal -- zeros by definition (reference :153, :160): written here, 16 rows per wave,
+  // instead of a memset of the whole (H, M, N) tensor in front of the launch (403 MB at S = 4096).  (PARTIAL: the slab reduction knows the mask.)
+  if constexpr (!PARTIAL) {
+    if (a.causal) {
+      for (int st = nt; st * 32 < N; ++st) {
+        const bool ok = row_ok && st * 32 + 8 * (l >> 4) < N;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, dbrs, ok ? dvo : 0x80000000u, (uint32_t)(st * 32 * ESZ), 0);
+      }
+    }
+  }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (asm MFMA -> accumulator reads below: see mfma_acc_agpr)
   wait_dma_all();  // (nothing may land in the ring once dQ goes through it)
 

@@ -644,11 +644,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   const long bh = (long)p->B * p->H;
   const bool bf16 = p->dtype == FAT5_BF16;
   if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && L.qdb64) {
-    // (tiles above the causal diagonal are never visited: zeros by definition, reference :153,:160; with partial slabs the reduction knows the mask)
-    if (p->causal && (stages & FAT5_BWD_DQ) && L.qdb_groups == 1) {
-      hipError_t e = hipMemsetAsync(p->dbias, 0, (size_t)p->H * MN * 2, stream);
-      if (e != hipSuccess) return hip_fail(e, "memset dbias");
-    }
+    // (tiles above the causal diagonal are never visited: zeros by definition, reference :153,:160 -- the kernel writes them itself, row block by row
+    //  block; with partial slabs the reduction knows the mask.  No memset.)
   } else if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && !L.dbias_inkernel) {
     if (L.ds_staged) {
       a.ds_out = (uint16_t*)(ws + L.ds_off);
