@@ -27,6 +27,7 @@ for d in (32, 64, 128):
     UNITS.append(("attn_fwd_inst.hip", f"attn_fwd_d{d}.o", [f"-DFAT5_INST_D={d}"]))
     UNITS.append(("attn_bwd_inst.hip", f"attn_bwd_d{d}.o", [f"-DFAT5_INST_D={d}"]))
 UNITS.append(("attn_fwd64_inst.hip", "attn_fwd64_d64.o", ["-DFAT5_INST_D=64"]))
+UNITS.append(("attn_fwd64_inst.hip", "attn_fwd64_d128.o", ["-DFAT5_INST_D=128"]))
 UNITS.append(("attn_bwd64_inst.hip", "attn_bwd64_d64.o", ["-DFAT5_INST_D=64"]))
 UNITS.append(("attn_bwd_qdb64_inst.hip", "attn_bwd_qdb64_d64.o", []))
 

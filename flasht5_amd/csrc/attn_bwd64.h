@@ -94,19 +94,6 @@ FAT5_DEV float asm_mul(float a, float b) {
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// acc += A . B with the accumulator tuple in AGPRs.  The dK^T / dV^T accumulators (128 registers) are touched by nothing but
-// MFMAs: hipcc's VGPR-form MFMA selection would keep them in VGPRs and spill everything else through v_accvgpr moves.
-// No hazard padding is generated for asm: same-accumulator MFMAs need none, A / B come from LDS reads (waitcnt is inserted
-// for asm operands) or from VALU results that are many instructions old; the epilogue pads before it reads the tuples.
-template <bool BF16>
-FAT5_DEV void mfma_acc_agpr(f32x16& acc, const u32x4 A, const u32x4 B) {
-  if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
-}
-FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
-  typedef s16x4_t __attribute__((address_space(3))) * p_t;
-  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)addr));
-}
 
 
 // (b, h, nblk): the key block of this workgroup; part_row: its row among the a.part_stride partial diagonal-sum rows of (b, h);

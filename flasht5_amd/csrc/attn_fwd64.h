@@ -132,6 +132,19 @@ FAT5_DEV void mfma16_acc(f32x4& acc, const u32x4 A, const u32x4 B) {
   if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
 }
+// acc += A . B with the accumulator tuple in AGPRs.  The dK^T / dV^T accumulators (128 registers) are touched by nothing but
+// MFMAs: hipcc's VGPR-form MFMA selection would keep them in VGPRs and spill everything else through v_accvgpr moves.
+// No hazard padding is generated for asm: same-accumulator MFMAs need none, A / B come from LDS reads (waitcnt is inserted
+// for asm operands) or from VALU results that are many instructions old; the epilogue pads before it reads the tuples.
+template <bool BF16>
+FAT5_DEV void mfma_acc_agpr(f32x16& acc, const u32x4 A, const u32x4 B) {
+  if constexpr (BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+}
+FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
+  typedef s16x4_t __attribute__((address_space(3))) * p_t;
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((p_t)(uintptr_t)addr));
+}
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
@@ -139,6 +152,10 @@ template <int D, bool BF16, int BIAS, bool KSPLIT>
 FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const int m0) {
   static_assert(BIAS != FAT5_BIAS_DENSE || !KSPLIT, "dense bias: 256-row workgroups only");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
+  // W1 (round 5, head_dim 128): one wave per SIMD -- O^T (128 registers per lane) lives in AGPRs and is touched by asm MFMAs only
+  // (mfma_acc_agpr), the Q fragments sit in AGPRs as well; a pipelined block has 32 MFMA gaps; Q arrives and O leaves as whole rows through LDS
+  constexpr bool W1 = D == 128;
+  static_assert(!W1 || (!KSPLIT && !DENSE), "head_dim 128: 256-row workgroups, bias none / rpe1d");
   using Cfg = Fwd64Cfg<D, KSPLIT>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
@@ -193,6 +210,28 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
       const int pi = 4 * kh + i;  // (wave-uniform)
       dma16_asm(qrs, dst + (uint32_t)(pi * 1024), sq.voff[i % 2], r0 + sq.piece_step * (uint32_t)(pi / 2));
     }
+  } else if constexpr (W1) {
+    // the wave's 64 rows through the K ring (free until stage_first): 16 pieces of 4 rows, read back as fragments at once
+    using SDma = DmaStage<D, 64, 64>;
+    static_assert(SDma::PER == 16 && SDma::NV == 4, "sixteen 1-KiB pieces of 4 rows");
+    static_assert(Cfg::NW * 64 * 2 * D <= NS * TILE, "the Q images fit the K ring");
+    SDma sq;
+    sq.init(a.qs[2], l);
+    const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb_, a.qs[2], M, D);
+    const uint32_t qi = (uint32_t)(uintptr_t)smem + (uint32_t)(w * 64 * 2 * D);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+    const uint32_t r0 = (uint32_t)qrow0 * (uint32_t)a.qs[2] * 2u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dma16_asm(qrs, dst + (uint32_t)(i * 1024), sq.voff[i % 4], r0 + sq.piece_step * (uint32_t)(i / 4));
+    FragAddr<D> fq;
+    fq.init(l);
+    wait_dma_all();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) qf[qb][kk] = lds_rd128(qi + (uint32_t)(fq.rm[kk] + qb * 32 * 2 * D));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // (stage_first overwrites the images)
   } else {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -348,7 +387,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(qf[qb][kk]));  // (see attn_fwd.h: retire the loads in the waitcnt model)
+    for (int kk = 0; kk < KK; ++kk) {
+      if constexpr (W1) asm volatile("" : "+a"(qf[qb][kk]));  // MFMA-only operands: AGPRs
+      else asm volatile("" ::"v"(qf[qb][kk]));  // (see attn_fwd.h: retire the loads in the waitcnt model)
+    }
   const float c2 = a.scale * kLog2e;
   const bool fold_ok = c2 > 0.f;
   float cst_neg = 0.f, cst_pos = 0.f;
@@ -392,6 +434,21 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // Both query blocks per 32-key block: K / V fragments are read once and used twice.
   // NOMAX: reference point 0 for every row (the optimistic sweep's masked tiles); otherwise the exact running maximum.
   // ------------------------------------------------------------------------------------------------------------------
+  auto acc_fence = [&]() {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int i = 0; i < DB; ++i) asm volatile("" : "+a"(oacc[qb][i]));
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int i = 0; i < DB; ++i) asm volatile("" : "+a"(oacc[qb][i]));
+  };
+  auto pv_mfma = [&](f32x16& acc, const u32x4 A, const u32x4 B) {
+    if constexpr (W1) mfma_acc_agpr<BF16>(acc, A, B);
+    else acc = mfma32<BF16>(A, B, acc);
+  };
   auto tile_exact = [&]<int MODE, bool NOMAX, bool MAXONLY = false>(int t, int slot, float cst) {
     const int n0 = t * BN;
     const uint32_t soff = (uint32_t)(slot * TILE);
@@ -487,10 +544,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
             const float alpha = fast_exp2(m_run[qb] - ((m_new == -INFINITY) ? 0.f : m_new));
             l_run[qb][0] *= alpha;
             l_run[qb][1] *= alpha;
+            if constexpr (W1) acc_fence();  // (asm MFMA -> VALU access of the accumulators: no padding is generated)
 #pragma unroll
             for (int i = 0; i < DB; ++i)
 #pragma unroll
               for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+            if constexpr (W1) acc_fence();
             m_run[qb] = m_new;
           }
           ad = add - ((m_run[qb] == -INFINITY) ? 0.f : m_run[qb]);
@@ -500,14 +559,23 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           const float x0 = fast_exp2(fmaf(sq[r], mul, ad)), x1 = fast_exp2(fmaf(sq[r + 1], mul, ad));
           sq[r] = x0;
           sq[r + 1] = x1;
-          l_run[qb][0] += x0;
-          l_run[qb][1] += x1;
+          if constexpr (NOMAX) {
+            // the sweep's row sums are sums of the ROUNDED probabilities (the operands of P.V); so are these: o is then a convex combination of V rows whatever
+            // the reference point -- a row with ONE visible key returns that V row exactly, as the running-maximum form does (p = 1)
+            const uint32_t w2 = pack2<BF16>(x0, x1);
+            l_run[qb][0] += cvt_lo<BF16>(w2);
+            l_run[qb][1] += cvt_hi<BF16>(w2);
+          } else {
+            l_run[qb][0] += x0;
+            l_run[qb][1] += x1;
+          }
         }
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-          const u32x4 pb = pack8<BF16>(sq, t2);
+          u32x4 pb = pack8<BF16>(sq, t2);
+          if constexpr (W1) asm volatile("s_nop 1" : "+v"(pb));  // (VALU write -> asm MFMA read: two wait states by hand)
 #pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[qb][db] = mfma32<BF16>(vf[t2][db], pb, oacc[qb][db]);
+          for (int db = 0; db < DB; ++db) pv_mfma(oacc[qb][db], vf[t2][db], pb);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -542,8 +610,102 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // periods old when chunk 0 of the next block reads it.
   constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
   auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS) {
-    static_assert(D == 64, "gap schedule written for D = 64 (16 MFMAs, 16 two-element chunks per block)");
+    static_assert(D == 64 || D == 128, "gap schedules written for D = 64 (16 MFMAs, 16 two-element chunks per block) and D = 128 (32 MFMAs)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
+    if constexpr (W1) {
+      // 32 gaps.  MFMA g < 16: O^T[qb][db] += V^T(t2, db) . P^T[qb][t2] of block i-1 (t2 outer, d-blocks, query blocks inner); g >= 16: S' = K(kk) Q^T of
+      // block i+1.  VALU: chunk c (two elements) opens in gap 2c (arguments), exp in gap 2c+1, packed in gap 2c+2 (chunk 15: gap 0 of the next
+      // block, `pc`).  LDS: gaps 0..7 the K fragments, gaps 16..31 the halves of the V^T fragments of block i; BAND: table entries >= 3 gaps ahead.
+      u32x4 kf[KK];
+      f32x16 Sn[2];
+      u32x4 PBn[2][2];
+      u32x2 vh[2][DB][2];
+      float X[16][2], Pr[16][2];
+      u32x4 T[2][4];
+      uint32_t tadr1 = 0;
+      if constexpr (BAND) {
+        T[0][0] = TN[0];
+        T[0][1] = TN[1];
+      }
+      static_for<32>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        if constexpr (g < 16) {
+          constexpr int qb = g & 1, db = (g >> 1) & 3, t2 = g >> 3;
+          mfma_acc_agpr<BF16>(oacc[qb][db], VF[t2][db], PB[qb][t2]);
+        } else {
+          constexpr int idx = g - 16, qb = idx & 1, kk = idx >> 1;
+          if constexpr (kk == 0) Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], zero16);
+          else Sn[qb] = mfma32<BF16>(kf[kk], qf[qb][kk], Sn[qb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LDS ----
+        if constexpr (g < KK) {
+          kf[g] = lds_rd128(rmA[g] + koff);
+        } else if constexpr (g >= 16) {
+          constexpr int v = g - 16, t2 = v >> 3, db = (v >> 1) & 3, j2 = v & 1;
+          vh[t2][db][j2] = lds_rd_tr_half(trA[j2][db] + voff + (uint32_t)(16 * t2 * 2 * D));
+        }
+        if constexpr (BAND) {  // T[qb][j] is first used in gap 16 qb + 4 j
+          if constexpr (g == 1) T[0][2] = lds_rd128(tadr0 + 64u);
+          else if constexpr (g == 5) T[0][3] = lds_rd128(tadr0 + 96u);
+          else if constexpr (g == 8) tadr1 = tab_addr(1, nbS);
+          else if constexpr (g == 9) T[1][0] = lds_rd128(tadr1);
+          else if constexpr (g == 13) T[1][1] = lds_rd128(tadr1 + 32u);
+          else if constexpr (g == 17) T[1][2] = lds_rd128(tadr1 + 64u);
+          else if constexpr (g == 21) T[1][3] = lds_rd128(tadr1 + 96u);
+          else if constexpr (g == 24) tadr0 = tab_addr(0, nbS + NSTEP);
+          else if constexpr (g == 25) TN[0] = lds_rd128(tadr0);
+          else if constexpr (g == 29) TN[1] = lds_rd128(tadr0 + 32u);
+        }
+        // ---- VALU ----
+        if constexpr ((g & 1) == 0) {
+          // pack of chunk c-1 (gap 0: chunk 15 of the previous block -> the last word of PB[1][1])
+          constexpr int c = (g >> 1) - 1;
+          if constexpr (c < 0) {
+            PB[1][1][3] = asm_cvt_pk<BF16>(pc[0], pc[1]);
+          } else {
+            constexpr int cq = c >> 3, cr = 2 * (c & 7);
+            PBn[cq][cr >> 3][(cr & 7) >> 1] = asm_cvt_pk<BF16>(Pr[c][0], Pr[c][1]);
+          }
+          // arguments of chunk g / 2
+          constexpr int cc = g >> 1, cq = cc >> 3, cr = 2 * (cc & 7);
+          if constexpr (BAND) {
+            float t0 = __uint_as_float(T[cq][cr >> 2][cr & 3]), t1 = __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]);
+            if constexpr (!BF16) {
+              asm_add(t0, cq == 0 ? ad0 : ad1);
+              asm_add(t1, cq == 0 ? ad0 : ad1);
+            }
+            X[cc][0] = asm_fma(S[cq][cr], c2, t0);
+            X[cc][1] = asm_fma(S[cq][cr + 1], c2, t1);
+          } else {
+            X[cc][0] = asm_fma(S[cq][cr], c2, cq == 0 ? ad0 : ad1);
+            X[cc][1] = asm_fma(S[cq][cr + 1], c2, cq == 0 ? ad0 : ad1);
+          }
+        } else {
+          constexpr int c = g >> 1;
+          Pr[c][0] = asm_exp2(X[c][0]);
+          Pr[c][1] = asm_exp2(X[c][1]);
+        }
+        // row sums of the rounded probabilities: a group of four words two gaps or more after its last pack
+        if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+        else if constexpr (g == 11) mfma16_acc<BF16>(lacc[0], sel, PBn[0][0]);
+        else if constexpr (g == 19) mfma16_acc<BF16>(lacc[0], sel, PBn[0][1]);
+        else if constexpr (g == 27) mfma16_acc<BF16>(lacc[1], sel, PBn[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      pc[0] = Pr[15][0]; pc[1] = Pr[15][1];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        S[qb] = Sn[qb];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) PB[qb][t2] = PBn[qb][t2];
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) VF[t2][db] = u32x4{vh[t2][db][0][0], vh[t2][db][0][1], vh[t2][db][1][0], vh[t2][db][1][1]};
+      return;
+    } else {
     u32x4 kf[KK];
     f32x16 Sn[2];
     u32x4 PBn[2][2];
@@ -684,6 +846,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int db = 0; db < DB; ++db) VF[t2][db] = u32x4{vh[t2][db][0][0], vh[t2][db][0][1], vh[t2][db][1][0], vh[t2][db][1][1]};
+    }
   };
   // nothing pending: an all-zero product, chunk arguments of -inf (exp2 -> 0)
   auto pipe_reset = [&]() {
@@ -700,9 +863,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   };
   // finish the pending block: its last two chunks, then its product (V fragments are in registers already)
   auto pipe_drain = [&]() {
-    const float q0 = fast_exp2(xc[0]), q1 = fast_exp2(xc[1]);
-    PB[1][1][2] = pack2<BF16>(pc[0], pc[1]);
-    PB[1][1][3] = pack2<BF16>(q0, q1);
+    const float q0 = W1 ? 0.f : fast_exp2(xc[0]), q1 = W1 ? 0.f : fast_exp2(xc[1]);
+    if constexpr (W1) {  // (only the last chunk's pack is pending)
+      PB[1][1][3] = pack2<BF16>(pc[0], pc[1]);
+    } else {
+      PB[1][1][2] = pack2<BF16>(pc[0], pc[1]);
+      PB[1][1][3] = pack2<BF16>(q0, q1);
+    }
     asm volatile("s_nop 1" : "+v"(PB[1][1]));  // (VALU write -> asm MFMA read: two wait states by hand)
     if constexpr ((FAT5_FWD_ABL & 3) == 0) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
     if constexpr ((FAT5_FWD_ABL & 2) != 0) lv[1] += q0 + q1;
@@ -711,7 +878,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) oacc[qb][db] = mfma32<BF16>(VF[t2][db], PB[qb][t2], oacc[qb][db]);
+        for (int qb = 0; qb < 2; ++qb) pv_mfma(oacc[qb][db], VF[t2][db], PB[qb][t2]);
     pipe_reset();
   };
   // fold the matrix-pipe row sums into l_run (both key halves hold the full sum and pair_sum adds the halves: half each, exact)
@@ -798,6 +965,9 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   FAT5_FSTAMP(4);
   for (int pass = 0;; ++pass) {
     const bool nomax = OPT && pass == 0;
+    if constexpr (W1) {
+      if (pass > 0) acc_fence();
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
@@ -955,6 +1125,33 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
       const u32x4 v4 = *reinterpret_cast<const u32x4*>(oimg + row * (2 * D) + slot * 16);
       if (orow0 + row < M) *reinterpret_cast<u32x4*>(ob_ + (int64_t)(orow0 + row) * a.os[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
     }
+  } else if constexpr (W1) {
+    // O through an LDS image of the wave's 64 rows (the rings are free behind the barrier), out again as whole 256-byte rows
+    acc_fence();
+    __syncthreads();
+    char* oimg = smem + w * (64 * 2 * D);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qrow0 + 32 * qb + lq;
+      const float l_tot = pair_sum(l_run[qb][0] + l_run[qb][1]);
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 wv;
+          wv[0] = pack2<BF16>(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
+          wv[1] = pack2<BF16>(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(oimg + rm_off<D>(32 * qb + lq, 4 * db + g) + 8 * hi) = wv;
+        }
+      if (qrow < M && hi == 0) a.lse[lse_off + qrow] = l_tot > 0.f ? (m_run[qb] + fast_log2(l_tot)) * kLn2 : -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 4 * i + (l >> 4), slot = l & 15;
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(oimg + row * (2 * D) + slot * 16);
+      if (qrow0 + row < M) *reinterpret_cast<u32x4*>(ob_ + (int64_t)(qrow0 + row) * a.os[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
+    }
   } else {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -992,6 +1189,14 @@ void attn_fwd64_kernel(const AttnArgs a) {
   int b, h, mblk;
   decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
   attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, b, h, mblk * Fwd64Cfg<D, KSPLIT>::BM);
+}
+// head_dim 128 (round 5): one wave per SIMD (512 registers per lane)
+template <int D, bool BF16, int BIAS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_fwd64_w1_kernel(const AttnArgs a) {
+  int b, h, mblk;
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  attn_fwd64_body<D, BF16, BIAS, false>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
 }
 // dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
 template <int D, bool BF16>

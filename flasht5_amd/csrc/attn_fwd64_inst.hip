@@ -12,6 +12,26 @@
 
 namespace fat5 {
 
+#if FAT5_INST_D == 128
+// head_dim 128 (round 5): 256-row workgroups, one wave per SIMD, bias none / rpe1d
+template <bool BF16, int BIAS>
+static hipError_t launch_w1(const AttnArgs& a, int grid, hipStream_t s) {
+  const size_t smem = Fwd64Cfg<128, false>::smem(a.R, BIAS);
+  auto kern = attn_fwd64_w1_kernel<128, BF16, BIAS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  AttnArgs am = a;
+  fill_div_magic(am, grid);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, am);
+  return hipGetLastError();
+}
+hipError_t launch_fwd64_d128(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
+  (void)nw;
+  if (bias == FAT5_BIAS_RPE1D) return bf16 ? launch_w1<true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_w1<false, FAT5_BIAS_RPE1D>(a, grid, s);
+  if (bias == FAT5_BIAS_NONE) return bf16 ? launch_w1<true, FAT5_BIAS_NONE>(a, grid, s) : launch_w1<false, FAT5_BIAS_NONE>(a, grid, s);
+  return hipErrorInvalidValue;
+}
+#else
 template <int D, bool BF16, int BIAS, bool KSPLIT>
 static hipError_t launch64(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = Fwd64Cfg<D, KSPLIT>::smem(a.R, BIAS);
@@ -73,6 +93,8 @@ hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bia
   }
   return nw == 2 ? launch64_bias<true>(a, bf16, bias, grid, s) : launch64_bias<false>(a, bf16, bias, grid, s);
 }
+
+#endif
 
 size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D>::smem(R, bias); }
 

@@ -26,7 +26,9 @@ FAT5_DECL_LAUNCH(128)
 #undef FAT5_DECL_LAUNCH
 // 64 query rows per wave, software-pipelined (attn_fwd64.h): bias none / rpe1d, no packed batches
 hipError_t launch_fwd64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
-size_t smem_fwd64_d64(int R, int bias);  // dynamic LDS of one workgroup (two fit a CU up to 80 KB each)
+size_t smem_fwd64_d64(int R, int bias);
+hipError_t launch_fwd64_d128(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);  // (bias none / rpe1d)
+size_t smem_fwd64_d128(int R, int bias);  // dynamic LDS of one workgroup (two fit a CU up to 80 KB each)
 // 64 keys per wave, software-pipelined dK/dV body (attn_bwd64.h): bf16, bias none / rpe1d, no packed batches
 hipError_t launch_bwd_kv64_d64(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s);
 size_t smem_bwd_kv64_d64(int R, int bias);

@@ -206,6 +206,16 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     c.n_mblk = (p->M + 255) / 256;
     return c;
   }
+  // head_dim 128 (round 5): the same body at ONE wave per SIMD (O^T alone is 128 registers per lane), 32 MFMA gaps per block, 256-row workgroups;
+  // bias none / rpe1d.  Needs the chip full of 64-row waves.
+  if (p->D == 128 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
+      smem_fwd64_d128(p->rpe_radius, p->bias_mode) <= 160 * 1024 &&
+      (f64_env == 1 || (waves64 >= cu_scaled(1024) && p->N >= 512))) {
+    c.fwd64 = true;
+    c.nw = 4;
+    c.n_mblk = (p->M + 255) / 256;
+    return c;
+  }
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
       // (fp16, round 4: the pipelined sweep with the first tile's row maxima as reference point -- (4,12,8192) 739 us against 913 for the
       //  32-row body, (4,12,2048) 64.3 vs 69.4)
@@ -291,7 +301,7 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* stream_) {
   int nw = fc.nw;
   a.n_mblk = fc.n_mblk;
   a.mix_na = fc.mix_na; a.mix_a_lo = fc.mix_a_lo; a.mix_k_hi = fc.mix_k_hi;
-  launch_fn fn = fc.fwd64 ? launch_fwd64_d64 : (effD(p) == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
+  launch_fn fn = fc.fwd64 ? (p->D == 128 ? launch_fwd64_d128 : launch_fwd64_d64) : (effD(p) == 32 ? launch_fwd_d32 : (p->D == 64 ? launch_fwd_d64 : launch_fwd_d128));
   const long grid = fc.mixed ? fc.mix_grid : n_units(p) * a.n_mblk;
   if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
   hipError_t e = fn(a, p->dtype == FAT5_BF16, p->bias_mode, nw, (int)grid, stream);

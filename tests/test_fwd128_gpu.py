@@ -1,0 +1,129 @@
+"""GPU parity tests of the head_dim-128 instantiation of the long-sequence forward body (csrc/attn_fwd64.h, round 5: ONE wave per SIMD, O^T in AGPRs behind
+asm MFMAs, 32 MFMA gaps per pipelined block, Q / O as whole rows through LDS) -- forced per call with FAT5_V_FWD64_ON at sizes the oracle finishes in seconds.
+Reference operator: src/model/ops/flash_attention_v2_bias.py:327-483 (`_fwd_kernel`), benchmarked at d_head 128 by benchmarks/bench_fa2_bias.py."""
+import pytest
+import torch
+
+import oracle
+from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
+from test_attention_gpu import bound, gbound
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+def _case(B, H, M, N, dtype, mode, seed):
+    q, k, v, _, do = make_inputs(B, H, M, N, D, dtype, None, seed=seed, strided=True)
+    if mode != "rpe":
+        return q, k, v, do, None, None
+    table = torch.randn(32, H, generator=torch.Generator().manual_seed(seed + 100)) * 0.5
+    bias = oracle.compute_bias(table, M, N, True, 32, 128).contiguous().cuda()
+    return q, k, v, do, table, bias
+
+
+def _run(q, k, v, do, causal, scale, table, bits):
+    from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe, _lib
+    from flasht5_amd.flash_attention_v2_bias import _attn_fwd
+    from flasht5_amd import positional_encoding as pe
+    with _lib.variant(bits):
+        leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
+        if table is None:
+            o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], None, causal, scale)
+        else:
+            o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], table.cuda(), True, 32, 128, causal, scale)
+        dq, dk, dv = torch.autograd.grad(o, leaves, do)
+        rp = pe.rpe1d_from_table(table.cuda(), True, 32, 128) if table is not None else None
+        _, L = _attn_fwd(q, k, v, None, rp, 128 if table is not None else 0, causal, scale)
+    return {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv, "L": L}
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,mode,dtype", [
+    (1, 2, 256, 256, False, "none", torch.bfloat16),      # one workgroup, one steady-state trip
+    (1, 2, 100, 90, False, "rpe", torch.bfloat16),        # shorter than a tile: masked tiles only
+    (2, 3, 1024, 1024, False, "none", torch.bfloat16),    # pipelined range + remainder tiles
+    (2, 3, 1024, 1024, False, "rpe", torch.bfloat16),     # far-negative range, band, far-positive range
+    (1, 2, 1280, 1280, False, "rpe", torch.bfloat16),     # band range cut short by the end of the keys
+    (1, 2, 2048, 2048, True, "rpe", torch.bfloat16),      # causal: the mask rides in the bias table
+    (1, 2, 1000, 1100, True, "rpe", torch.bfloat16),      # ... cut at a non-zero table offset, ragged rows and keys
+    (1, 2, 1100, 1000, True, "rpe", torch.bfloat16),      # ... P < 0: the first 100 rows see no key
+    (1, 2, 2048, 2048, True, "none", torch.bfloat16),     # plain causal: diagonal tiles masked (unpipelined), the rest pipelined
+    (1, 2, 1000, 1100, False, "rpe", torch.bfloat16),     # ragged M and N (rows past M arrive as zeros, N tail)
+    (1, 2, 300, 2500, True, "rpe", torch.bfloat16),       # M << N, bottom-right causal
+    (1, 2, 2500, 300, True, "none", torch.bfloat16),      # M >> N: fully masked rows (o = 0, lse = -inf)
+    (1, 2, 1536, 1536, False, "rpe", torch.float16),      # fp16: the first tile's row maxima as reference point
+    (2, 3, 1024, 1024, False, "none", torch.float16),
+    (1, 2, 1000, 1100, True, "rpe", torch.float16),
+    (1, 1, 3072, 3072, False, "none", torch.bfloat16),    # several trips of the 4-tile steady-state loop
+])
+def test_fwd128_matches_oracle(B, H, M, N, causal, mode, dtype):
+    from flasht5_amd import _lib
+    scale = D ** -0.5
+    q, k, v, do, table, bias = _case(B, H, M, N, dtype, mode, seed=M + 5 * N)
+    ref = oracle_all(q, k, v, bias, do, scale, causal)
+    got = _run(q, k, v, do, causal, scale, table, _lib.V_FWD64_ON)
+    old = _run(q, k, v, do, causal, scale, table, _lib.V_FWD64_OFF)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], dtype)
+    # against the 32-row body: o to one output rounding
+    assert maxdiff(got["o"], old["o"]) <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * max(1.0, float(ref["o"].abs().max()))
+    for key in ("dq", "dk", "dv"):  # the backward consumes the lse this body wrote
+        assert torch.isfinite(got[key].float()).all(), key
+        assert maxdiff(got[key], ref[key]) <= gbound(ref[key], dtype), key
+    # lse: the pipelined blocks sum the probabilities as rounded to 16 bits (see test_fwd64_gpu.py for the model of this bound)
+    sc = torch.einsum("bhmd,bhnd->bhmn", q.float(), k.float()) * scale
+    if bias is not None:
+        sc = sc + bias.float()
+    if causal:
+        keep = torch.arange(N, device=sc.device)[None, :] <= torch.arange(M, device=sc.device)[:, None] + (N - M)
+        sc = sc.masked_fill(~keep, float("-inf"))
+    fin = torch.isfinite(ref["L"])
+    pr = torch.exp(sc - torch.where(fin, ref["L"], torch.zeros_like(ref["L"]))[..., None])
+    sigma = 0.425 * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * pr.square().sum(-1).sqrt()
+    L = got["L"]
+    assert torch.equal(torch.isfinite(L), fin) and bool((L[~fin] == float("-inf")).all())
+    dl = (L - ref["L"]).abs()[fin]
+    allow = (5 * sigma + 1e-4 * ref["L"].abs().clamp(min=1.0))[fin]
+    assert bool((dl <= allow).all()), (dl.max().item(), allow.max().item())
+
+
+@pytest.mark.parametrize("boost,rows,at", [(0.0, "all", 512), (40.0, "all", 1111), (400.0, "all", 512), (1000.0, "even", 768),
+                                           (72.0, "all", 1024), (-60.0, "all", 0), (-60.0, "even", 0), (-300.0, "all", 0)])
+def test_fwd128_optimistic_softmax_edge_cases(boost, rows, at):
+    """no running maximum in the pipelined sweep: scores shifted by `boost` nats from key `at` on -- inside the sweep's range, or beyond it -> the exact second
+    pass of the workgroup (rescaling the AGPR accumulators behind hand-placed wait states)"""
+    from flasht5_amd import _lib
+    B, H, S = 1, 2, 2048
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, S, D, generator=g).bfloat16()
+    k = torch.randn(B, H, S, D, generator=g).bfloat16()
+    v = torch.randn(B, H, S, D, generator=g).bfloat16()
+    q[..., 0] = 4.0
+    if rows == "even":
+        q[..., 1::2, 0] = 0.0
+    k[..., at:, 0] = boost / 4.0
+    q, k, v = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B, H, S, D, generator=g).bfloat16().cuda()
+    sc = 0.25  # (|q.k| over 128 dims has sigma ~ 11: keep the unboosted logits inside the sweep's range)
+    got = _run(q, k, v, do, False, sc, None, _lib.V_FWD64_ON)
+    ref = oracle_all(q, k, v, None, do, sc, False)
+    assert torch.isfinite(got["o"].float()).all()
+    assert maxdiff(got["o"], ref["o"]) <= bound(ref["o"], torch.bfloat16)
+    lp = eager_lowprec_errors(q, k, v, None, do, sc, False, ref)
+    for key in ("dq", "dk", "dv"):
+        e = maxdiff(got[key], ref[key])
+        assert torch.isfinite(got[key].float()).all(), key
+        assert e <= max(gbound(ref[key], torch.bfloat16), 3 * lp[key]), (key, e, lp[key])
+
+
+def test_fwd128_default_dispatch_and_determinism():
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    q, k, v, _, do = make_inputs(8, 16, 1024, 1024, D, torch.bfloat16, None, seed=5, strided=True)
+    plan = AttentionPlan(q, k, v, do, sm_scale=D ** -0.5, need_dbias=False)
+    assert plan.describe()["fwd"] == "64row"  # 2048 waves of 64 rows: two rounds of the chip's 1024 SIMDs
+    plan.forward(); a = plan.o.clone(); la = plan.lse.clone()
+    plan.forward()
+    torch.cuda.synchronize()
+    assert torch.equal(a, plan.o) and torch.equal(la, plan.lse)
+    small = AttentionPlan(q[:1, :2], k[:1, :2], v[:1, :2], do[:1, :2], sm_scale=D ** -0.5, need_dbias=False)
+    assert small.describe()["fwd"] != "64row"
