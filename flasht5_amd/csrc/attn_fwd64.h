@@ -51,11 +51,13 @@
 #endif
 namespace fat5 {
 
-template <int D, bool KSPLIT = false>
+// D3 (head_dim 128 with a dense bias, round 5): three ring slots per operand (96 KB) so that the two-tile bias ring (64 KB) fits the CU's 160 KB; the exact-pass
+// flag then lives in the first word of the bias ring (free once the sweep is over: see the body)
+template <int D, bool KSPLIT = false, bool D3 = false>
 struct Fwd64Cfg {
-  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = KSPLIT ? FAT5_FWD_NS_KSPLIT : 4;  // NS ring slots per operand
+  static constexpr int NW = 4, BM = KSPLIT ? 32 * NW : 64 * NW, BN = 64, NT = 64 * NW, NS = D3 ? 3 : (KSPLIT ? FAT5_FWD_NS_KSPLIT : 4);  // NS ring slots per operand
   static constexpr int TILE = rm_bytes<D, BN>();
-  static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + 16;
+  static constexpr int KOFF = 0, VOFF = NS * TILE, FLAG = 2 * NS * TILE, TAB = FLAG + (D3 ? 0 : 16);
   static constexpr int MERGE = 32 * 64 * 4 + 1024;  // KSPLIT: per wave, one query block's O^T (32 registers x 64 lanes) + (m, l) -- inside the rings
   static_assert(NW * MERGE <= 2 * NS * TILE, "merge area lives in the K / V rings");
   // dense bias (round 4): the workgroup's (BM rows x 64 keys) 16-bit bias tile of every key tile travels global -> LDS like K / V,
@@ -148,15 +150,20 @@ FAT5_DEV u32x2 lds_rd_tr_half(uint32_t addr) {
 FAT5_DEV void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
-template <int D, bool BF16, int BIAS, bool KSPLIT>
+// SPREAD (head_dim 128): the ring requests of a tile leave one piece per MFMA gap instead of eight back to back in front of the tile.  Measured (us):
+// (4,12,1024,128) -- 192 workgroups, one partial round, every CU in the same phase -- 32.4 vs 38.7; (16,12,1024) 106.9 vs 105.5, (4,12,8192) 1299 vs 1281:
+// the launcher takes it for grids of at most one round.
+template <int D, bool BF16, int BIAS, bool KSPLIT, bool SPREAD = false>
 FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const int m0) {
   static_assert(BIAS != FAT5_BIAS_DENSE || !KSPLIT, "dense bias: 256-row workgroups only");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
   // W1 (round 5, head_dim 128): one wave per SIMD -- O^T (128 registers per lane) lives in AGPRs and is touched by asm MFMAs only
   // (mfma_acc_agpr), the Q fragments sit in AGPRs as well; a pipelined block has 32 MFMA gaps; Q arrives and O leaves as whole rows through LDS
   constexpr bool W1 = D == 128;
-  static_assert(!W1 || (!KSPLIT && !DENSE), "head_dim 128: 256-row workgroups, bias none / rpe1d");
-  using Cfg = Fwd64Cfg<D, KSPLIT>;
+  static_assert(!W1 || !KSPLIT, "head_dim 128: 256-row workgroups");
+  constexpr bool D3 = W1 && DENSE;
+  static_assert(!D3 || !SPREAD, "dense: the ring requests leave in front of the tile, behind the bias tile's (counted waits)");
+  using Cfg = Fwd64Cfg<D, KSPLIT, D3>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, TILE = Cfg::TILE, NS = Cfg::NS;
   constexpr int KK = D / 16, DB = D / 32;
   constexpr int NKB = KSPLIT ? 1 : 2;  // 32-key blocks of a tile that THIS wave works on
@@ -214,7 +221,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     // the wave's 64 rows through the K ring (free until stage_first): 16 pieces of 4 rows, read back as fragments at once
     using SDma = DmaStage<D, 64, 64>;
     static_assert(SDma::PER == 16 && SDma::NV == 4, "sixteen 1-KiB pieces of 4 rows");
-    static_assert(Cfg::NW * 64 * 2 * D <= NS * TILE, "the Q images fit the K ring");
+    static_assert(Cfg::NW * 64 * 2 * D <= 2 * NS * TILE, "the Q images fit the K / V rings (contiguous)");
     SDma sq;
     sq.init(a.qs[2], l);
     const __amdgpu_buffer_rsrc_t qrs = make_rows_rsrc(qb_, a.qs[2], M, D);
@@ -252,7 +259,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // row sends the workgroup through the exact pass (the check the bf16 sweep has for 2^100); what lies far BELOW that maximum
   // is flushed, as negligible beside the row's own first tile as it is in the exact algorithm.  (dense bias: bf16 only)
   constexpr bool OPT = FAT5_OPTIMISTIC && (BF16 || !DENSE);
-  if (OPT && tid == 0) *sFlag = 0;
+  if (OPT && !D3 && tid == 0) *sFlag = 0;
 
   f32x16 oacc[2][DB];
   float m_run[2];
@@ -334,12 +341,28 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     for (int i = 0; i < NS - 2; ++i)
       if (i < nt) dma_v(i, i);
   };
-  auto begin_iter = [&](int t, int slot) {
+  auto begin_iter = [&](int t, int slot, [[maybe_unused]] bool in_pipe = false) {
     const int sk = slot == 0 ? NS - 1 : slot - 1;                    // (t + NS - 1) % NS
     const int sv = slot <= 1 ? slot + NS - 2 : slot - 2;             // (t + NS - 2) % NS
     if (t + 1 < nt) dma_b(t + 1);
+    if constexpr ((FAT5_FWD_ABL & 16) != 0) return;
+    if constexpr (W1 && SPREAD) {
+      if (!in_pipe) {
+        if (t + NS - 1 < nt) dma_k(t + NS - 1, sk);
+        if (t + NS - 2 < nt) dma_v(t + NS - 2, sv);
+      }
+      return;
+    }
     if (t + NS - 1 < nt) dma_k(t + NS - 1, sk);
     if (t + NS - 2 < nt) dma_v(t + NS - 2, sv);
+  };
+  // everything but the K / V requests of iteration t has landed (this wave's pieces): the bias tile of t + 1 among it.  (Round 5: counted by what the iteration did
+  // issue -- the fixed count of round 4 let the last tiles' bias reads run ahead of their DMA)
+  auto bias_wait = [&](int t) {
+    constexpr int PER = Dma::PER;
+    if (t + NS - 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (t + NS - 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else wait_dma_all();
   };
   auto end_iter = [&](int t) {
     constexpr int PER = Dma::PER;
@@ -609,7 +632,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // and pads no hazards for them -- the youngest MFMA result they read (S'[0], finished by MFMA 14) is two MFMA issue
   // periods old when chunk 0 of the next block reads it.
   constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
-  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS) {
+  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS, [[maybe_unused]] const int tt = 0) {
     static_assert(D == 64 || D == 128, "gap schedules written for D = 64 (16 MFMAs, 16 two-element chunks per block) and D = 128 (32 MFMAs)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
     if constexpr (W1) {
@@ -627,6 +650,22 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
         T[0][0] = TN[0];
         T[0][1] = TN[1];
       }
+      // DENSE: the block's bias words [query block][4-key group] from this wave's rows of the staged tile (slot = tile parity: a run-time offset with three
+      // ring slots); the first two groups were fetched during the previous block.  Per element one shift / mask and one multiply (log2 units) in front of the FMA,
+      // placed one gap ahead of it
+      [[maybe_unused]] u32x2 Bw[2][4];
+      [[maybe_unused]] float Bf[16][2];
+      [[maybe_unused]] const uint32_t bcur = (uint32_t)((tt & 1) * Cfg::BIASB), bnxt = VB == 0 ? bcur : (uint32_t)Cfg::BIASB - bcur;
+      if constexpr (DENSE) {
+        Bw[0][0] = BN0;
+        Bw[0][1] = BN1;
+      }
+      auto bias_f = [&]<int C>() {  // chunk C: its two bias values in log2 units
+        constexpr int cq = C >> 3, cr = 2 * (C & 7);
+        const uint32_t wd = Bw[cq][cr >> 2][(cr & 3) >> 1];
+        Bf[C][0] = asm_mulf(asm_shl16(wd), kLog2e);
+        Bf[C][1] = asm_mulf(asm_and_hi(wd), kLog2e);
+      };
       static_for<32>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
         if constexpr (g < 16) {
@@ -644,6 +683,28 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
         } else if constexpr (g >= 16) {
           constexpr int v = g - 16, t2 = v >> 3, db = (v >> 1) & 3, j2 = v & 1;
           vh[t2][db][j2] = lds_rd_tr_half(trA[j2][db] + voff + (uint32_t)(16 * t2 * 2 * D));
+        }
+        // the tile's ring requests, one 1-KiB piece per gap in the gaps without an LDS read (instead of eight back to back in front of the tile: SPREAD):
+        // first block K(tt + NS - 1), second block V(tt + NS - 2) -- the order begin_iter issues them in (end_iter counts on it)
+        if constexpr (SPREAD && g >= 8 && g < 8 + Dma::PER) {
+          constexpr int i = g - 8;
+          constexpr int sk = (VS + NS - 1) % NS, sv = (VS + NS - 2) % NS;
+          if constexpr (VB == 0) {
+            if (tt + NS - 1 < nt) dma16_asm(krs, wave_lds + (uint32_t)(Cfg::KOFF + sk * TILE + NT * 16 * i), kst.voff[0], (uint32_t)((tt + NS - 1) * BN) * kstride_b + kst.piece_step * i);
+          } else {
+            if (tt + NS - 2 < nt) dma16_asm(vrs, wave_lds + (uint32_t)(Cfg::VOFF + sv * TILE + NT * 16 * i), vst.voff[0], (uint32_t)((tt + NS - 2) * BN) * vstride_b + vst.piece_step * i);
+          }
+        }
+        if constexpr (DENSE) {  // Bw[qb][j] is first unpacked in gap 16 qb + 4 j - 1
+          if constexpr (g == 2) Bw[0][2] = lds_rd64(bA[VB][2] + bcur);
+          else if constexpr (g == 6) Bw[0][3] = lds_rd64(bA[VB][3] + bcur);
+          else if constexpr (g == 10) Bw[1][0] = lds_rd64(bA[VB][0] + bcur + 4096u);
+          else if constexpr (g == 14) Bw[1][1] = lds_rd64(bA[VB][1] + bcur + 4096u);
+          else if constexpr (g == 18) Bw[1][2] = lds_rd64(bA[VB][2] + bcur + 4096u);
+          else if constexpr (g == 22) Bw[1][3] = lds_rd64(bA[VB][3] + bcur + 4096u);
+          else if constexpr (g == 25 && VB == 1) bias_wait(tt);  // (the next block opens tile t + 1)
+          else if constexpr (g == 26) BN0 = lds_rd64(bA[KB][0] + bnxt);  // the next block = (KS, KB)
+          else if constexpr (g == 30) BN1 = lds_rd64(bA[KB][1] + bnxt);
         }
         if constexpr (BAND) {  // T[qb][j] is first used in gap 16 qb + 4 j
           if constexpr (g == 1) T[0][2] = lds_rd128(tadr0 + 64u);
@@ -669,7 +730,11 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           }
           // arguments of chunk g / 2
           constexpr int cc = g >> 1, cq = cc >> 3, cr = 2 * (cc & 7);
-          if constexpr (BAND) {
+          if constexpr (DENSE) {
+            if constexpr (cc == 0) bias_f.template operator()<0>();
+            X[cc][0] = asm_fma(S[cq][cr], c2, Bf[cc][0]);
+            X[cc][1] = asm_fma(S[cq][cr + 1], c2, Bf[cc][1]);
+          } else if constexpr (BAND) {
             float t0 = __uint_as_float(T[cq][cr >> 2][cr & 3]), t1 = __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]);
             if constexpr (!BF16) {
               asm_add(t0, cq == 0 ? ad0 : ad1);
@@ -683,11 +748,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           }
         } else {
           constexpr int c = g >> 1;
-          Pr[c][0] = asm_exp2(X[c][0]);
-          Pr[c][1] = asm_exp2(X[c][1]);
+          Pr[c][0] = abl_exp2(X[c][0]);
+          Pr[c][1] = abl_exp2(X[c][1]);
+          if constexpr (DENSE && c < 15) bias_f.template operator()<c + 1>();
         }
         // row sums of the rounded probabilities: a group of four words two gaps or more after its last pack
-        if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
+        if constexpr ((FAT5_FWD_ABL & 1) != 0) {
+        } else if constexpr (g == 3) mfma16_acc<BF16>(lacc[1], sel, PB[1][1]);
         else if constexpr (g == 11) mfma16_acc<BF16>(lacc[0], sel, PBn[0][0]);
         else if constexpr (g == 19) mfma16_acc<BF16>(lacc[0], sel, PBn[0][1]);
         else if constexpr (g == 27) mfma16_acc<BF16>(lacc[1], sel, PBn[1][0]);
@@ -753,7 +820,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
         else if constexpr (g == 7) Bw[1][1] = lds_rd64(bA[VB][1] + bcur + 4096u);
         else if constexpr (g == 9) Bw[1][2] = lds_rd64(bA[VB][2] + bcur + 4096u);
         else if constexpr (g == 11) Bw[1][3] = lds_rd64(bA[VB][3] + bcur + 4096u);
-        else if constexpr (g == 12 && VB == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Dma::PER) : "memory");  // (the next block opens tile t + 1: this wave's pieces of its bias tile, requested ahead of this iteration's K / V)
+        else if constexpr (g == 12 && VB == 1) bias_wait(tt);  // (the next block opens tile t + 1: this wave's pieces of its bias tile, requested ahead of this iteration's K / V)
         else if constexpr (g == 13) BN0 = lds_rd64(bA[KB][0] + bnxt);  // the next block = (KS, KB)
         else if constexpr (g == 15) BN1 = lds_rd64(bA[KB][1] + bnxt);
       }
@@ -904,12 +971,12 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     const float ad0 = BF16 ? cst : cst - m_run[0], ad1 = BF16 ? cst : cst - m_run[1];
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
-      begin_iter(tt, SL);
+      begin_iter(tt, SL, true);
       if constexpr (KSPLIT) {
         pipe_block.template operator()<S1, 0, SL, 0, BAND>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
       } else {
-        pipe_block.template operator()<SL, 1, SL, 0, BAND>(ad0, ad1, tt * BN);
-        pipe_block.template operator()<S1, 0, SL, 1, BAND>(ad0, ad1, tt * BN + 32);
+        pipe_block.template operator()<SL, 1, SL, 0, BAND>(ad0, ad1, tt * BN, tt);
+        pipe_block.template operator()<S1, 0, SL, 1, BAND>(ad0, ad1, tt * BN + 32, tt);
       }
       end_iter(tt);
     };
@@ -1083,6 +1150,11 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
         const bool visible = !(a.causal && qrow0 + 32 * qb + lq + P < 0);  // (a row without any visible key has l = 0 exactly)
         bad = bad || !(lt < 0x1p100f) || (visible && lt < 0x1p-40f);
       }
+      if constexpr (D3) {  // (the flag word is the first word of the bias ring: every wave is done with its tiles first)
+        __syncthreads();
+        if (tid == 0) *sFlag = 0;
+        __syncthreads();
+      }
       if (bad && (FAT5_FWD_ABL & 13) == 0) *sFlag = 1;  // (ablations with wrong sums must not take the exact pass)
       __syncthreads();
       if (*sFlag == 0) break;
@@ -1191,12 +1263,12 @@ void attn_fwd64_kernel(const AttnArgs a) {
   attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, b, h, mblk * Fwd64Cfg<D, KSPLIT>::BM);
 }
 // head_dim 128 (round 5): one wave per SIMD (512 registers per lane)
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool SPREAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd64_w1_kernel(const AttnArgs a) {
   int b, h, mblk;
   decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
-  attn_fwd64_body<D, BF16, BIAS, false>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
+  attn_fwd64_body<D, BF16, BIAS, false, SPREAD>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
 }
 // dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
 template <int D, bool BF16>

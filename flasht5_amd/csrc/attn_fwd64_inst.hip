@@ -14,10 +14,10 @@ namespace fat5 {
 
 #if FAT5_INST_D == 128
 // head_dim 128 (round 5): 256-row workgroups, one wave per SIMD, bias none / rpe1d
-template <bool BF16, int BIAS>
-static hipError_t launch_w1(const AttnArgs& a, int grid, hipStream_t s) {
+template <bool BF16, int BIAS, bool SPREAD>
+static hipError_t launch_w1s(const AttnArgs& a, int grid, hipStream_t s) {
   const size_t smem = Fwd64Cfg<128, false>::smem(a.R, BIAS);
-  auto kern = attn_fwd64_w1_kernel<128, BF16, BIAS>;
+  auto kern = attn_fwd64_w1_kernel<128, BF16, BIAS, SPREAD>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   AttnArgs am = a;
@@ -25,10 +25,22 @@ static hipError_t launch_w1(const AttnArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, am);
   return hipGetLastError();
 }
+template <bool BF16, int BIAS>
+static hipError_t launch_w1(const AttnArgs& a, int nw, int grid, hipStream_t s) {
+  return nw == 5 ? launch_w1s<BF16, BIAS, true>(a, grid, s) : launch_w1s<BF16, BIAS, false>(a, grid, s);
+}
+// nw == 5: the ring requests spread over the MFMA gaps (grids of at most one round: see attn_fwd64_body)
 hipError_t launch_fwd64_d128(const AttnArgs& a, int bf16, int bias, int nw, int grid, hipStream_t s) {
-  (void)nw;
-  if (bias == FAT5_BIAS_RPE1D) return bf16 ? launch_w1<true, FAT5_BIAS_RPE1D>(a, grid, s) : launch_w1<false, FAT5_BIAS_RPE1D>(a, grid, s);
-  if (bias == FAT5_BIAS_NONE) return bf16 ? launch_w1<true, FAT5_BIAS_NONE>(a, grid, s) : launch_w1<false, FAT5_BIAS_NONE>(a, grid, s);
+  if (bias == FAT5_BIAS_RPE1D) return bf16 ? launch_w1<true, FAT5_BIAS_RPE1D>(a, nw, grid, s) : launch_w1<false, FAT5_BIAS_RPE1D>(a, nw, grid, s);
+  if (bias == FAT5_BIAS_NONE) return bf16 ? launch_w1<true, FAT5_BIAS_NONE>(a, nw, grid, s) : launch_w1<false, FAT5_BIAS_NONE>(a, nw, grid, s);
+  if (bias == FAT5_BIAS_DENSE && bf16) {  // three ring slots + the two-tile bias ring: exactly 160 KB
+    const size_t smem = Fwd64Cfg<128, false, true>::smem(0, FAT5_BIAS_DENSE);
+    auto kern = attn_fwd64_w1_kernel<128, true, FAT5_BIAS_DENSE, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);  // (no division magic: the batch-inner decode of a shared bias divides by run-time values)
+    return hipGetLastError();
+  }
   return hipErrorInvalidValue;
 }
 #else
@@ -96,6 +108,11 @@ hipError_t CAT(launch_fwd64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int bia
 
 #endif
 
-size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) { return Fwd64Cfg<FAT5_INST_D>::smem(R, bias); }
+size_t CAT(smem_fwd64_d, FAT5_INST_D)(int R, int bias) {
+#if FAT5_INST_D == 128
+  if (bias == FAT5_BIAS_DENSE) return Fwd64Cfg<128, false, true>::smem(R, bias);
+#endif
+  return Fwd64Cfg<FAT5_INST_D>::smem(R, bias);
+}
 
 }  // namespace fat5

@@ -199,7 +199,12 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                        ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) && (p->bias_stride[1] % 8 == 0) &&
                        (p->bias_stride[2] % 8 == 0) && smem_fwd64_d64(0, FAT5_BIAS_DENSE) <= 160 * 1024 &&
                        (f64_env == 1 || (!p->causal && ((waves64 >= cu_scaled(3072) && p->N >= 4096) || (waves64 >= cu_scaled(6144) && p->N >= 2048))));  // (round 5: (16,12,2048) 324 vs 360 us)  // (measured, us, 64-row vs 32-row body: (4,12,8192) 1217 vs 1371; (4,12,2048) 102 vs 95; (16,12,1024) causal 95 vs 77)
-  if (dense64) {
+  // ... head_dim 128 (round 5): the one-wave-per-SIMD form of the body with three ring slots beside the bias ring (160 KB)
+  const bool dense128 = p->D == 128 && p->bias_mode == FAT5_BIAS_DENSE && p->dtype == FAT5_BF16 && !p->cu_seqlens_q && f64_env != 0 &&
+                        ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) && (p->bias_stride[1] % 8 == 0) &&
+                        (p->bias_stride[2] % 8 == 0) && smem_fwd64_d128(0, FAT5_BIAS_DENSE) <= 160 * 1024 &&
+                        (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024 && !(p->causal && p->N < 2048)));
+  if (dense64 || dense128) {
     c.fwd64 = true;
     c.ksplit = false;
     c.nw = 4;
@@ -210,10 +215,13 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   // bias none / rpe1d.  Needs the chip full of 64-row waves.
   if (p->D == 128 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&
       smem_fwd64_d128(p->rpe_radius, p->bias_mode) <= 160 * 1024 &&
-      (f64_env == 1 || (waves64 >= cu_scaled(1024) && p->N >= 512))) {
+      // (measured, us, 64-row vs 32-row body, tools/attn_time.py --D 128: (4,12,1024) 30.6 vs 39.8, (2,12,2048) 51.3 vs 63.5, (1,12,4096) 94.8 vs 120.6, (16,12,4096) 1305 vs 1628,
+      //  (4,12,8192) 1265; below 768 waves it loses -- (2,12,1024) 27.3 vs 22.4 -- and at 512 keys it ties: (16,12,512) 39.7 vs 39.8.  Plain causal (diagonal
+      //  tiles unpipelined): (16,12,1024) 105 vs 93, (4,12,2048) 87.5 vs 88.2, (16,12,4096) 843 vs 893; with the T5 table carrying the mask: (16,12,1024) 88.7 vs 96.6)
+      (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024 && !(p->causal && !ctab && p->N < 2048)))) {
     c.fwd64 = true;
-    c.nw = 4;
     c.n_mblk = (p->M + 255) / 256;
+    c.nw = bh * c.n_mblk <= chip_cus() ? 5 : 4;  // (5: ring requests spread over the MFMA gaps -- one partial round, every CU in the same phase: (4,12,1024) 32.4 vs 38.7 us)
     return c;
   }
   if (p->D == 64 && p->bias_mode != FAT5_BIAS_DENSE && !p->cu_seqlens_q && f64_env != 0 &&

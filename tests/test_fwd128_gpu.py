@@ -127,3 +127,60 @@ def test_fwd128_default_dispatch_and_determinism():
     assert torch.equal(a, plan.o) and torch.equal(la, plan.lse)
     small = AttentionPlan(q[:1, :2], k[:1, :2], v[:1, :2], do[:1, :2], sm_scale=D ** -0.5, need_dbias=False)
     assert small.describe()["fwd"] != "64row"
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,scale", [
+    (2, 3, 1024, 1024, False, None),    # trips of three tiles (three ring slots), the bias slot by tile parity
+    (1, 2, 256, 256, False, None),      # one workgroup
+    (2, 2, 1280, 1280, True, None),     # causal: diagonal tiles through the masked, unpipelined tile (bias read from the staged tile)
+    (1, 2, 1000, 1096, False, None),    # ragged rows and a key tail
+    (16, 2, 512, 576, False, 1.3),      # the reference benchmark's batch and scale (benchmarks/bench_fa2_bias.py): 16 workgroups share every bias tile
+    (1, 2, 300, 2504, True, None),      # M << N, bottom-right causal
+    (1, 1, 1664, 1664, False, None),    # 26 tiles: eight trips and a remainder of two
+])
+def test_fwd128_dense_bias_matches_oracle(B, H, M, N, causal, scale):
+    """the reference's own operator -- one (1, H, M, N) bias for the batch (flash_attention_v2_bias.py:228-288) -- at head_dim 128: three ring slots per operand beside
+    the two-tile bias ring, the exact-pass flag inside the bias ring"""
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    dtype = torch.bfloat16
+    scale = scale or D ** -0.5
+    q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, "1h", seed=M + 3 * N, strided=True)
+    if scale > 1.0:
+        q = (q.float() * 0.25).to(dtype)
+    ref = oracle_all(q, k, v, b, do, scale, causal)
+    outs = {}
+    for name, bits in (("new", _lib.V_FWD64_ON), ("old", _lib.V_FWD64_OFF)):
+        plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=scale, variant=bits)
+        assert (plan.describe()["fwd"] == "64row") == (name == "new")
+        plan.o.fill_(float("nan")); plan.lse.fill_(float("nan"))
+        plan.forward()
+        outs[name] = (plan.o.clone(), plan.lse.clone(), [t.clone() for t in plan.backward()])
+    o, L, grads = outs["new"]
+    assert torch.isfinite(o.float()).all()
+    assert maxdiff(o, ref["o"]) <= bound(ref["o"], dtype)
+    assert maxdiff(o, outs["old"][0]) <= 2.0 ** -7 * max(1.0, float(ref["o"].abs().max()))
+    fin = torch.isfinite(ref["L"])
+    assert torch.equal(torch.isfinite(L), fin)
+    assert maxdiff(L[fin], ref["L"][fin]) <= 2e-3 * max(1.0, float(ref["L"][fin].abs().max()))
+    for got, key in zip(grads[:3], ("dq", "dk", "dv")):  # the backward consumes this lse
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+
+
+def test_fwd128_dense_exact_second_pass_and_masked_bias():
+    """logits beyond the sweep's range (the workgroup's exact second pass: flag in the bias ring, accumulators rescaled in AGPRs) and a bias with finfo.min columns
+    (`use_masking`, modeling_flash_t5.py:266-270)"""
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    B, H, S = 2, 2, 1024
+    q, k, v, b, do = make_inputs(B, H, S, S, D, torch.bfloat16, "1h", seed=21, strided=True)
+    b = b.clone()
+    b[..., 900:] = torch.finfo(torch.bfloat16).min
+    b[:, 0, :512, 300:400] = 150.0   # 150 nats: 2^216 -- rows 0..511 of head 0 leave the sweep's range, the others stay inside
+    ref = oracle_all(q, k, v, b, do, 0.05, False)
+    plan = AttentionPlan(q, k, v, do, bias=b, causal=False, sm_scale=0.05, variant=_lib.V_FWD64_ON)
+    plan.forward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(plan.o.float()).all()
+    assert maxdiff(plan.o, ref["o"]) <= bound(ref["o"], torch.bfloat16)
+    assert maxdiff(plan.lse, ref["L"]) <= 2e-3 * float(ref["L"].abs().max())
