@@ -222,6 +222,34 @@ def reference_shape_bench(device):
     return out
 
 
+def d128_forward_bench(device):
+    """head_dim 128 (the reference benchmarks d_head 64 and 128: benchmarks/bench_fa2_bias.py): forward of (4,12,S,128) bf16, non-causal, with the T5 bias generated
+    in-kernel and with the reference's dense (1,12,S,S) bias -- the pipelined 64-row body at one wave per SIMD (round 5)."""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    out = {}
+    for S in (1024, 2048, 8192):
+        g = torch.Generator().manual_seed(S)
+        q, k, v, do = (torch.randn(4, S, 12, 128, generator=g).to(torch.bfloat16).to(device).permute(0, 2, 1, 3) for _ in range(4))
+        table = (torch.randn(NUM_BUCKETS, 12, generator=g) * 0.5).to(device)
+        bias = torch.randn(1, 12, S, S, generator=g).to(torch.bfloat16).to(device)
+        f = 4.0 * 4 * 12 * S * S * 128
+        row = {}
+        for mode, kw in (("rpe", dict(rpe1d=pe.rpe1d_from_table(table, True, NUM_BUCKETS, MAX_DISTANCE), radius=MAX_DISTANCE, need_dbias=False)),
+                         ("dense", dict(bias=bias, need_dbias=False))):
+            plan = AttentionPlan(q, k, v, do, sm_scale=128 ** -0.5, **kw)
+            plan.forward()
+            st = event_stats(plan.forward, 20 if S <= 2048 else 5, reps=3)
+            row[mode] = {"fwd_ms": round(st["median"], 4), "fwd_tflops": round(f / st["median"] / 1e9, 1), "fwd_frac_of_peak": round(f / st["median"] / 1e9 / PEAK_BF16_TFLOPS, 4),
+                         "kernel": plan.describe()["fwd"]}
+            del plan
+        out[str(S)] = row
+        del q, k, v, do, bias
+        torch.cuda.empty_cache()
+    out["what"] = "(4,12,S,128) bf16 forward, non-causal, (B,S,H,D)-strided inputs; T5 bias in-kernel / dense (1,12,S,S) bias; median of 3 event-timed batches"
+    return out
+
+
 def dense_by_seq_bench(device):
     """The reference's own operator at the metric's sizes: (4,12,S,64) bf16, non-causal, a dense (1,12,S,S) bias shared by the batch + its gradient
     (flash_attention_v2_bias(q, k, v, bias); modeling_flash_t5.py:280-285).  FLOPs as everywhere (benchmarks/bench_fa2_bias.py:10-13)."""
@@ -870,6 +898,7 @@ def main():
                 out["eager_autograd"] = eager_autograd(S, device)
                 out["rowwise"] = rowwise_bench(device)
                 out["reference_shape"] = reference_shape_bench(device)
+                out["d128_forward"] = d128_forward_bench(device)
                 out["dense_by_seq"] = dense_by_seq_bench(device)
                 out["n3_fusions"] = n3_bench(device)
                 out["cpu_baseline"] = cpu_baseline(512)

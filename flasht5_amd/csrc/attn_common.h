@@ -338,6 +338,7 @@ struct AttnArgs {
   uint32_t mg_mix[4];                // ... of the mixed forward launch's divisors a_lo + 1, a_lo, b_hi, b_lo
   int32_t mix_na, mix_a_lo, mix_k_hi;  // forward, mixed launch (attn_fwd64_mixed_kernel): 256-row workgroups in total / per pair (low) / pairs per XCD with one more
   int32_t dvalid;           // valid head-dim columns: = D except head_dim 16, which runs the D = 32 instantiations with columns 16..31 read as zeros and never written
+  int32_t ref_first;        // forward sweep, bf16 without the T5 table: reference point of every row = its maximum over the first tile instead of 0 (large logits: see attn_fwd64.h)
   int32_t lds_stage;        // 64-wide backward bodies: the register-resident operands arrive / the outputs leave through wave-private LDS images (set by the launcher when the LDS fits)
   float scale;
 };

@@ -259,6 +259,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // row sends the workgroup through the exact pass (the check the bf16 sweep has for 2^100); what lies far BELOW that maximum
   // is flushed, as negligible beside the row's own first tile as it is in the exact algorithm.  (dense bias: bf16 only)
   constexpr bool OPT = FAT5_OPTIMISTIC && (BF16 || !DENSE);
+  // reference point of the sweep: 0 for every row (bf16 with the T5 table: the band blocks would pay an add per element; T5 logits are small), else the rows'
+  // first-tile maxima -- always in fp16, in bf16 when the launcher asks for it (large sm_scale * sqrt(D)): the addend of the FMA either way, no extra instruction
+  constexpr bool REF0 = BF16 && BIAS == FAT5_BIAS_RPE1D;
+  const bool ref_first = !BF16 || (!REF0 && a.ref_first != 0);
   if (OPT && !D3 && tid == 0) *sFlag = 0;
 
   f32x16 oacc[2][DB];
@@ -663,8 +667,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
       auto bias_f = [&]<int C>() {  // chunk C: its two bias values in log2 units
         constexpr int cq = C >> 3, cr = 2 * (C & 7);
         const uint32_t wd = Bw[cq][cr >> 2][(cr & 3) >> 1];
-        Bf[C][0] = asm_mulf(asm_shl16(wd), kLog2e);
-        Bf[C][1] = asm_mulf(asm_and_hi(wd), kLog2e);
+        Bf[C][0] = asm_fma(asm_shl16(wd), kLog2e, cq == 0 ? ad0 : ad1);  // (ad = - the row's reference point)
+        Bf[C][1] = asm_fma(asm_and_hi(wd), kLog2e, cq == 0 ? ad0 : ad1);
       };
       static_for<32>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
@@ -869,8 +873,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           const uint32_t wd = Bw[cq][cr >> 2][(cr & 3) >> 1];
           float b0, b1;
           if constexpr (BF16) {
-            b0 = asm_mulf(asm_shl16(wd), kLog2e);
-            b1 = asm_mulf(asm_and_hi(wd), kLog2e);
+            b0 = asm_fma(asm_shl16(wd), kLog2e, cq == 0 ? ad0 : ad1);  // (ad = - the row's reference point)
+            b1 = asm_fma(asm_and_hi(wd), kLog2e, cq == 0 ? ad0 : ad1);
           } else {
             const f16x2_t hv = __builtin_bit_cast(f16x2_t, wd);
             b0 = (float)hv[0] * kLog2e;
@@ -968,7 +972,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // every merge (tuple copies, spilled accumulators).
   auto pipe_run = [&]<bool BAND>(int& t, const int te, int& slot, const float cst) {
     // the exponent's addend per query block: the tile-constant bias minus the row's reference point (bf16: 0; fp16: m_run, fixed during the sweep)
-    const float ad0 = BF16 ? cst : cst - m_run[0], ad1 = BF16 ? cst : cst - m_run[1];
+    const float ad0 = REF0 ? cst : cst - m_run[0], ad1 = REF0 ? cst : cst - m_run[1];
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
       begin_iter(tt, SL, true);
@@ -1041,7 +1045,7 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
       for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
-      m_run[qb] = (nomax && BF16) ? 0.f : -INFINITY;
+      m_run[qb] = (nomax && !ref_first) ? 0.f : -INFINITY;
       l_run[qb][0] = l_run[qb][1] = 0.f;
     }
     if (pass > 0) {
@@ -1053,12 +1057,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     int t = 0, slot = 0;
     if constexpr (OPT) {
       if (nomax) {
-        if constexpr (!BF16) {
-          // fp16: the reference point of every row = its maximum over the first tile (scores only); a row that sees none of its keys: 0
+        if (ref_first) {
+          // fp16, and bf16 on request (a.ref_first): the reference point of every row = its maximum over the first tile (scores only); a row that sees none of its
+          // keys there, or nothing but masked-out bias entries (finfo.min: left padding), keeps 0
           if (nt > 0) tile_exact.template operator()<0, false, true>(0, 0, 0.f);
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb)
-            if (m_run[qb] == -INFINITY) m_run[qb] = 0.f;
+            if (!(m_run[qb] > -0x1p100f)) m_run[qb] = 0.f;
         }
         if (t_full > 0) {
           // fill: scores of the wave's first block, nothing pending

@@ -122,6 +122,10 @@ void fill_common(const fat5_attn_params* p, AttnArgs& a) {
   }
   a.B = p->B; a.H = p->H; a.M = p->M; a.N = p->N;
   a.dvalid = p->D;
+  // forward, pipelined sweep: with reference point 0 a row whose largest logit passes ~69 nats (2^100) sends its workgroup through the exact pass again.  The reference
+  // benchmarks at sm_scale 1.3 on unit-variance inputs (benchmarks/bench_fa2_bias.py): logits of sigma 1.3 sqrt(D) = 10 .. 15 nats -- at d_head 128 a third of the
+  // workgroups repeated (272 vs 130 us).  From sigma 8 on the sweep takes the rows' maxima over the first tile as reference point (a scores-only pre-pass of one tile).
+  a.ref_first = std::fabs(p->sm_scale) * std::sqrt((float)p->D) >= 8.f;
   a.causal = p->causal; a.scale = p->sm_scale; a.R = p->rpe_radius;
   a.bias = (const uint16_t*)p->bias; a.rpe1d = p->rpe1d;
   a.cu_q = p->cu_seqlens_q; a.cu_k = p->cu_seqlens_k;
@@ -203,7 +207,10 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
   const bool dense128 = p->D == 128 && p->bias_mode == FAT5_BIAS_DENSE && p->dtype == FAT5_BF16 && !p->cu_seqlens_q && f64_env != 0 &&
                         ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) && (p->bias_stride[1] % 8 == 0) &&
                         (p->bias_stride[2] % 8 == 0) && smem_fwd64_d128(0, FAT5_BIAS_DENSE) <= 160 * 1024 &&
-                        (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024 && !(p->causal && p->N < 2048)));
+                        // (measured, us, 64-row vs 32-row body: (16,12,1024) 127 vs 244, causal 130 vs 213; (4,12,8192) 1872 vs 3734; (2,12,1024) 39.6 vs 48.8, (1,12,2048) 68.8 vs 83.4,
+                        //  (4,12,1024) causal 45.7 vs 66.9; (1,12,1024) -- 192 waves -- 38.2 vs 26.4)
+                        //  (16,12,512) 49.0 vs 74.9, causal 58.3 vs 75.8)
+                        (f64_env == 1 || (waves64 >= cu_scaled(384) && (p->N >= 1024 || (p->N >= 512 && waves64 >= cu_scaled(1536)))));
   if (dense64 || dense128) {
     c.fwd64 = true;
     c.ksplit = false;

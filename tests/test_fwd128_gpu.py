@@ -184,3 +184,30 @@ def test_fwd128_dense_exact_second_pass_and_masked_bias():
     assert torch.isfinite(plan.o.float()).all()
     assert maxdiff(plan.o, ref["o"]) <= bound(ref["o"], torch.bfloat16)
     assert maxdiff(plan.lse, ref["L"]) <= 2e-3 * float(ref["L"].abs().max())
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("Dh,mode", [(128, "dense"), (128, "none"), (64, "dense"), (64, "none")])
+def test_large_scale_takes_the_first_tile_reference_point(Dh, mode, causal):
+    """sm_scale 1.3 on unit-variance inputs (the reference's benchmark, benchmarks/bench_fa2_bias.py): logits of sigma 10 .. 15 nats.  From sm_scale * sqrt(D) >= 8 on the
+    bf16 sweep takes the rows' first-tile maxima as reference point instead of 0 (no second pass for rows beyond 69 nats).  A padded bias (finfo.min columns): part of
+    the first tile (causal case), or all of it and half of the second -- left padding: the rows keep reference point 0 (non-causal case).  (No row is left without
+    an unmasked key: the fp32 oracle does not normalise such rows -- its exp(x - L) absorbs ln(l) beside 3e38 -- while the kernels, like the reference, return the mean of V.)"""
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    B, H, S = 2, 2, 1024
+    q, k, v, b, do = make_inputs(B, H, S, S, Dh, torch.bfloat16, "1h" if mode == "dense" else None, seed=31, strided=True)
+    if b is not None:
+        b = b.clone()
+        if causal:
+            b[:, 1, :, 32:96] = torch.finfo(torch.bfloat16).min
+        else:
+            b[:, 1, :, :96] = torch.finfo(torch.bfloat16).min
+    ref = oracle_all(q, k, v, b, do, 1.3, causal)
+    plan = AttentionPlan(q, k, v, do, bias=b, causal=causal, sm_scale=1.3, variant=_lib.V_FWD64_ON)
+    assert plan.describe()["fwd"].startswith("64row")
+    plan.forward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(plan.o.float()).all()
+    assert maxdiff(plan.o, ref["o"]) <= bound(ref["o"], torch.bfloat16)
+    assert maxdiff(plan.lse, ref["L"]) <= 2e-3 * float(ref["L"].abs().max())
