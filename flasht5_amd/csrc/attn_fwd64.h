@@ -420,6 +420,13 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
     }
   const float c2 = a.scale * kLog2e;
   const bool fold_ok = c2 > 0.f;
+  // Masked blocks inside the pipelined sweep (round 5; bias none / dense): the FMA's addend of a masked (key, row) position is -inf (p = 0) -- the causal diagonal
+  // and the key tail cost two VALU ops (compare, select) per element of the blocks that carry a mask instead of an unpipelined tile each.  limq: last visible key
+  // of the lane's row, minus the lane's 4 hi (register r <-> key crow(r, 0) + 4 hi).
+  constexpr bool PMASK = BIAS != FAT5_BIAS_RPE1D;
+  int limq[2] = {0, 0};
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) limq[qb] = (a.causal ? min(N - 1, qrow0 + 32 * qb + lq + P) : N - 1) - 4 * hi;
   float cst_neg = 0.f, cst_pos = 0.f;
   // band tiles of the pipelined sweep: LDS byte address of entry 0 of this lane's table copy, and the lane's position term
   // (index of block-relative key 0 for query block qb; see tile_exact: R + nb + 4 hi - qrow - ((R - qrow) & 3))
@@ -636,7 +643,18 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // and pads no hazards for them -- the youngest MFMA result they read (S'[0], finished by MFMA 14) is two MFMA issue
   // periods old when chunk 0 of the next block reads it.
   constexpr int NSTEP = KSPLIT ? 64 : 32;  // first key of a wave's next block minus first key of this one
-  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND>(const float ad0, const float ad1, const int nbS, [[maybe_unused]] const int tt = 0) {
+  auto pipe_block = [&]<int KS, int KB, int VS, int VB, bool BAND, bool MK = false>(const float ad0, const float ad1, const int nbS, [[maybe_unused]] const int tt = 0) {
+    static_assert(!(MK && BAND), "masked pipelined blocks: bias none / dense");
+    // MK: the block whose softmax is due (first key nbS) carries a mask: element r of query block qb is masked when crow(r, 0) > dlm[qb]
+    [[maybe_unused]] int dlm[2] = {0, 0};
+    if constexpr (MK) {
+      dlm[0] = limq[0] - nbS;
+      dlm[1] = limq[1] - nbS;
+    }
+    auto madd = [&]<int QB, int R>(const float v) {  // the addend of element (QB, R)
+      if constexpr (MK) return crow(R, 0) > dlm[QB] ? -INFINITY : v;
+      else return v;
+    };
     static_assert(D == 64 || D == 128, "gap schedules written for D = 64 (16 MFMAs, 16 two-element chunks per block) and D = 128 (32 MFMAs)");
     constexpr uint32_t koff = KS * TILE + KB * 32 * 2 * D, voff = VS * TILE + VB * 32 * 2 * D;
     if constexpr (W1) {
@@ -736,8 +754,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           constexpr int cc = g >> 1, cq = cc >> 3, cr = 2 * (cc & 7);
           if constexpr (DENSE) {
             if constexpr (cc == 0) bias_f.template operator()<0>();
-            X[cc][0] = asm_fma(S[cq][cr], c2, Bf[cc][0]);
-            X[cc][1] = asm_fma(S[cq][cr + 1], c2, Bf[cc][1]);
+            X[cc][0] = asm_fma(S[cq][cr], c2, madd.template operator()<cq, cr>(Bf[cc][0]));
+            X[cc][1] = asm_fma(S[cq][cr + 1], c2, madd.template operator()<cq, cr + 1>(Bf[cc][1]));
           } else if constexpr (BAND) {
             float t0 = __uint_as_float(T[cq][cr >> 2][cr & 3]), t1 = __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]);
             if constexpr (!BF16) {
@@ -747,8 +765,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
             X[cc][0] = asm_fma(S[cq][cr], c2, t0);
             X[cc][1] = asm_fma(S[cq][cr + 1], c2, t1);
           } else {
-            X[cc][0] = asm_fma(S[cq][cr], c2, cq == 0 ? ad0 : ad1);
-            X[cc][1] = asm_fma(S[cq][cr + 1], c2, cq == 0 ? ad0 : ad1);
+            X[cc][0] = asm_fma(S[cq][cr], c2, madd.template operator()<cq, cr>(cq == 0 ? ad0 : ad1));
+            X[cc][1] = asm_fma(S[cq][cr + 1], c2, madd.template operator()<cq, cr + 1>(cq == 0 ? ad0 : ad1));
           }
         } else {
           constexpr int c = g >> 1;
@@ -880,8 +898,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
             b0 = (float)hv[0] * kLog2e;
             b1 = (float)hv[1] * kLog2e;
           }
-          X[g][0] = asm_fma(S[cq][cr], c2, b0);
-          X[g][1] = asm_fma(S[cq][cr + 1], c2, b1);
+          X[g][0] = asm_fma(S[cq][cr], c2, madd.template operator()<cq, cr>(b0));
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, madd.template operator()<cq, cr + 1>(b1));
         } else if constexpr (BAND) {
           float t0 = __uint_as_float(T[cq][cr >> 2][cr & 3]), t1 = __uint_as_float(T[cq][cr >> 2][(cr & 3) + 1]);
           if constexpr (!BF16) {  // (fp16: table entry minus the row's reference point -- in bf16 the reference point is 0)
@@ -891,8 +909,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           X[g][0] = asm_fma(S[cq][cr], c2, t0);
           X[g][1] = asm_fma(S[cq][cr + 1], c2, t1);
         } else {
-          X[g][0] = asm_fma(S[cq][cr], c2, cq == 0 ? ad0 : ad1);
-          X[g][1] = asm_fma(S[cq][cr + 1], c2, cq == 0 ? ad0 : ad1);
+          X[g][0] = asm_fma(S[cq][cr], c2, madd.template operator()<cq, cr>(cq == 0 ? ad0 : ad1));
+          X[g][1] = asm_fma(S[cq][cr + 1], c2, madd.template operator()<cq, cr + 1>(cq == 0 ? ad0 : ad1));
         }
       }
       // chunk c is packed in gap c + 2: a group of four words is summed two gaps after its last one (the previous block's last group,
@@ -970,17 +988,17 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
   // reads K(t) and K(t+1) (scores one block ahead) and V(t) -- inside the ring protocol's window.  Steady state: NS tiles (ring
   // slots 0 .. NS-1) per trip, straight-line -- a slot switch inside the loop makes the register allocator reconcile the bodies at
   // every merge (tuple copies, spilled accumulators).
-  auto pipe_run = [&]<bool BAND>(int& t, const int te, int& slot, const float cst) {
+  auto pipe_run = [&]<bool BAND, bool MK = false>(int& t, const int te, int& slot, const float cst) {
     // the exponent's addend per query block: the tile-constant bias minus the row's reference point (bf16: 0; fp16: m_run, fixed during the sweep)
     const float ad0 = REF0 ? cst : cst - m_run[0], ad1 = REF0 ? cst : cst - m_run[1];
     auto one_tile = [&]<int SL>(int tt) {
       constexpr int S1 = (SL + 1) % NS;
       begin_iter(tt, SL, true);
       if constexpr (KSPLIT) {
-        pipe_block.template operator()<S1, 0, SL, 0, BAND>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
+        pipe_block.template operator()<S1, 0, SL, 0, BAND, MK>(ad0, ad1, tt * BN + 32 * kh);  // (the wave's key block: folded into its lane bases)
       } else {
-        pipe_block.template operator()<SL, 1, SL, 0, BAND>(ad0, ad1, tt * BN, tt);
-        pipe_block.template operator()<S1, 0, SL, 1, BAND>(ad0, ad1, tt * BN + 32, tt);
+        pipe_block.template operator()<SL, 1, SL, 0, BAND, MK>(ad0, ad1, tt * BN, tt);
+        pipe_block.template operator()<S1, 0, SL, 1, BAND, MK>(ad0, ad1, tt * BN + 32, tt);
       }
       end_iter(tt);
     };
@@ -1065,7 +1083,10 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
           for (int qb = 0; qb < 2; ++qb)
             if (!(m_run[qb] > -0x1p100f)) m_run[qb] = 0.f;
         }
-        if (t_full > 0) {
+        // PMASK: whole trips of unmasked tiles first, then every tile up to nt in the masked form of the pipelined block (the visible tiles of its first trip
+        // pay the mask arithmetic as well: nothing masked)
+        const int te1 = PMASK ? t_full / NS * NS : t_full;
+        if (PMASK ? nt > 0 : t_full > 0) {
           // fill: scores of the wave's first block, nothing pending
           {
             u32x4 kf[KK];
@@ -1091,7 +1112,8 @@ FAT5_DEV void attn_fwd64_body(const AttnArgs& a, const int b, const int h, const
               BN0 = lds_rd64(bA[0][0]);
               BN1 = lds_rd64(bA[0][1]);
             }
-            pipe_run.template operator()<false>(t, t_full, slot, 0.f);
+            pipe_run.template operator()<false>(t, te1, slot, 0.f);
+            if constexpr (PMASK) pipe_run.template operator()<false, true>(t, nt, slot, 0.f);
           }
           pipe_drain();
           merge_lacc();

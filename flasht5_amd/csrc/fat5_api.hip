@@ -225,7 +225,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
       // (measured, us, 64-row vs 32-row body, tools/attn_time.py --D 128: (4,12,1024) 30.6 vs 39.8, (2,12,2048) 51.3 vs 63.5, (1,12,4096) 94.8 vs 120.6, (16,12,4096) 1305 vs 1628,
       //  (4,12,8192) 1265; below 768 waves it loses -- (2,12,1024) 27.3 vs 22.4 -- and at 512 keys it ties: (16,12,512) 39.7 vs 39.8.  Plain causal (diagonal
       //  tiles unpipelined): (16,12,1024) 105 vs 93, (4,12,2048) 87.5 vs 88.2, (16,12,4096) 843 vs 893; with the T5 table carrying the mask: (16,12,1024) 88.7 vs 96.6)
-      (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024 && !(p->causal && !ctab && p->N < 2048)))) {
+      //  (masked blocks inside the pipelined sweep, round 5: plain causal (16,12,1024) 92.3 vs 92.6, (4,12,1024) 32.2 vs 38.5, (4,12,4096) 237 vs 259)
+      (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024))) {
     c.fwd64 = true;
     c.n_mblk = (p->M + 255) / 256;
     c.nw = bh * c.n_mblk <= chip_cus() ? 5 : 4;  // (5: ring requests spread over the MFMA gaps -- one partial round, every CU in the same phase: (4,12,1024) 32.4 vs 38.7 us)

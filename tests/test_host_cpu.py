@@ -348,7 +348,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="64row", dq="32row", dkdv="32key")),            # head_dim 128 (round 5): the forward on the pipelined body, one wave per SIMD
         (dict(B=2, H=12, M=1024, N=1024, D=128), dict(fwd="32row-split")),                                     # ... from 768 waves of 64 rows on
         (dict(B=4, H=12, M=1024, N=1024, D=128), dict(fwd="64row")),
-        (dict(B=16, H=12, M=1024, N=1024, D=128, causal=True), dict(fwd="32row")),                        # plain causal: from 2048 keys
+        (dict(B=16, H=12, M=1024, N=1024, D=128, causal=True), dict(fwd="64row")),                        # plain causal: diagonal blocks masked inside the pipelined sweep
         (dict(B=16, H=12, M=1024, N=1024, D=128, **dense), dict(fwd="64row")),                            # the d_head 128 rows of the reference benchmark
         # forced per call
         (dict(B=4, H=12, M=1024, N=1024, variant=L.V_KV64_ON | L.V_KV64_HALF_ON | L.V_Q64_ON | L.V_FWD64_OFF), dict(fwd="32row", dq="64row", dkdv="64key-half")),
