@@ -21,7 +21,7 @@ ap.add_argument("--S", default="512,2048,8192"); ap.add_argument("--modes", defa
 ap.add_argument("--variant", type=int, default=0); ap.add_argument("--B", type=int, default=4); ap.add_argument("--H", type=int, default=12)
 ap.add_argument("--D", type=int, default=64); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--causal", action="store_true")
 ap.add_argument("--radius", type=int, default=128); ap.add_argument("--no-dbias", action="store_true")
-ap.add_argument("--iters", type=int, default=20); ap.add_argument("--reps", type=int, default=5); ap.add_argument("--eager", action="store_true")
+ap.add_argument("--contig", action="store_true"); ap.add_argument("--randbias", action="store_true"); ap.add_argument("--scale", type=float, default=0.125); ap.add_argument("--iters", type=int, default=20); ap.add_argument("--reps", type=int, default=5); ap.add_argument("--eager", action="store_true")
 a = ap.parse_args()
 dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 STAGE = {"bwd": 7, "dq": 1, "dkdv": 2, "red": 4, "dq+dkdv": 3}
@@ -38,14 +38,14 @@ def prewarm(fn, seconds=0.15):  # leave the idle clock
 
 for S in (int(x) for x in a.S.split(",")):
     for mode in a.modes.split(","):
-        q, k, v, _, do = make_inputs(a.B, a.H, S, S, a.D, dtype, None, seed=1, strided=True)
+        q, k, v, _, do = make_inputs(a.B, a.H, S, S, a.D, dtype, None, seed=1, strided=not a.contig)
         table = (torch.randn(32, a.H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
         kw = {}
         if mode == "rpe":
             kw = dict(rpe1d=pe.rpe1d_from_table(table, max_distance=a.radius), radius=a.radius)
         elif mode == "dense":
-            kw = dict(bias=pe.compute_bias(table, S, S).to(dtype).contiguous())
-        plan = AttentionPlan(q, k, v, do, causal=a.causal, sm_scale=0.125, need_dbias=not a.no_dbias, variant=a.variant or None, **kw)
+            kw = dict(bias=(torch.randn(1, a.H, S, S, generator=torch.Generator().manual_seed(2)).to(dtype).cuda() if a.randbias else pe.compute_bias(table, S, S).to(dtype).contiguous()))
+        plan = AttentionPlan(q, k, v, do, causal=a.causal, sm_scale=a.scale, need_dbias=not a.no_dbias, variant=a.variant or None, **kw)
         plan.forward(); plan.backward(); torch.cuda.synchronize()
         f = 4.0 * a.B * a.H * S * S * a.D / (2 if a.causal else 1)
         cells = []

@@ -3,7 +3,7 @@ kernel body and with each body forced (fat5_attn_params.variant) -- graph replay
 wherever the default is more than 5 % behind the best forced variant.  How the causal mis-dispatch of round 3 was found
 ((16,12,1024) causal: the 64-wide backward bodies 20 % behind the 32-wide ones).
 
-    python tools/dispatch_audit.py [--bh 4x12,16x12] [--S 512,1024,2048,4096,8192] [--modes none,rpe] [--quick]"""
+    python tools/dispatch_audit.py [--bh 4x12,16x12] [--S 512,1024,2048,4096,8192] [--modes none,rpe,dense] [--D 64|128] [--stages fwd] [--scale 0.125]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +15,8 @@ from flasht5_amd import positional_encoding as pe, _lib as L
 ap = argparse.ArgumentParser()
 ap.add_argument("--bh", default="4x12,8x12,16x12"); ap.add_argument("--S", default="512,1024,2048,4096,8192"); ap.add_argument("--modes", default="none,rpe")
 ap.add_argument("--max-work", type=float, default=48 * 8192.0 ** 2 * 1.01)
+ap.add_argument("--D", type=int, default=64); ap.add_argument("--scale", type=float, default=0.125)
+ap.add_argument("--stages", default="fwd,dq,dkdv,bwd")  # (head_dim 128: --stages fwd -- only the forward has more than one body there)
 ap.add_argument("--MN", default="")  # rectangular problems instead of --S: "512x1024,2048x512" (M x N)
 a = ap.parse_args()
 
@@ -54,20 +56,25 @@ for bh in a.bh.split(","):
             continue
         for causal in (False, True):
             for mode in a.modes.split(","):
-                q, k, v, _, do = make_inputs(B, H, M, S, 64, torch.bfloat16, None, seed=1, strided=True)
+                q, k, v, _, do = make_inputs(B, H, M, S, a.D, torch.bfloat16, None, seed=1, strided=True)
                 table = (torch.randn(32, H, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
                 kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128) if mode == "rpe" else {}
                 if mode == "dense":
                     kw = dict(bias=pe.compute_bias(table, M, S).to(torch.bfloat16).contiguous())
-                plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=0.125, **kw)
-                plan.forward(); plan.backward(); torch.cuda.synchronize()
+                plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=a.scale, **kw)
+                stages = a.stages.split(",")
+                plan.forward(); torch.cuda.synchronize()
+                if stages != ["fwd"]:
+                    plan.backward(); torch.cuda.synchronize()
                 it = max(2, min(20, int(2e10 / (B * H * float(M) * S))))
                 line = f"({B:2d},{H},{M:5d}x{S:5d}) {'causal' if causal else 'full  '} {mode:4s}"
                 fused = plan.bwd_launches() == 1  # (short problems: dQ and dK/dV share ONE launch -- the stage timings below are not the real path)
                 dense = mode == "dense"
                 kvt = {k_: v_ for k_, v_ in KV.items() if not (dense and k_ in ("64key-half", "64key-mixed"))}
-                for stage, table_, fn in (("fwd", FWD if not dense else {k_: v_ for k_, v_ in FWD.items() if k_ in ("default", "32row", "64row")}, plan.forward),
+                for stage, table_, fn in (("fwd", FWD if not (dense or a.D != 64) else {k_: v_ for k_, v_ in FWD.items() if k_ in ("default", "32row", "64row")}, plan.forward),
                                           ("dq", DQ_DENSE if dense else DQ, (lambda: plan.backward(5)) if dense else (lambda: plan.backward(1))), ("dkdv", kvt, lambda: plan.backward(2))):
+                    if stage not in stages:
+                        continue
                     if fused and stage != "fwd":
                         line += f" | {stage}: (fused launch)"
                         continue
@@ -82,10 +89,14 @@ for bh in a.bh.split(","):
                     if bad:
                         flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
                 res = {}
-                for name, bits in (BWD.items() if not dense else {"default": 0, "round4": L.V_QDB64_OFF | L.V_KV64_OFF}.items()):
+                for name, bits in () if "bwd" not in stages else (BWD.items() if not dense else {"default": 0, "round4": L.V_QDB64_OFF | L.V_KV64_OFF}.items()):
                     plan.set_variant(bits)
                     res[name] = gpu_time(lambda: plan.backward(7 if dense else 3), it)
                 plan.set_variant(0)
+                if not res:
+                    print(line, flush=True)
+                    del plan, q, k, v, do
+                    continue
                 best = min((t, n) for n, t in res.items() if n != "default")
                 bad = res["default"] > 1.05 * best[0]
                 line += f" | bwd: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
