@@ -67,9 +67,10 @@ FAT5_DEV constexpr int qdb_word(int r) { return qdb_key(r, 0) >> 1; }
 
 // PARTIAL: the sums go out as fp32 (one (H, M, N) slab per group of four batch elements) instead of the final 16-bit dbias
 // ONE: 1 / scale is itself a 16-bit value (1: T5, 8: the default) -- one selector term, 16 bias rows per MFMA: four bias MFMAs per step instead of eight
+// bid: the workgroup's index among the body's own (the launch may hold other workgroups in front: attn_bwd_dfused64_kernel; a multiple of eight of them, so that
+// bid % 8 stays the XCD); wstats: write the row statistics the dK/dV kernels read (a.stat2) -- off when bwd_stat2_kernel wrote them ahead of the launch
 template <int D, bool BF16, bool PARTIAL, bool ONE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
+FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int bid, const bool wstats) {
   static_assert(D == 64 && BF16, "gap schedule written for D = 64, bf16");
   using Cfg = BwdQdb64Cfg<D>;
   constexpr int IMG = Cfg::IMG, BT = Cfg::BT;
@@ -84,7 +85,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
   const int ngrp = (a.B + 3) >> 2;
   int pair, mblk;
   {
-    const int W = a.H * ngrp * a.n_mblk, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int W = a.H * ngrp * a.n_mblk, x = bid & 7, idx = bid >> 3;
     const int base = W >> 3, rem = W & 7;
     if (idx >= base + (x < rem ? 1 : 0)) return;  // (grid = 8 ceil(W / 8))
     const int item = x * base + min(x, rem) + idx;
@@ -171,7 +172,7 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       if (bvalid && a.delta && qrow < M && hi == 0) a.delta[stat_off + qrow] = delta;
       const float Lq = Lq_[qb];
       nL2[qb] = (Lq < kDeadRowLse || !bvalid) ? -INFINITY : -Lq * kLog2e;  // (dead rows: attn_bwd.h)
-      if (bvalid && a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
+      if (wstats && bvalid && a.stat2 && hi == 0 && qrow < (M + 31) / 32 * 32) {
         float* st = a.stat2 + (((int64_t)b * a.H + h) * ((M + 31) / 32) + (qrow >> 5)) * 64 + (qrow & 31);
         const bool live = qrow < M && !(Lq < kDeadRowLse);
         st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
@@ -720,6 +721,72 @@ void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
       const u32x4 v4 = *reinterpret_cast<const u32x4*>(img + row * (2 * D) + slot * 16);
       if (qw0 + row < M) *reinterpret_cast<u32x4*>(dqb_ + (int64_t)(qw0 + row) * a.dqs[2] + ((slot ^ swz<D>(row)) << 3)) = v4;
     }
+  }
+}
+
+template <int D, bool BF16, bool PARTIAL, bool ONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_qdb64_kernel(const AttnArgs a, void* dbias_out) {
+  attn_bwd_qdb64_body<D, BF16, PARTIAL, ONE>(a, dbias_out, (int)blockIdx.x, true);
+}
+
+// The whole dense-bias backward in ONE launch (round 5, second half; the dense counterpart of attn_bwd_fused64_kernel): workgroups [0, n_kv_blocks) -- a multiple
+// of eight, the padding exits -- run the 256-key dense dK/dV body (attn_bwd64.h), the others the dQ + dBias body above.  Separately the two launches of a short
+// sequence leave most of the chip idle twice ((4,12,512): 96 workgroups each on 256 CUs) and those of a mid one each end in a half-empty round ((4,12,2048):
+// 384 + 384 workgroups at one per CU).  The dK/dV half cannot wait for the dQ half's row statistics: bwd_stat2_kernel writes them ahead of the launch
+// (the reference's _bwd_preprocess, flash_attention_v2_bias.py:516-556) -- the same values bit for bit, so a call that runs the stages as separate launches
+// (a unit range, one stage only) returns identical results.
+template <int D, bool BF16, bool PARTIAL, bool ONE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void attn_bwd_dfused64_kernel(const AttnArgs a, void* dbias_out) {
+  const int nkv8 = (a.n_kv_blocks + 7) & ~7;
+  if ((int)blockIdx.x < nkv8) {
+    if ((int)blockIdx.x >= a.n_kv_blocks) return;
+    int b, h, nblk;
+    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+    attn_bwd_kv64_body<D, BF16, FAT5_BIAS_DENSE, false, false, ONE>(a, b, h, nblk, nblk, false);
+  } else {
+    attn_bwd_qdb64_body<D, BF16, PARTIAL, ONE>(a, dbias_out, (int)blockIdx.x - nkv8, false);
+  }
+}
+
+// Row statistics of the backward ahead of a launch whose dK/dV workgroups run beside the dQ ones: stat2[(b, h), step][0..31] = -L / scale (a dead or padded row: the
+// value whose probability is zero), [32..63] = -delta = -rowsum(o * do) (reference _bwd_preprocess, :516-556).  One wave per 32-row step, lane = (row, half of the
+// columns): the products of a row are summed in exactly the order of the dQ bodies' prologues (16-column groups ascending, low word first, the two halves last) --
+// the same bits.  a.delta gets the plain delta as there.
+template <int D, bool BF16>
+__global__ __launch_bounds__(256) void bwd_stat2_kernel(const AttnArgs a) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
+  const int nst = (a.M + 31) / 32;
+  const int64_t gs = (int64_t)blockIdx.x * 4 + w;  // (b, h, step), step minor
+  if (gs >= (int64_t)a.B * a.H * nst) return;
+  const int bh = (int)(gs / nst), st_i = (int)(gs - (int64_t)bh * nst);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qrow = 32 * st_i + lq, qr = min(qrow, a.M - 1);
+  const uint16_t* orow = a.o + (int64_t)b * a.os[0] + (int64_t)h * a.os[1] + (int64_t)qr * a.os[2];
+  const uint16_t* dorow = a.dout + (int64_t)b * a.dos[0] + (int64_t)h * a.dos[1] + (int64_t)qr * a.dos[2];
+  u32x4 of[D / 16], dof[D / 16];
+#pragma unroll
+  for (int kk = 0; kk < D / 16; ++kk) {
+    of[kk] = *reinterpret_cast<const u32x4*>(orow + 16 * kk + 8 * hi);
+    dof[kk] = *reinterpret_cast<const u32x4*>(dorow + 16 * kk + 8 * hi);
+  }
+  const float Lq = a.lse[(int64_t)bh * a.M + qr];
+  float dsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < D / 16; ++kk)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dsum = fmaf(cvt_lo<BF16>(of[kk][j]), cvt_lo<BF16>(dof[kk][j]), dsum);
+      dsum = fmaf(cvt_hi<BF16>(of[kk][j]), cvt_hi<BF16>(dof[kk][j]), dsum);
+    }
+  const float delta = pair_sum(dsum);
+  if (hi == 0) {
+    if (a.delta && qrow < a.M) a.delta[(int64_t)bh * a.M + qrow] = delta;
+    float* st = a.stat2 + ((int64_t)bh * nst + st_i) * 64 + lq;
+    const bool live = qrow < a.M && !(Lq < kDeadRowLse);
+    st[0] = live ? -Lq / a.scale : (a.scale > 0.f ? -INFINITY : INFINITY);
+    st[32] = qrow < a.M ? -delta : 0.f;
   }
 }
 

@@ -28,6 +28,38 @@ hipError_t launch_bwd_qdb64_d64(const AttnArgs& a, int bf16, void* dbias_out, in
   return one ? go(attn_bwd_qdb64_kernel<64, true, false, true>) : go(attn_bwd_qdb64_kernel<64, true, false, false>);
 }
 
+// The dense backward in one launch (attn_bwd_dfused64_kernel): the row statistics by bwd_stat2_kernel, then a.n_kv_blocks 256-key dK/dV workgroups (padded to a
+// multiple of eight) followed by the `grid_qdb` dQ + dBias workgroups.  a.n_nblk / a.part_stride as for launch_bwd_kv64_d64, a.stat2 set.
+hipError_t launch_bwd_dfused64_d64(const AttnArgs& a, int bf16, void* dbias_out, int partial, int grid_qdb, hipStream_t s) {
+  if (!bf16 || !a.stat2) return hipErrorInvalidValue;
+  const long nst = (a.M + 31) / 32, nsw = (long)a.B * a.H * nst;
+  hipLaunchKernelGGL((bwd_stat2_kernel<64, true>), dim3((unsigned)((nsw + 3) / 4)), dim3(256), 0, s, a);
+  hipError_t e0 = hipGetLastError();
+  if (e0 != hipSuccess) return e0;
+  AttnArgs as = a;
+  as.n_mblk = (a.M + 63) / 64;
+  const int nkv8 = (a.n_kv_blocks + 7) & ~7;
+  const int grid = nkv8 + (grid_qdb + 7) / 8 * 8;
+  as.mg_mblk = div_magic(as.n_mblk, grid);
+  as.mg_nblk = div_magic(as.n_nblk, grid);
+  as.mg_H = div_magic(as.H, grid);
+  as.lds_stage = 0;  // (the dense dK/dV body's ring leaves no room for staged K / V images: Bwd64Cfg)
+  constexpr int smem = BwdQdb64Cfg<64>::SMEM;
+  static_assert(Bwd64Cfg<64, false, false, true>::RINGB <= smem, "the dK/dV half's ring fits the dQ half's LDS");
+  const float inv = 1.f / a.scale;
+  uint32_t bits;
+  memcpy(&bits, &inv, 4);
+  const bool one = (bits & 0xffffu) == 0u;
+  auto go = [&](auto kern) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, as, dbias_out);
+    return hipGetLastError();
+  };
+  if (partial) return one ? go(attn_bwd_dfused64_kernel<64, true, true, true>) : go(attn_bwd_dfused64_kernel<64, true, true, false>);
+  return one ? go(attn_bwd_dfused64_kernel<64, true, false, true>) : go(attn_bwd_dfused64_kernel<64, true, false, false>);
+}
+
 hipError_t launch_dbias_partial_reduce(const float* part, void* out, int bf16, int ngrp, int H, int M, int N, int causal, hipStream_t s) {
   const int64_t HMN = (int64_t)H * M * N;
   const int grid = (int)((HMN / 8 + 255) / 256);

@@ -40,5 +40,7 @@ hipError_t launch_bwd_fused64_d64(const AttnArgs& a, int bf16, int bias, int nw,
 size_t smem_bwd_fused64_d64(int R, int bias);
 // dense (1, H, M, N) bias: dQ + the batch-reduced dbias, four batch elements per workgroup (attn_bwd_qdb64.h): bf16, D = 64
 hipError_t launch_bwd_qdb64_d64(const AttnArgs& a, int bf16, void* dbias_out, int partial, int grid, hipStream_t s);
+// ... and the whole dense backward in one launch: row statistics ahead (bwd_stat2_kernel), then a.n_kv_blocks 256-key dense dK/dV workgroups + the dQ + dBias ones
+hipError_t launch_bwd_dfused64_d64(const AttnArgs& a, int bf16, void* dbias_out, int partial, int grid_qdb, hipStream_t s);
 hipError_t launch_dbias_partial_reduce(const float* part, void* out, int bf16, int ngrp, int H, int M, int N, int causal, hipStream_t s);
 }  // namespace fat5

@@ -41,6 +41,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // 22.4 / 26.1; at S = 512 -- 384 waves -- only its key-split variant (128-row workgroups: 192 of them) keeps up with the
 // two-waves-per-32-rows split body of attn_fwd.h: 10.4 / 11.6 against 10.4 / 12.5 us)
 constexpr long kFwd64MinWaves = 384;
+constexpr long kDfusedMaxWg = 1152;  // dense one-launch backward (dfused64): up to this many workgroups of both halves together (x CUs / 256)
 
 // kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
 inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
@@ -54,6 +55,7 @@ struct BwdLayout {
   bool fused64;     // both 64-wide bodies in one launch when a call asks for both stages (attn_bwd_fused64_kernel); implies kv64 (256-key) and q64
   bool ds_staged;   // dense dS goes through the workspace and is reduced afterwards
   bool dbias_inkernel;  // dense (1, H, M, N) gradient by the batch-inner kernel (attn_bwd_dbias.h): nothing of size B*H*M*N
+  bool dfused64;    // dense (1, H, M, N) bias: the 256-key dense dK/dV workgroups and the dQ + dBias ones in ONE launch behind bwd_stat2_kernel (attn_bwd_dfused64_kernel); implies kv64 (256-key) and qdb64
   bool qdb64;       // dense (1, H, M, N) bias shared by the batch: dQ AND the batch-reduced dbias by attn_bwd_qdb64_kernel (four batch elements per workgroup)
   int qdb_groups;   // ... ceil(B / 4); > 1: fp32 slabs in the workspace + dbias_partial_reduce_kernel
   int n_nblk;
@@ -210,7 +212,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                         // (measured, us, 64-row vs 32-row body: (16,12,1024) 127 vs 244, causal 130 vs 213; (4,12,8192) 1872 vs 3734; (2,12,1024) 39.6 vs 48.8, (1,12,2048) 68.8 vs 83.4,
                         //  (4,12,1024) causal 45.7 vs 66.9; (1,12,1024) -- 192 waves -- 38.2 vs 26.4)
                         //  (16,12,512) 49.0 vs 74.9, causal 58.3 vs 75.8)
-                        (f64_env == 1 || (waves64 >= cu_scaled(384) && (p->N >= 1024 || (p->N >= 512 && waves64 >= cu_scaled(1536)))));
+                        //  (audit, profiles/r05_dispatch_audit_d128_fwd.log: (8,12,512) 27.7 vs 49.5, causal 28.6 vs 50.5; (4,12,512) 25.5 vs 28.5 -> from 512 keys at every size;
+                        //   causal below 768 waves and 2048 keys the 32-row body stays: (2,12,1024) causal 41.1 vs 36.9, (4,12,512) causal 23.5 either way)
+                        (f64_env == 1 || (waves64 >= cu_scaled(384) && p->N >= 512 && !(p->causal && waves64 < cu_scaled(768) && p->N < 2048)));
   if (dense64 || dense128) {
     c.fwd64 = true;
     c.ksplit = false;
@@ -226,7 +230,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
       //  (4,12,8192) 1265; below 768 waves it loses -- (2,12,1024) 27.3 vs 22.4 -- and at 512 keys it ties: (16,12,512) 39.7 vs 39.8.  Plain causal (diagonal
       //  tiles unpipelined): (16,12,1024) 105 vs 93, (4,12,2048) 87.5 vs 88.2, (16,12,4096) 843 vs 893; with the T5 table carrying the mask: (16,12,1024) 88.7 vs 96.6)
       //  (masked blocks inside the pipelined sweep, round 5: plain causal (16,12,1024) 92.3 vs 92.6, (4,12,1024) 32.2 vs 38.5, (4,12,4096) 237 vs 259)
-      (f64_env == 1 || (waves64 >= cu_scaled(768) && p->N >= 1024))) {
+      //  (audit, profiles/r05_dispatch_audit_d128_fwd.log: at 512 keys the body wins where its workgroups are one partial round -- (8,12,512) none 21.6 vs 24.9, T5 table 21.9 vs 26.6,
+      //   causal 22.9 vs 25.9 / 21.7 vs 25.6 -- and ties at 1.5 rounds: (16,12,512) 39.6 / 42.4 either way)
+      (f64_env == 1 || (waves64 >= cu_scaled(768) && (p->N >= 1024 || (p->N >= 512 && waves64 <= 4L * chip_cus()))))) {
     c.fwd64 = true;
     c.n_mblk = (p->M + 255) / 256;
     c.nw = bh * c.n_mblk <= chip_cus() ? 5 : 4;  // (5: ring requests spread over the MFMA gaps -- one partial round, every CU in the same phase: (4,12,1024) 32.4 vs 38.7 us)
@@ -479,6 +485,38 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     L.nw_kv = 4;
     L.n_nblk = (p->N + 255) / 256;
   }
+  // Dense (1, H, M, N) bias shared by the batch (the reference's own operator): is the dQ + dBias body (attn_bwd_qdb64.h) legal for this call?
+  const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
+  const int qdb_ngrp = (p->B + 3) / 4;
+  const bool qdb_legal = dense && p->dbias && p->D == 64 && p->dtype == FAT5_BF16 &&
+                         scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
+                         p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
+                         (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
+                         (int64_t)p->M * p->N * (qdb_ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
+                         ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+  // ... and both dense 64-wide bodies in ONE launch (attn_bwd_dfused64_kernel, round 5): the dense counterpart of fused64 -- the row statistics come from
+  // bwd_stat2_kernel ahead of the launch instead of from the dK/dV half itself.  Separately the two launches of a short sequence leave most of the chip idle
+  // twice ((4,12,512): 96 + 96 workgroups on 256 CUs) and those of a mid one each end in a half-empty round ((4,12,2048): 384 + 384).
+  L.dfused64 = false;
+  if (qdb_legal && dense_kv_ok && f64_env != 0 && qdb_env != 0 && b64_env != 0 && kvh_env != 1 && mix_env != 1 &&
+      !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL)) && smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024) {
+    const long nq = (long)p->H * qdb_ngrp * ((p->M + 63) / 64), tot = wg256 + nq;
+    // Measured, whole dense backward, one launch vs the same two bodies as separate launches (tools/attn_time.py --modes dense --what bwd, us; profiles/r05_dfused_time.log):
+    //   both halves in one round of the chip: (4,12,512) 28.4 vs 45.8 (and 45.2 for the 32-wide launch + staged dS it replaces), causal 31.2 vs 50.4;
+    //   three rounds: (4,12,2048) 230 vs 270, causal 182 vs 194; (8,12,1024) 150.5 vs 174.2; (16,12,512) 95.2 vs 104.2, causal 90.7 vs 101.0;
+    //   1.5 to 2 rounds lose what the statistics kernel costs -- (4,12,1024) 81.1 vs 77.6, (2,12,2048) 198 vs 189, (4,16,1024) 88.5 vs 86.2 -- and from six rounds on
+    //   nothing is left: (4,12,4096) 925 vs 922, (16,12,1024) causal 272.6 vs 273.8.
+    const bool rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 22) &&
+                      (tot <= chip_cus() || (tot >= cu_scaled(768) && tot <= cu_scaled(kDfusedMaxWg)));
+    if (f64_env == 1 || rule) {
+      L.dfused64 = true;
+      L.kv64 = true;
+      L.kv64_half = false;
+      L.kv64_mix_pf = -1;
+      L.nw_kv = 4;
+      L.n_nblk = (p->N + 255) / 256;
+    }
+  }
   if (L.q64) L.nw_q = 8;  // (256 query rows per workgroup)
   size_t off = 0;
   L.delta_off = off;
@@ -495,19 +533,14 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && p->D == 64 && p->dtype == FAT5_BF16) {
     // Round 5: the reference's own operator -- one (1, H, M, N) bias for the whole batch (modeling_flash_t5.py:280-285) -- runs its dQ and the batch
     // sum of dS in ONE kernel (attn_bwd_qdb64.h): no (B, H, M, N) staging tensor, no third recomputation of S / dP.
-    const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
-    const int ngrp = (p->B + 3) / 4;
-    const bool legal = scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
-                       p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
-                       (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
-                       (int64_t)p->M * p->N * (ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
-                       ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+    const int ngrp = qdb_ngrp;
+    const bool legal = qdb_legal;
     // (a call that asks for one of the older dbias paths by variant bit keeps it)
     // (measured, whole backward, us, against the round-4 paths -- profiles/r05_dispatch_audit_none_dense_H12.log: (4,12,512) 49.4 vs 45.3, causal 55.1 vs 42.2: the one
     //  32-wide launch + staged dS stays ahead on the smallest problems; (4,12,1024) 81.8 vs 166.9, (16,12,512) 110.8 vs 118.9, (4,12,2048) 284 vs 436, (16,12,1024)
     //  causal 285 vs 330, (16,12,4096) 5014 vs 9162 -> from 2^25 scores per call on)
     const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 25);
-    if (legal && qdb_env != 0 && (qdb_env == 1 || (qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
+    if (legal && qdb_env != 0 && (qdb_env == 1 || L.dfused64 || (qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
       L.qdb64 = true;
       L.qdb_groups = ngrp;
       L.q64 = false;
@@ -591,7 +624,7 @@ int fat5_attn_bwd_launches(const fat5_attn_params* p) {
   bwd_layout(p, L);
   const long bh = (long)p->B * p->H;
   const long grid_q = bh * ((p->M + 32 * L.nw_q - 1) / (32 * L.nw_q)), grid_kv = bh * L.n_nblk;
-  return (bwd_fusable(L, grid_q, grid_kv, effD(p), p->variant) || L.fused64) ? 1 : 2;
+  return (bwd_fusable(L, grid_q, grid_kv, effD(p), p->variant) || L.fused64 || L.dfused64) ? 1 : 2;  // (dfused64: one launch of both bodies behind the small statistics kernel)
 }
 
 // Which kernel bodies a problem runs, as text (tests pin the dispatch rules with it; no device needed, no pointer of `p` is followed)
@@ -609,7 +642,7 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
   snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
-           L.qdb64 ? "64row-batch4" : (L.q64 ? "64row" : "32row"), kv, (fused || L.fused64) ? 1 : 0,
+           L.qdb64 ? "64row-batch4" : (L.q64 ? "64row" : "32row"), kv, (fused || L.fused64 || L.dfused64) ? 1 : 0,
            L.qdb64 ? (L.qdb_groups > 1 ? "dq-kernel+partials" : "dq-kernel") : (L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct")));
   return FAT5_OK;
 }
@@ -723,6 +756,14 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     a.stat2 = nullptr;
     hipError_t e = launch_bwd_fused64_d64(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused64 launch");
+  } else if (L.dfused64 && (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV)) {
+    // dense bias: row statistics, then the dense dK/dV workgroups and the dQ + dBias ones side by side (a call for one stage runs the same bodies as separate launches)
+    a.n_kv_blocks = (int)grid_kv;
+    a.part_stride = a.n_nblk;
+    const long g = (long)p->H * L.qdb_groups * ((p->M + 63) / 64);
+    if (g + grid_kv + 16 > 0x7fffffffL) return fail(FAT5_EINVAL, "grid too large");
+    hipError_t e = launch_bwd_dfused64_d64(a, bf16, L.qdb_groups > 1 ? (void*)(ws + L.scratch_off) : p->dbias, L.qdb_groups > 1, (int)g, stream);
+    if (e != hipSuccess) return hip_fail(e, "attn_bwd_dfused64 launch");
   } else {
     // 1) dQ (+ delta)
     if ((stages & FAT5_BWD_DQ) && L.qdb64) {

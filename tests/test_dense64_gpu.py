@@ -148,3 +148,39 @@ def test_dense_bodies_at_scales_that_are_not_powers_of_two(B, H, M, N, causal, s
         assert torch.isfinite(got.float()).all(), key
         assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
     assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,scale", [
+    (4, 12, 512, 512, False, 0.125),    # the metric's smallest size with the reference's own operator: 96 + 96 workgroups side by side
+    (4, 3, 512, 512, True, 0.125),      # causal: workgroups of unequal length in both halves, 24 + 24 (the dK/dV count a multiple of eight)
+    (2, 3, 300, 560, False, 1.3),       # ragged rows / keys, two idle waves per dQ workgroup, 18 dK/dV workgroups: padded to 24, the padding exits
+    (6, 2, 256, 264, True, 1.0),        # B > 4: fp32 slabs + the ordered reduction behind the one launch; 1 / scale a 16-bit value (one selector term)
+    (1, 5, 1000, 1096, False, 0.0884),  # forced at B = 1; rows past M inside the last 32-row step of the statistics kernel
+    (5, 2, 520, 72, True, 0.125),       # M >> N: dead rows (lse = -inf) -- their statistics are the zero-probability value in both forms
+])
+def test_dfused64_is_bit_identical_to_the_separate_launches(B, H, M, N, causal, scale):
+    """Both dense 64-wide bodies in ONE launch behind bwd_stat2_kernel (attn_bwd_dfused64_kernel, FAT5_V_FUSED64_ON) against the same bodies as separate launches
+    with the dQ body's own statistics (FAT5_V_FUSED64_OFF): every output bit for bit (the statistics kernel sums a row in the dQ prologue's order), and against the oracle."""
+    from flasht5_amd import _lib
+    dtype = torch.bfloat16
+    q, k, v, b, do = make_inputs(B, H, M, N, 64, dtype, "1h", seed=7 * M + N + B, strided=True)
+    if abs(scale) > 1.0:
+        q = (q.float() * 0.5).to(dtype)
+    ref = oracle_all(q, k, v, b, do, scale, causal)
+    base = _lib.V_QDB64_ON | _lib.V_KV64_ON
+    pn, new = _plan(q, k, v, do, b, causal, scale, base | _lib.V_FUSED64_ON)
+    po, old = _plan(q, k, v, do, b, causal, scale, base | _lib.V_FUSED64_OFF)
+    assert pn.describe()["fused"] == "1" and po.describe()["fused"] == "0"
+    assert pn.describe()["dq"] == "64row-batch4" and pn.describe()["dkdv"] == "64key" and pn.bwd_launches() == 1 and po.bwd_launches() == 2
+    for x, y, key in zip(new, old, ("dq", "dk", "dv", "db")):
+        assert torch.isfinite(x.float()).all(), key
+        assert torch.equal(x, y), key
+    for got, key in zip(new[:3], ("dq", "dk", "dv")):
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
+    # stage-by-stage calls of the same plan (dQ + dbias, then dK/dV: separate launches whatever the layout says) give the same bits again
+    pn.dq.fill_(float("nan")); pn.dk.fill_(float("nan")); pn.dv.fill_(float("nan")); pn.dbias.fill_(float("nan"))
+    pn.backward(5); pn.backward(2)
+    torch.cuda.synchronize()
+    for x, y, key in zip((pn.dq, pn.dk, pn.dv, pn.dbias), old, ("dq", "dk", "dv", "db")):
+        assert torch.equal(x, y), key

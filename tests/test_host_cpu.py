@@ -331,10 +331,12 @@ def test_dispatch_rules_are_pinned():
         # round 5: dQ + the batch-reduced dbias in one kernel (four batch elements per workgroup), the 64-key dK/dV body with the bias on the matrix pipe -- from 2^25
         # scores per call on (profiles/r05_dispatch_audit_none_dense_H12.log); fp32 slabs + ordered reduction beyond four batch elements
         (dict(B=4, H=12, M=8192, N=8192, **dense), dict(fwd="64row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel")),
-        (dict(B=4, H=12, M=2048, N=2048, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel")),
-        (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", dbias="dq-kernel+partials")),
+        (dict(B=4, H=12, M=2048, N=2048, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", fused="1", dbias="dq-kernel")),   # 384 + 384 workgroups: three rounds in ONE launch (dfused64: 230 vs 270 us)
+        (dict(B=16, H=12, M=1024, N=1024, causal=True, **dense), dict(fwd="32row", dq="64row-batch4", dkdv="64key", fused="0", dbias="dq-kernel+partials")),  # six rounds: separate launches (272.6 vs 273.8)
+        (dict(B=4, H=12, M=1024, N=1024, **dense), dict(dq="64row-batch4", dkdv="64key", fused="0")),                                          # 1.5 rounds: separate launches (81.1 vs 77.6 us in one)
         (dict(B=16, H=12, M=2048, N=2048, **dense), dict(fwd="64row")),                                  # (324 vs 360 us)
-        (dict(B=4, H=12, M=512, N=512, **dense), dict(dq="32row", dkdv="32key", fused="1", dbias="staged")),   # the smallest problems: one 32-wide launch + staged dS (45.3 vs 49.4 us)
+        (dict(B=4, H=12, M=512, N=512, **dense), dict(dq="64row-batch4", dkdv="64key", fused="1", dbias="dq-kernel")),   # the metric's smallest size: 96 + 96 workgroups side by side in one launch (dfused64: 28.4 us; the 32-wide launch + staged dS 45.2)
+        (dict(B=2, H=8, M=128, N=128, **dense), dict(dq="32row", dkdv="32key", dbias="staged")),              # config 1's shape: below 2^22 scores the 32-wide launch stays
         (dict(B=1, H=12, M=2048, N=2048, **dense), dict(dq="32row", dbias="direct")),                    # nothing to reduce over
         (dict(B=4, H=12, M=1024, N=1024, sm_scale=0.0, **dense), dict(dq="32row", dkdv="32key")),        # a zero scale: 1 / scale does not exist -- the per-element bodies
         (dict(B=4, H=12, M=2048, N=2048, variant=L.V_DBIAS_STAGED, **dense), dict(dq="32row", dbias="staged")),  # the older paths stay selectable
@@ -350,6 +352,12 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=1024, N=1024, D=128), dict(fwd="64row")),
         (dict(B=16, H=12, M=1024, N=1024, D=128, causal=True), dict(fwd="64row")),                        # plain causal: diagonal blocks masked inside the pipelined sweep
         (dict(B=16, H=12, M=1024, N=1024, D=128, **dense), dict(fwd="64row")),                            # the d_head 128 rows of the reference benchmark
+        # (audit at d_head 128, profiles/r05_dispatch_audit_d128_fwd.log: 512 keys where the 256-row workgroups are one partial round; dense from 512 keys, causal dense from 768 waves)
+        (dict(B=8, H=12, M=512, N=512, D=128), dict(fwd="64row")),
+        (dict(B=16, H=12, M=512, N=512, D=128), dict(fwd="32row")),
+        (dict(B=8, H=12, M=512, N=512, D=128, **dense), dict(fwd="64row")),
+        (dict(B=4, H=12, M=512, N=512, D=128, **dense), dict(fwd="64row")),
+        (dict(B=2, H=12, M=1024, N=1024, D=128, causal=True, **dense), dict(fwd="32row-split")),
         # forced per call
         (dict(B=4, H=12, M=1024, N=1024, variant=L.V_KV64_ON | L.V_KV64_HALF_ON | L.V_Q64_ON | L.V_FWD64_OFF), dict(fwd="32row", dq="64row", dkdv="64key-half")),
     ]
