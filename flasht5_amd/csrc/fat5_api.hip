@@ -41,7 +41,6 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // 22.4 / 26.1; at S = 512 -- 384 waves -- only its key-split variant (128-row workgroups: 192 of them) keeps up with the
 // two-waves-per-32-rows split body of attn_fwd.h: 10.4 / 11.6 against 10.4 / 12.5 us)
 constexpr long kFwd64MinWaves = 384;
-constexpr long kDfusedMaxWg = 1152;  // dense one-launch backward (dfused64): up to this many workgroups of both halves together (x CUs / 256)
 
 // kernel-variant override of a call (fat5_attn_params.variant; tests / profilers): 1 forced on, 0 forced off, -1 library's choice
 inline int vsel(int variant, int on_bit, int off_bit) { return (variant & on_bit) ? 1 : ((variant & off_bit) ? 0 : -1); }
@@ -360,6 +359,19 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const bool dense_kv_ok = dense && scale_exact && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
                            (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) &&
                            ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+  // Dense (1, H, M, N) bias shared by the batch (the reference's own operator): is the dQ + dBias body (attn_bwd_qdb64.h) legal for this call?
+  const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
+  const int qdb_ngrp = (p->B + 3) / 4;
+  const bool qdb_legal = dense && p->dbias && p->D == 64 && p->dtype == FAT5_BF16 &&
+                         scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
+                         p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
+                         (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
+                         (int64_t)p->M * p->N * (qdb_ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
+                         ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
+  // (measured, whole dense backward, both 64-wide bodies against both older ones, us -- profiles/r05_dfused_time2.log: (4,12,768) 60.5 vs 78.5, (8,12,512) 55.1 vs 72.8, (2,12,1024) 71.9 vs 83.5,
+  //  (16,12,256) 39.6 vs 47.6; (8,12,256) 36.6 vs 28.9, (4,12,256) 29.8 vs 29.5 -> from 2^23 scores per call on; below that only inside the one-launch form, see dfused64)
+  const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 23);
+  const bool qdb_pick = qdb_legal && dense_kv_ok && qdb_env != 0 && qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL));
   L.kv64_half = !dense && (kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full));
   // Both variants in one launch (attn_bwd_kv64_mixed_kernel): the first `pf` (b, h) pairs of every XCD as 256-key workgroups, the
   // others half-length.  pf by a list-scheduling model of one XCD (32 CUs, one workgroup per CU, launch order; a half-length
@@ -421,7 +433,8 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const bool kv64_causal_ok = !p->causal || p->N >= ((ctab_kv || p->bias_mode == FAT5_BIAS_NONE) ? 2048 : 4096);
   // (dense, round 5 -- bias on the matrix pipe, causal mask in the C operand; 64-key vs 32-key body, us: (4,12,2048) 137 vs 164, (4,12,8192) 1700 vs 2208;
   //  causal (16,12,512) 52.5 vs 54.1, (16,12,1024) 121 vs 133, (16,12,2048) 344 vs 392 -> from 192 workgroups on)
-  const bool dense_rule = dense && wg256 >= cu_scaled(192) && (int64_t)bh * p->M * p->N >= (int64_t(1) << 25);
+  //  (with the dQ + dBias body taken -- qdb_pick above -- the 64-key body follows it down to 2^23 scores)
+  const bool dense_rule = dense && ((wg256 >= cu_scaled(192) && (int64_t)bh * p->M * p->N >= (int64_t(1) << 25)) || qdb_pick);
   L.kv64 = p->D == 64 && (!dense || dense_kv_ok) && !p->cu_seqlens_q && b64_env != 0 &&
            (b64_env == 1 || dense_rule || ((wg256 >= cu_scaled(fills ? 320 : 512) ||
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
@@ -485,15 +498,6 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     L.nw_kv = 4;
     L.n_nblk = (p->N + 255) / 256;
   }
-  // Dense (1, H, M, N) bias shared by the batch (the reference's own operator): is the dQ + dBias body (attn_bwd_qdb64.h) legal for this call?
-  const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
-  const int qdb_ngrp = (p->B + 3) / 4;
-  const bool qdb_legal = dense && p->dbias && p->D == 64 && p->dtype == FAT5_BF16 &&
-                         scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
-                         p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
-                         (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
-                         (int64_t)p->M * p->N * (qdb_ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
-                         ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
   // ... and both dense 64-wide bodies in ONE launch (attn_bwd_dfused64_kernel, round 5): the dense counterpart of fused64 -- the row statistics come from
   // bwd_stat2_kernel ahead of the launch instead of from the dK/dV half itself.  Separately the two launches of a short sequence leave most of the chip idle
   // twice ((4,12,512): 96 + 96 workgroups on 256 CUs) and those of a mid one each end in a half-empty round ((4,12,2048): 384 + 384).
@@ -501,13 +505,17 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   if (qdb_legal && dense_kv_ok && f64_env != 0 && qdb_env != 0 && b64_env != 0 && kvh_env != 1 && mix_env != 1 &&
       !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL)) && smem_bwd_kv64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024) {
     const long nq = (long)p->H * qdb_ngrp * ((p->M + 63) / 64), tot = wg256 + nq;
-    // Measured, whole dense backward, one launch vs the same two bodies as separate launches (tools/attn_time.py --modes dense --what bwd, us; profiles/r05_dfused_time.log):
-    //   both halves in one round of the chip: (4,12,512) 28.4 vs 45.8 (and 45.2 for the 32-wide launch + staged dS it replaces), causal 31.2 vs 50.4;
-    //   three rounds: (4,12,2048) 230 vs 270, causal 182 vs 194; (8,12,1024) 150.5 vs 174.2; (16,12,512) 95.2 vs 104.2, causal 90.7 vs 101.0;
-    //   1.5 to 2 rounds lose what the statistics kernel costs -- (4,12,1024) 81.1 vs 77.6, (2,12,2048) 198 vs 189, (4,16,1024) 88.5 vs 86.2 -- and from six rounds on
-    //   nothing is left: (4,12,4096) 925 vs 922, (16,12,1024) causal 272.6 vs 273.8.
-    const bool rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 22) &&
-                      (tot <= chip_cus() || (tot >= cu_scaled(768) && tot <= cu_scaled(kDfusedMaxWg)));
+    // Measured, whole dense backward, one launch vs the same two bodies as separate launches (tools/attn_time.py --modes dense --what bwd, us; profiles/r05_dfused_time.log, r05_dfused_time2.log):
+    //   both halves in one round of the chip: (4,12,512) 28.4 vs 45.8 (and 45.2 for the 32-wide launch + staged dS it replaces), causal 31.2 vs 50.4; (2,12,512) 26.7 vs 44.2 (47.8);
+    //   (4,12,384) 31.5 vs 46.6; (8,12,256) 25.1 vs 36.6 (28.9); (4,12,256) 19.4 vs 29.8 (29.5); config 1's (2,8,128) 16.3 vs 23.1 (18.6)
+    //   a round saved: (4,12,1536) 288 + 288 workgroups 164.6 vs 204.5; (6,12,1024) 288 + 384: 140 vs 165; (4,12,2048) 384 + 384: 230 vs 270, causal 182 vs 194; (8,12,1024) 150.5 vs 174.2;
+    //   (16,12,512) 95.2 vs 104.2, causal 90.7 vs 101.0; (4,12,3072) 576 + 576: 550 vs 627
+    //   no round saved -- the statistics kernel is a loss: (4,12,768) 144 + 144: 63.8 vs 60.5; (2,12,1024) 74.2 vs 71.9; (8,12,512) 192 + 192: 58.7 vs 55.1; (4,12,1024) 81.1 vs 77.6; (2,12,2048) 198 vs 189;
+    //   (4,16,1024) 256 + 256: 88.5 vs 86.2; (16,12,256) 42.4 vs 39.6; (4,12,4096) 768 + 768: 925 vs 922; (16,12,1024) causal 272.6 vs 273.8; (8,12,2048) 630 vs 631.5
+    // -> exactly when the one launch takes fewer rounds of the chip (one workgroup per CU either way) than the two launches together
+    const long ncus = chip_cus();
+    const long r_one = (tot + ncus - 1) / ncus, r_two = (wg256 + ncus - 1) / ncus + (nq + ncus - 1) / ncus;
+    const bool rule = p->B >= 2 && r_one < r_two && r_two <= 8;
     if (f64_env == 1 || rule) {
       L.dfused64 = true;
       L.kv64 = true;
@@ -538,8 +546,7 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // (a call that asks for one of the older dbias paths by variant bit keeps it)
     // (measured, whole backward, us, against the round-4 paths -- profiles/r05_dispatch_audit_none_dense_H12.log: (4,12,512) 49.4 vs 45.3, causal 55.1 vs 42.2: the one
     //  32-wide launch + staged dS stays ahead on the smallest problems; (4,12,1024) 81.8 vs 166.9, (16,12,512) 110.8 vs 118.9, (4,12,2048) 284 vs 436, (16,12,1024)
-    //  causal 285 vs 330, (16,12,4096) 5014 vs 9162 -> from 2^25 scores per call on)
-    const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 25);
+    //  causal 285 vs 330, (16,12,4096) 5014 vs 9162 -> from 2^25 scores per call on; second sweep, profiles/r05_dfused_time2.log: from 2^23 -- qdb_rule above)
     if (legal && qdb_env != 0 && (qdb_env == 1 || L.dfused64 || (qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL))))) {
       L.qdb64 = true;
       L.qdb_groups = ngrp;

@@ -336,7 +336,10 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=1024, N=1024, **dense), dict(dq="64row-batch4", dkdv="64key", fused="0")),                                          # 1.5 rounds: separate launches (81.1 vs 77.6 us in one)
         (dict(B=16, H=12, M=2048, N=2048, **dense), dict(fwd="64row")),                                  # (324 vs 360 us)
         (dict(B=4, H=12, M=512, N=512, **dense), dict(dq="64row-batch4", dkdv="64key", fused="1", dbias="dq-kernel")),   # the metric's smallest size: 96 + 96 workgroups side by side in one launch (dfused64: 28.4 us; the 32-wide launch + staged dS 45.2)
-        (dict(B=2, H=8, M=128, N=128, **dense), dict(dq="32row", dkdv="32key", dbias="staged")),              # config 1's shape: below 2^22 scores the 32-wide launch stays
+        (dict(B=2, H=8, M=128, N=128, **dense), dict(dq="64row-batch4", dkdv="64key", fused="1", dbias="dq-kernel")),   # ... down to config 1's shape (16.3 vs 18.6 us)
+        (dict(B=4, H=12, M=768, N=768, **dense), dict(dq="64row-batch4", dkdv="64key", fused="0")),                      # 144 + 144 workgroups: two rounds either way -> separate launches (60.5 vs 63.8; the older bodies 78.5)
+        (dict(B=4, H=12, M=1536, N=1536, **dense), dict(dq="64row-batch4", dkdv="64key", fused="1")),                    # 288 + 288: three rounds instead of four (164.6 vs 204.5)
+        (dict(B=8, H=12, M=256, N=256, **dense), dict(dq="64row-batch4", dkdv="64key", fused="1", dbias="dq-kernel+partials")),
         (dict(B=1, H=12, M=2048, N=2048, **dense), dict(dq="32row", dbias="direct")),                    # nothing to reduce over
         (dict(B=4, H=12, M=1024, N=1024, sm_scale=0.0, **dense), dict(dq="32row", dkdv="32key")),        # a zero scale: 1 / scale does not exist -- the per-element bodies
         (dict(B=4, H=12, M=2048, N=2048, variant=L.V_DBIAS_STAGED, **dense), dict(dq="32row", dbias="staged")),  # the older paths stay selectable
