@@ -278,7 +278,7 @@ def dense_by_seq_bench(device):
                        "fwd_bwd_tflops": round(3.5 * f / (tf + tb) / 1e9, 1), "fwd_frac_of_peak": round(f / tf / 1e9 / PEAK_BF16_TFLOPS, 4),
                        "bwd_frac_of_peak": round(2.5 * f / tb / 1e9 / PEAK_BF16_TFLOPS, 4), "bwd_stages": stages, "kernels": plan.describe(),
                        "bwd_alg_bytes": alg_bwd, "bwd_alg_GBs": round(alg_bwd / tb / 1e6, 1),
-                       "bwd_traffic": {k_: load_traffic(k_, S, "dense") for k_ in ("attn_bwd_dq", "attn_bwd_dkdv")}}
+                       "bwd_traffic": {k_: load_traffic(k_, S, "dense") for k_ in (("attn_bwd_fused", "bwd_stat2") if plan.bwd_launches() == 1 else ("attn_bwd_dq", "attn_bwd_dkdv"))}}
         del plan
         torch.cuda.empty_cache()
     out["what"] = "(4,12,S,64) bf16, non-causal, dense (1,12,S,S) bias + dbias, sm_scale 0.125, (B,S,H,D)-strided inputs; median of 3 event-timed batches"

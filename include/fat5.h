@@ -55,7 +55,7 @@ enum fat5_variant {
   FAT5_V_FWD64_MIX_ON = 524288, FAT5_V_FWD64_MIX_OFF = 1048576,  /* 64-row forward: 256-row and key-split 128-row workgroups in ONE launch wherever legal / never */
   FAT5_V_DBIAS_NOSPLIT = 262144,                                 /* batch-inner dbias kernel: the one-group form (one wave per SIMD) of rounds 2-3 */
   FAT5_V_QDB64_ON = 2097152, FAT5_V_QDB64_OFF = 4194304,        /* dense (1,H,M,N) bias, bf16, D = 64: dQ and the batch-reduced dbias in one kernel, four batch elements per workgroup (attn_bwd_qdb64.h) wherever legal / never */
-  FAT5_V_FUSED64_ON = 65536, FAT5_V_FUSED64_OFF = 131072         /* backward: the 64-wide dK/dV and dQ bodies in ONE launch (the dK/dV half forms its row statistics itself) wherever legal / never */
+  FAT5_V_FUSED64_ON = 65536, FAT5_V_FUSED64_OFF = 131072         /* backward: the 64-wide dK/dV and dQ bodies in ONE launch (the dK/dV half forms its row statistics itself) wherever legal / never; dense (1,H,M,N) bias: the dense dK/dV body beside the dQ + dBias body in one launch behind a small row-statistics kernel */
 };
 
 enum fat5_bias_mode {

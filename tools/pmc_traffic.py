@@ -7,9 +7,10 @@ import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"attn_fwd_kernel": "attn_fwd", "attn_fwd64_kernel": "attn_fwd", "attn_fwd_split_kernel": "attn_fwd", "attn_bwd_fused_kernel": "attn_bwd_fused", "attn_bwd_fused64_kernel": "attn_bwd_fused", "attn_bwd_kv64_mixed_kernel": "attn_bwd_dkdv", "attn_bwd_q_kernel": "attn_bwd_dq",
          "attn_bwd_kv_kernel": "attn_bwd_dkdv", "attn_bwd_kv64_kernel": "attn_bwd_dkdv", "attn_bwd_q64_kernel": "attn_bwd_dq", "drpe_reduce_kernel": "bias_grad_reduce", "attn_bwd_dbias_kernel": "attn_bwd_dbias", "dbias_reduce_kernel": "dbias_reduce",
-         "attn_bwd_qdb64_kernel": "attn_bwd_dq", "attn_fwd64_dense_kernel": "attn_fwd", "attn_fwd64_mixed_kernel": "attn_fwd", "dbias_partial_reduce_kernel": "dbias_reduce"}  # (round 5: attn_bwd_dq of a dense problem = dQ + the batch-reduced dbias)
+         "attn_bwd_qdb64_kernel": "attn_bwd_dq", "attn_fwd64_dense_kernel": "attn_fwd", "attn_fwd64_mixed_kernel": "attn_fwd", "dbias_partial_reduce_kernel": "dbias_reduce",
+         "attn_bwd_dfused64_kernel": "attn_bwd_fused", "bwd_stat2_kernel": "bwd_stat2", "attn_fwd64_w1_kernel": "attn_fwd"}  # (round 5: attn_bwd_dq of a dense problem = dQ + the batch-reduced dbias)
 out = {}
-for S, mode in ((512, "rpe"), (2048, "rpe"), (8192, "rpe"), (8192, "none"), (2048, "dense"), (8192, "dense")):
+for S, mode in ((512, "rpe"), (2048, "rpe"), (8192, "rpe"), (8192, "none"), (512, "dense"), (2048, "dense"), (8192, "dense")):
     vals = collections.defaultdict(dict)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = f"/tmp/pmc_{S}_{mode}_{ctr}"

@@ -60,3 +60,25 @@ for S, M, reps2, force in ((1536, 1536, reps, "1"), (1000, 1100, reps, "1"), (15
             print(f"64-wide[{force}] M={M} N={S} {mode:5s} causal={int(causal)} x{reps2}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
             bad += n_bad
 print("TOTAL MISMATCHES", bad)
+# round 5: the dense 64-wide bodies in one launch (attn_bwd_dfused64_kernel: dK/dV and dQ + dBias workgroups side by side behind bwd_stat2_kernel), forced on ragged / multi-group
+# shapes; the head_dim-128 pipelined forward (default dispatch) with its dense bias ring
+from flasht5_amd import _lib
+for B, M, S, D, force in ((6, 1000, 1096, 64, True), (16, 512, 512, 64, True), (4, 1536, 1536, 64, False), (4, 2048, 2048, 128, False), (16, 1024, 1024, 128, False)):
+    for causal in (False, True):
+        _lib.set_variant((_lib.V_QDB64_ON | _lib.V_KV64_ON | _lib.V_FUSED64_ON) if force else 0)
+        q, k, v, _, do = make_inputs(B, 12, M, S, D, torch.bfloat16, None, seed=S + B, strided=True)
+        bias = torch.randn(1, 12, M, S, generator=torch.Generator().manual_seed(3)).bfloat16().cuda()
+        plan = AttentionPlan(q, k, v, do, sm_scale=1.3 if B == 16 else D ** -0.5, causal=causal, bias=bias)
+        plan.forward(); plan.backward(); torch.cuda.synchronize()
+        ref = [t.clone() for t in (plan.o, plan.lse, plan.dq, plan.dk, plan.dv, plan.dbias)]
+        n_bad = 0
+        for i in range(reps):
+            plan.forward(); plan.backward()
+            if i % 25 == 24 or i == reps - 1:
+                torch.cuda.synchronize()
+                n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, (plan.o, plan.lse, plan.dq, plan.dk, plan.dv, plan.dbias)))
+        print(f"dense[{'forced one-launch' if force else 'default'}] B={B} M={M} N={S} D={D} causal={int(causal)} {plan.describe()} x{reps}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
+        bad += n_bad
+        del plan
+_lib.set_variant(0)
+print("stress (round-5 block) done, mismatches:", bad)
