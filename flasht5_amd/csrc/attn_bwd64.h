@@ -405,8 +405,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   if constexpr (DENSE) {
     // E(jj): A operand, lane = row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3), holding 1/scale's leading 16 bits for j < 4 and the next 16 for j >= 4
     const float invf = 1.f / a.scale;
-    const uint32_t ih = __float_as_uint(invf) >> 16;
-    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
+    uint32_t ih, il;
+    split16<BF16>(invf, ih, il);
 #pragma unroll
     for (int jj = 0; jj < (ONE ? 2 : 4); ++jj) {
       uint32_t wv[4];

@@ -12,13 +12,8 @@
 
 namespace fat5 {
 
-// 1 / scale representable in 16 bits (bf16): the one-term selector of the dense body
-static inline bool inv_scale_is_bf16(float scale) {
-  const float inv = 1.f / scale;
-  uint32_t bits;
-  memcpy(&bits, &inv, 4);
-  return (bits & 0xffffu) == 0u;
-}
+// 1 / scale representable in the 16-bit operand dtype: the one-term selector of the dense body
+static inline bool inv_scale_is_16bit(float scale, bool bf16) { return bf16 ? is_one16<true>(1.f / scale) : is_one16<false>(1.f / scale); }
 template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false>
 static hipError_t launch_kv64(const AttnArgs& a, int grid, hipStream_t s) {
   // (operands / outputs through LDS images whenever the workgroup's LDS allows: see BwdQ64Cfg)
@@ -59,11 +54,11 @@ hipError_t CAT(launch_bwd_q64_d, FAT5_INST_D)(const AttnArgs& a, int bf16, int b
 
 template <bool HALF>
 static hipError_t launch_kv64_bias(const AttnArgs& a, int bf16, int bias, int grid, hipStream_t s) {
-  if constexpr (!HALF) {  // (dense bias, round 5: 256-key workgroups, bf16)
+  if constexpr (!HALF) {  // (dense bias, round 5: 256-key workgroups; fp16 since the second half of the round)
     if (bias == FAT5_BIAS_DENSE) {
-      if (!bf16) return hipErrorInvalidValue;
-      return inv_scale_is_bf16(a.scale) ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, true>(a, grid, s)
-                                        : launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, false>(a, grid, s);
+      const bool one = inv_scale_is_16bit(a.scale, bf16 != 0);
+      if (bf16) return one ? launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, true>(a, grid, s) : launch_kv64<FAT5_INST_D, true, FAT5_BIAS_DENSE, false, false>(a, grid, s);
+      return one ? launch_kv64<FAT5_INST_D, false, FAT5_BIAS_DENSE, false, true>(a, grid, s) : launch_kv64<FAT5_INST_D, false, FAT5_BIAS_DENSE, false, false>(a, grid, s);
     }
   }
   if (bias == FAT5_BIAS_RPE1D)

@@ -71,7 +71,7 @@ FAT5_DEV constexpr int qdb_word(int r) { return qdb_key(r, 0) >> 1; }
 // bid % 8 stays the XCD); wstats: write the row statistics the dK/dV kernels read (a.stat2) -- off when bwd_stat2_kernel wrote them ahead of the launch
 template <int D, bool BF16, bool PARTIAL, bool ONE>
 FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int bid, const bool wstats) {
-  static_assert(D == 64 && BF16, "gap schedule written for D = 64, bf16");
+  static_assert(D == 64, "gap schedule written for D = 64");
   using Cfg = BwdQdb64Cfg<D>;
   constexpr int IMG = Cfg::IMG, BT = Cfg::BT;
   constexpr int KK = D / 16, DB = D / 32;
@@ -293,8 +293,8 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
   u32x4 selB[4];
   {
     const float invf = 1.f / a.scale;
-    const uint32_t ih = __float_as_uint(invf) >> 16;
-    const uint32_t il = __float_as_uint(invf - __uint_as_float(ih << 16)) >> 16;
+    uint32_t ih, il;
+    split16<BF16>(invf, ih, il);
 #pragma unroll
     for (int jj = 0; jj < (ONE ? 2 : 4); ++jj) {
       uint32_t wv[4];
@@ -329,7 +329,8 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
     uint32_t wv[4];
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
-      const uint32_t lo = (kb8 + 2 * j2 == i16) ? 0x3F80u : 0u, hi16 = (kb8 + 2 * j2 + 1 == i16) ? 0x3F80u : 0u;  // bf16 1.0
+      constexpr uint32_t one16 = BF16 ? 0x3F80u : 0x3C00u;  // 1.0
+      const uint32_t lo = (kb8 + 2 * j2 == i16) ? one16 : 0u, hi16 = (kb8 + 2 * j2 + 1 == i16) ? one16 : 0u;
       wv[j2] = lo | (hi16 << 16);
     }
     sel16 = u32x4{wv[0], wv[1], wv[2], wv[3]};

@@ -91,6 +91,38 @@ FAT5_DEV float cvt_hi(uint32_t w) {  // high 16 bits -> fp32
     return (float)r[1];
   }
 }
+// x as two 16-bit terms of the operand dtype, x ~ hi + lo (the dense bodies' 1 / scale on the matrix pipe): bf16 by truncation (8 + 8 mantissa bits, 2^-17 relative),
+// fp16 by rounding (11 bits + whatever the second term still resolves: never worse than one fp16 rounding of the bias itself); host and device
+template <bool BF16>
+__host__ __device__ inline void split16(float x, uint32_t& hi, uint32_t& lo) {
+  if constexpr (BF16) {
+    uint32_t xb, rb;
+    __builtin_memcpy(&xb, &x, 4);
+    hi = xb >> 16;
+    const uint32_t hb = hi << 16;
+    float hf;
+    __builtin_memcpy(&hf, &hb, 4);
+    const float r = x - hf;
+    __builtin_memcpy(&rb, &r, 4);
+    lo = rb >> 16;
+  } else {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    uint16_t hb, lb;
+    __builtin_memcpy(&hb, &h, 2);
+    __builtin_memcpy(&lb, &l, 2);
+    hi = hb;
+    lo = lb;
+  }
+}
+// ... and whether x is ONE such term exactly (the one-selector-term kernels)
+template <bool BF16>
+__host__ __device__ inline bool is_one16(float x) {
+  uint32_t hi, lo;
+  split16<BF16>(x, hi, lo);
+  return (lo & 0x7fffu) == 0u;
+}
+
 template <bool BF16>
 FAT5_DEV float cvt16(uint16_t h) {
   return cvt_lo<BF16>((uint32_t)h);

@@ -355,14 +355,15 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   // bias rows 16-byte aligned (LDS-DMA)
   const bool dense = p->bias_mode == FAT5_BIAS_DENSE;
   // (the bodies add bias / scale on the matrix pipe, 1 / scale as two 16-bit terms: a zero scale keeps the older bodies)
-  const bool scale_exact = p->sm_scale != 0.f && std::isfinite(1.f / p->sm_scale) && std::isfinite(p->sm_scale);
-  const bool dense_kv_ok = dense && scale_exact && p->dtype == FAT5_BF16 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
+  // (fp16: 1 / scale itself has to be an fp16 value in range -- |scale| down to 2e-5)
+  const bool scale_exact = p->sm_scale != 0.f && std::isfinite(1.f / p->sm_scale) && std::isfinite(p->sm_scale) && (p->dtype == FAT5_BF16 || std::fabs(1.f / p->sm_scale) <= 60000.f);
+  const bool dense_kv_ok = dense && scale_exact && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) && (p->bias_stride[0] % 8 == 0) &&
                            (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) &&
                            ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
   // Dense (1, H, M, N) bias shared by the batch (the reference's own operator): is the dQ + dBias body (attn_bwd_qdb64.h) legal for this call?
   const int qdb_env = vsel(p->variant, FAT5_V_QDB64_ON, FAT5_V_QDB64_OFF);
   const int qdb_ngrp = (p->B + 3) / 4;
-  const bool qdb_legal = dense && p->dbias && p->D == 64 && p->dtype == FAT5_BF16 &&
+  const bool qdb_legal = dense && p->dbias && p->D == 64 &&
                          scale_exact && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 && (p->bias_stride[1] != 0 || p->H == 1) &&
                          p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
                          (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
@@ -538,7 +539,7 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   L.scratch_off = off;
   L.qdb64 = false;
   L.qdb_groups = 0;
-  if (p->bias_mode == FAT5_BIAS_DENSE && p->dbias && p->D == 64 && p->dtype == FAT5_BF16) {
+  if (qdb_legal) {
     // Round 5: the reference's own operator -- one (1, H, M, N) bias for the whole batch (modeling_flash_t5.py:280-285) -- runs its dQ and the batch
     // sum of dS in ONE kernel (attn_bwd_qdb64.h): no (B, H, M, N) staging tensor, no third recomputation of S / dP.
     const int ngrp = qdb_ngrp;

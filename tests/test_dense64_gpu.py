@@ -184,3 +184,38 @@ def test_dfused64_is_bit_identical_to_the_separate_launches(B, H, M, N, causal, 
     torch.cuda.synchronize()
     for x, y, key in zip((pn.dq, pn.dk, pn.dv, pn.dbias), old, ("dq", "dk", "dv", "db")):
         assert torch.equal(x, y), key
+
+
+@pytest.mark.parametrize("B,H,M,N,causal,scale", [
+    (4, 3, 512, 512, False, 0.125),     # 1 / scale an fp16 value: the one-term selector kernels
+    (4, 2, 512, 512, True, 1.3),        # the reference benchmark's scale: 1 / 1.3 as two fp16 terms
+    (6, 2, 300, 560, False, 0.0884),    # B > 4: fp32 slabs; ragged
+    (2, 3, 1000, 1096, True, -0.5),     # a negative scale, ragged rows and keys with the mask
+    (16, 2, 256, 256, True, 1.0),       # T5's scale, four groups
+])
+def test_dense_64wide_bodies_in_fp16(B, H, M, N, causal, scale):
+    """fp16 through the dense 64-wide backward bodies (second half of round 5): dQ + dBias (qdb64), the 64-key dK/dV body, both in one launch -- against the oracle at the
+    fp16 bounds, bit-identical between the one-launch and the separate-launch form, and within a rounding of the older fp16 paths (same terms: dS rounded to fp16 per batch element)."""
+    from flasht5_amd import _lib
+    dtype = torch.float16
+    q, k, v, b, do = make_inputs(B, H, M, N, 64, dtype, "1h", seed=5 * M + N + B, strided=True)
+    if abs(scale) > 1.0:
+        q = (q.float() * 0.5).to(dtype)
+    ref = oracle_all(q, k, v, b, do, scale, causal)
+    base = _lib.V_QDB64_ON | _lib.V_KV64_ON
+    pn, new = _plan(q, k, v, do, b, causal, scale, base | _lib.V_FUSED64_ON)
+    ps, sep = _plan(q, k, v, do, b, causal, scale, base | _lib.V_FUSED64_OFF)
+    po, old = _plan(q, k, v, do, b, causal, scale, _lib.V_QDB64_OFF | _lib.V_KV64_OFF)
+    assert pn.describe()["dq"] == "64row-batch4" and pn.describe()["dkdv"] == "64key" and pn.describe()["fused"] == "1"
+    assert ps.describe()["dq"] == "64row-batch4" and ps.describe()["fused"] == "0" and po.describe()["dq"] != "64row-batch4" and po.describe()["dkdv"] == "32key"
+    for x, y, key in zip(new, sep, ("dq", "dk", "dv", "db")):
+        assert torch.isfinite(x.float()).all(), key
+        assert torch.equal(x, y), key
+    for got, key in zip(new[:3], ("dq", "dk", "dv")):
+        assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    assert maxdiff(new[3], ref["db"]) <= gbound(ref["db"], dtype) * (1 + B)
+    for i, key in enumerate(("dq", "dk", "dv", "db")):
+        assert maxdiff(new[i], old[i]) <= 2.0 ** -8 * max(1.0, float(old[i].float().abs().max())) * (1 + (B if key == "db" else 0)), key
+    if causal:
+        keep = torch.arange(N, device="cuda")[None, :] <= torch.arange(M, device="cuda")[:, None] + (N - M)
+        assert bool((new[3][0][:, ~keep] == 0).all())
