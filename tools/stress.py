@@ -81,4 +81,26 @@ for B, M, S, D, force in ((6, 1000, 1096, 64, True), (16, 512, 512, 64, True), (
         bad += n_bad
         del plan
 _lib.set_variant(0)
+# ... the head_dim-128 pipelined forward without / with the T5 table: one partial round (ring requests spread over the MFMA gaps), several rounds, ragged, causal; each behind
+# its backward (cold caches: what exposed the three-slot race above)
+for B, M, S in ((4, 1024, 1024), (4, 2048, 2048), (16, 1024, 1024), (8, 1000, 1100)):
+    for mode in ("none", "rpe"):
+        for causal in (False, True):
+            q, k, v, _, do = make_inputs(B, 12, M, S, 128, torch.bfloat16, None, seed=S + B + 1, strided=True)
+            kw = {}
+            if mode == "rpe":
+                table = (torch.randn(32, 12, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+                kw = dict(rpe1d=pe.rpe1d_from_table(table), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+            plan = AttentionPlan(q, k, v, do, sm_scale=128 ** -0.5, causal=causal, **kw)
+            plan.forward(); plan.backward(); torch.cuda.synchronize()
+            ref = [t.clone() for t in (plan.o, plan.lse, plan.dq, plan.dk, plan.dv)]
+            n_bad = 0
+            for i in range(reps):
+                plan.forward(); plan.backward()
+                if i % 25 == 24 or i == reps - 1:
+                    torch.cuda.synchronize()
+                    n_bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(ref, (plan.o, plan.lse, plan.dq, plan.dk, plan.dv)))
+            print(f"d128 B={B} M={M} N={S} {mode:5s} causal={int(causal)} fwd={plan.describe()['fwd']} x{reps}: {'OK' if n_bad == 0 else 'MISMATCH x%d' % n_bad}", flush=True)
+            bad += n_bad
+            del plan
 print("stress (round-5 block) done, mismatches:", bad)
