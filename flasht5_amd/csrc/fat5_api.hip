@@ -568,7 +568,10 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // (B > 4 costs the kernel one fp32 read-modify-write pass over (H, M, N) per 4 batch elements: at the reference's benchmark
     //  shape B = 16, S = 512 / 1024 the staged path is 1.8x / 1.35x faster (132 vs 235 us, 436 vs 590 us) -> staged up to 2 GB)
     const size_t staging = (size_t)bh * p->M * p->N * 2;
-    const bool big = p->B <= 4 ? staging > (size_t(64) << 20) : staging > (size_t(2) << 30);
+    // (head_dim 128, where this choice still decides the model's case -- at D = 64 the dQ + dBias body took it over --: the third recomputation costs twice the MFMA work
+    //  of D = 64 while the staging tensor stays the same: (4,12,1024,128) staged 274 vs 341 us, (4,12,2048,128) 896 vs 933 (400 MB) -> staged up to 512 MB there;
+    //  (16,12,1024,128) causal 713 vs 1077: profiles/r05_d128_bwd_variants.log)
+    const bool big = p->B <= 4 ? staging > (size_t(p->D == 128 ? 512 : 64) << 20) : staging > (size_t(2) << 30);
     if (reduced && inker_env && (big || inker_env > 1) && p->dbias_batch == 1 && p->dbias_heads == p->H && p->bias_stride[0] == 0 &&
         (p->bias_stride[1] != 0 || p->H == 1) && p->unit_count == 0 && !p->cu_seqlens_q) {
       L.dbias_inkernel = true;

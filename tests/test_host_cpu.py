@@ -361,6 +361,8 @@ def test_dispatch_rules_are_pinned():
         (dict(B=8, H=12, M=512, N=512, D=128, **dense), dict(fwd="64row")),
         (dict(B=4, H=12, M=512, N=512, D=128, **dense), dict(fwd="64row")),
         (dict(B=2, H=12, M=1024, N=1024, D=128, causal=True, **dense), dict(fwd="32row-split")),
+        (dict(B=4, H=12, M=1024, N=1024, D=128, **dense), dict(dq="32row", dkdv="32key", dbias="staged")),   # head_dim 128: the staged dS + reduction up to 512 MB (274 vs 341 us for the batch-inner kernel)
+        (dict(B=4, H=12, M=4096, N=4096, D=128, **dense), dict(dbias="inkernel")),
         # forced per call
         (dict(B=4, H=12, M=1024, N=1024, variant=L.V_KV64_ON | L.V_KV64_HALF_ON | L.V_Q64_ON | L.V_FWD64_OFF), dict(fwd="32row", dq="64row", dkdv="64key-half")),
     ]
