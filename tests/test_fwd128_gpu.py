@@ -211,3 +211,33 @@ def test_large_scale_takes_the_first_tile_reference_point(Dh, mode, causal):
     assert torch.isfinite(plan.o.float()).all()
     assert maxdiff(plan.o, ref["o"]) <= bound(ref["o"], torch.bfloat16)
     assert maxdiff(plan.lse, ref["L"]) <= 2e-3 * float(ref["L"].abs().max())
+
+
+def test_fwd128_golden_fixture_through_the_pipelined_dense_body():
+    """The reference-generated head_dim-128 fixture (tests/golden/attn_d128_nc_bf16.npz: the reference's eager path on (1,2,64,100,128) with a (1,H,M,N) bias) through the
+    pipelined 64-row dense body, forced: its 100 keys per row are no multiple of 8, so the bias goes in as a view of a buffer with a 104-key row pitch
+    (16-byte aligned rows: the LDS-DMA condition) -- the same values.  o and lse against the stored reference outputs; the backward consumes this o / lse."""
+    import golden_io
+    from flasht5_amd import _lib
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    g = golden_io.load_attn("attn_d128_nc_bf16")
+    assert g["D"] == 128 and g["dtype"] == torch.bfloat16 and not g["causal"]
+    q, k, v, do = (g[n].cuda() for n in ("q", "k", "v", "do"))
+    M, N = g["M"], g["N"]
+    big = torch.zeros(1, g["H"], M, (N + 7) // 8 * 8, dtype=torch.bfloat16, device="cuda")
+    big[..., :N] = g["bias"].cuda()
+    bias = big[..., :N]
+    plan = AttentionPlan(q, k, v, do, bias=bias, causal=False, sm_scale=g["sm_scale"], variant=_lib.V_FWD64_ON)
+    assert plan.describe()["fwd"] == "64row"
+    plan.o.fill_(float("nan")); plan.lse.fill_(float("nan"))
+    plan.forward()
+    grads = plan.backward()
+    torch.cuda.synchronize()
+    o_ref, L_ref = g["o"].cuda(), g["L"].cuda()
+    assert torch.isfinite(plan.o.float()).all()
+    assert maxdiff(plan.o, o_ref) <= bound(o_ref, torch.bfloat16)
+    assert maxdiff(plan.lse, L_ref) <= 2e-3 * max(1.0, float(L_ref.abs().max()))
+    for got, key in zip(grads[:3], ("dq", "dk", "dv")):
+        ref = g[key].cuda()
+        assert maxdiff(got, ref) <= gbound(ref, torch.bfloat16), key
+    assert maxdiff(grads[3], g["dbias"].cuda()) <= gbound(g["dbias"].cuda(), torch.bfloat16) * 2
