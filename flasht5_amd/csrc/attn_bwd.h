@@ -56,7 +56,7 @@ FAT5_DEV void attn_bwd_q_body(const AttnArgs& a, const int bid) {
   float* sT = reinterpret_cast<float*>(smem + 2 * Cfg::STAGE) + kRpePad;  // (entry d of copy 0 at sT[d + R]; see attn_common.h)
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int b, h, mblk;
-  decode_unit(a, bid, a.n_mblk, b, h, mblk);
+  decode_unit(a, bid, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],
           dooff = (int64_t)b * a.dos[0], dqoff = (int64_t)b * a.dqs[0];
@@ -394,7 +394,7 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lq = l & 31, hi = l >> 5;
   int b, h, nblk;
-  decode_unit(a, bid, a.n_nblk, b, h, nblk);
+  decode_unit(a, bid, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
   const int bh = b * a.H + h;  // (row of this (batch, head) in the partial-sum workspace)
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0], ooff = (int64_t)b * a.os[0],

@@ -1122,7 +1122,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
 
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, lq = l & 31, hi = l >> 5;  // (w: provably wave-uniform)
   int b, h, mblk;
-  decode_unit(a, bid, a.n_mblk, b, h, mblk);
+  decode_unit(a, bid, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
   const int M = a.M, N = a.N;
   const int m0 = mblk * BM;
   if (m0 >= M) return;
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_fused64_kernel(const AttnArgs a) {
   if ((int)blockIdx.x < a.n_kv_blocks) {
     int b, h, nblk;
-    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
     attn_bwd_kv64_body<D, BF16, BIAS, false, true>(a, b, h, nblk, nblk, false);
   } else {
     attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x - a.n_kv_blocks);
@@ -1689,7 +1689,7 @@ template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_kv64_kernel(const AttnArgs a) {
   int b, h, nblk;
-  decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+  decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
   // (part_rows2: a 256-key launch over some units of a problem whose other units run half-length -- a unit range of a mixed launch)
   const bool two = !HALF && a.part_rows2;
   attn_bwd_kv64_body<D, BF16, BIAS, HALF, false, ONE>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);

@@ -89,9 +89,17 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
     const int base = W >> 3, rem = W & 7;
     if (idx >= base + (x < rem ? 1 : 0)) return;  // (grid = 8 ceil(W / 8))
     const int item = x * base + min(x, rem) + idx;
-    pair = fast_div(item, a.n_mblk, a.mg_mblk);
-    mblk = item - pair * a.n_mblk;
-    if (a.causal) mblk = a.n_mblk - 1 - mblk;  // (the row blocks that see the most keys first: the short ones fill the tail of the launch)
+    const int npair = a.H * ngrp;
+    if (FAT5_CAUSAL_ORDER && a.causal && (npair & 7) == 0) {
+      // causal: row-block-major over the XCD's pairs (x, x + 8, ...), the blocks that see the most keys first -- longest-first list scheduling (decode_block, order 1)
+      const int per = npair >> 3, tq = idx / per;
+      pair = (idx - tq * per) * 8 + x;
+      mblk = a.n_mblk - 1 - tq;
+    } else {
+      pair = fast_div(item, a.n_mblk, a.mg_mblk);
+      mblk = item - pair * a.n_mblk;
+      if (a.causal) mblk = a.n_mblk - 1 - mblk;  // (the row blocks that see the most keys first inside every pair)
+    }
   }
   const int h = pair / ngrp, grp = pair - h * ngrp;
   const int b_ = 4 * grp + w;
@@ -744,7 +752,7 @@ void attn_bwd_dfused64_kernel(const AttnArgs a, void* dbias_out) {
   if ((int)blockIdx.x < nkv8) {
     if ((int)blockIdx.x >= a.n_kv_blocks) return;
     int b, h, nblk;
-    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk);
+    decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
     attn_bwd_kv64_body<D, BF16, FAT5_BIAS_DENSE, false, false, ONE>(a, b, h, nblk, nblk, false);
   } else {
     attn_bwd_qdb64_body<D, BF16, PARTIAL, ONE>(a, dbias_out, (int)blockIdx.x - nkv8, false);

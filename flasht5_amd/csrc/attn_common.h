@@ -226,18 +226,33 @@ __host__ inline uint32_t div_magic(long d, long n_max) {  // n_max: the largest 
   if (d <= 1 || d >= (1L << 31) || n_max < 0 || (unsigned long long)n_max * (unsigned long long)d >= (1ull << 32)) return 0u;
   return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d);
 }
-FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile, uint32_t mg_tile = 0) {
-  const int total = nbh * ntile;
+// order (causal problems: the tiles of a pair have unequal lengths): 0 = pair-major, a pair's tiles side by side (its K / V stay in the XCD's L2);
+// 1 = tile-major, the LAST tile of every pair of the XCD first (row blocks of a causal problem: the ones that see the most keys); 2 = tile-major, the FIRST tile
+// first (key blocks: the ones most rows see) -- longest-first list scheduling: in launch order the dispatcher hands a freed CU the next workgroup, and with
+// pair-major order the last workgroups to start include full-length ones (24 pairs x 4 row blocks on the 32 CUs of an XCD: 51 tile-times against 43
+// longest-first, 41 ideal).  Measured, causal forward (profiles/r05_causal_order_fwd_ab.log, us): (16,12,1024,128) dense 123.8 -> 101.3, (4,12,2048,128) 81.9 -> 62.6,
+// (16,12,1024,64) dense 73.5 -> 59.6, (4,12,2048,64) 48.1 -> 39.9, (4,12,4096,64) 140.7 -> 116.0 -- 11 .. 33 % on every causal shape but one ((16,12,512) T5 table: +2 %).
+// Results do not depend on the order (every workgroup computes its own tile).
+FAT5_DEV void decode_block(int bid, int nbh, int ntile, int& bh, int& tile, uint32_t mg_tile = 0, int order = 0) {
   const int nx = 8;
   if ((nbh % nx) == 0) {
     const int xcd = bid % nx;
     const int idx = bid / nx;           // sequence number inside this XCD
     const int per = nbh / nx;           // (b,h) pairs per XCD
-    const int pair = fast_div(idx, ntile, mg_tile);  // which of this XCD's pairs
-    tile = idx - pair * ntile;
+    int pair;
+    if (order) {
+      const int tq = idx / per;
+      pair = idx - tq * per;
+      tile = order == 1 ? ntile - 1 - tq : tq;
+    } else {
+      pair = fast_div(idx, ntile, mg_tile);  // which of this XCD's pairs
+      tile = idx - pair * ntile;
+    }
     bh = pair * nx + xcd;               // pairs dealt round-robin to XCDs
-    (void)per;
-    (void)total;
+  } else if (order) {
+    const int tq = bid / nbh;
+    bh = bid - tq * nbh;
+    tile = order == 1 ? ntile - 1 - tq : tq;
   } else {
     bh = fast_div(bid, ntile, mg_tile);
     tile = bid - bh * ntile;
@@ -376,7 +391,10 @@ struct AttnArgs {
 };
 
 // workgroup index -> (batch, head, tile).  The grid covers the call's units x tiles (all B * H units, or a unit range).
-FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h, int& tile) {
+#ifndef FAT5_CAUSAL_ORDER
+#define FAT5_CAUSAL_ORDER 1  // 1: the kernels of a causal problem launch their longest workgroups first (decode_block: order 1 for row blocks -- forward, dQ --, 2 for key blocks -- dK/dV); 0: pair-major (rounds 1-4)
+#endif
+FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h, int& tile, int order = 0) {
   const uint32_t mg_tile = ntile == a.n_mblk ? a.mg_mblk : (ntile == a.n_nblk ? a.mg_nblk : 0u);
   if (a.batch_inner) {
     // A batch-broadcast dense bias tile (1, h, m-tile, n-tile) is read by all B batch elements: give the B workgroups of one
@@ -393,12 +411,21 @@ FAT5_DEV void decode_unit(const AttnArgs& a, int bid, int ntile, int& b, int& h,
       b = bid % a.B;
       gid = bid / a.B;
     }
+    if (order) {
+      // causal: tile-major over the heads, longest tiles first -- consecutive groups (= the XCDs at any moment) work on the same tile level.  (The head-major deal
+      // below sends tile (8 k + xcd) % ntile to an XCD: with ntile a power of two every XCD sees only one or two tile indices, i.e. lengths -- the XCDs with the
+      // long ones decide the launch.)
+      const int tq = gid / a.H;
+      h = gid - tq * a.H;
+      tile = order == 1 ? ntile - 1 - tq : tq;
+      return;
+    }
     h = gid / ntile;
     tile = gid - h * ntile;
     return;
   }
   int ui;
-  decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile, mg_tile);
+  decode_block(bid, a.unit_count > 0 ? a.unit_count : a.B * a.H, ntile, ui, tile, mg_tile, order);
   if (a.unit_count > 0) {
     const int u = a.unit_begin + ui;
     h = u / a.B;

@@ -101,7 +101,7 @@ FAT5_DEV void attn_fwd_body(const AttnArgs& a) {
   const int half = SPLIT ? w / QG : 0;                 // SPLIT: which 32-key block of every tile this wave owns
   const int qg = SPLIT ? w - half * QG : w;
   int b, h, mblk;
-  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
 
   int M = a.M, N = a.N;
   int64_t qoff = (int64_t)b * a.qs[0], koff = (int64_t)b * a.ks[0], voff = (int64_t)b * a.vs[0],

@@ -1291,7 +1291,7 @@ template <int D, bool BF16, int BIAS, bool KSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))  // (two waves per SIMD: <= 256 registers)
 void attn_fwd64_kernel(const AttnArgs a) {
   int b, h, mblk;
-  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
   attn_fwd64_body<D, BF16, BIAS, KSPLIT>(a, b, h, mblk * Fwd64Cfg<D, KSPLIT>::BM);
 }
 // head_dim 128 (round 5): one wave per SIMD (512 registers per lane)
@@ -1299,7 +1299,7 @@ template <int D, bool BF16, int BIAS, bool SPREAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd64_w1_kernel(const AttnArgs a) {
   int b, h, mblk;
-  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
   attn_fwd64_body<D, BF16, BIAS, false, SPREAD>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
 }
 // dense bias: the two-tile bias ring (64 KB) beside the K / V rings leaves room for ONE workgroup per CU -- one wave per SIMD
@@ -1307,7 +1307,7 @@ template <int D, bool BF16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_fwd64_dense_kernel(const AttnArgs a) {
   int b, h, mblk;
-  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk);
+  decode_unit(a, blockIdx.x, a.n_mblk, b, h, mblk, (FAT5_CAUSAL_ORDER && a.causal) ? 1 : 0);
   attn_fwd64_body<D, BF16, FAT5_BIAS_DENSE, false>(a, b, h, mblk * Fwd64Cfg<D, false>::BM);
 }
 // Both workgroup forms in ONE launch (round 4) for problems of 1 .. 2 64-row waves per SIMD.  With 1.5 waves of 64 rows per SIMD either
