@@ -487,8 +487,11 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     const long max_wg = (ctab && p->N <= 2048) ? cu_scaled(1536) : FUSED64_MAX_WG;
     // (round 5, no bias: the dK/dV half's diagonal steps are pipelined (mask in the C operand) -- (16,12,512) causal 65.7 vs 72.1 us, (4,12,512) 21.7 vs 22.6;
     //  (4,12,1024) 45.9 either way -> up to 512 keys)
-    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= chip_cus() || tot >= cu_scaled(512) || p->N >= 2048)) ||
-                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (p->N <= 512 || tot <= chip_cus()));  // ((3,5,2048) causal, 240 workgroups: 56.5 vs 70.9 us -- profiles/r05_dispatch_audit_H8_16_32.log)
+    // (closing audit of round 5, after causal launches went longest-first -- profiles/r05c_dispatch_audit_H12.log: T5 bias (4,12,1024), 384 workgroups, 44.6 one launch vs
+    //  49.6 -> the 256 .. 512-workgroup exception holds below 1024 keys only; no bias (2,12,2048) 63.5 vs 70.3, (4,12,2048) 117.4 vs 127.7, (2,12,4096) 195.8 vs 198.7
+    //  -> from 2048 keys on as well; (4,12,1024) 40.6 separate stays)
+    const bool causal_ok = !p->causal || (ctab && squarish && (tot <= chip_cus() || tot >= cu_scaled(512) || p->N >= 1024)) ||
+                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (p->N <= 512 || tot <= chip_cus() || p->N >= 2048));  // ((3,5,2048) causal, 240 workgroups: 56.5 vs 70.9 us -- profiles/r05_dispatch_audit_H8_16_32.log)
     const bool rule = causal_ok && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }

@@ -296,7 +296,10 @@ def test_dispatch_rules_are_pinned():
         (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
-        (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="32row")),                          # (384 workgroups: the measured exception)
+        (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="64row", dkdv="64key", fused="1")),  # (384 workgroups: an exception until causal launches went longest-first -- 44.6 vs 49.6 us, profiles/r05c_dispatch_audit_H12.log)
+        (dict(B=8, H=12, M=512, N=512, causal=True, **rpe), dict(dq="32row")),                            # ... the exception holds below 1024 keys
+        (dict(B=4, H=12, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),        # plain causal from 2048 keys on: 117.4 vs 127.7 us (same audit)
+        (dict(B=2, H=12, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),        # ... 63.5 vs 70.3
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(dq="64row", dkdv="64key", fused="1")),          # causal without bias, up to 512 keys (round 5): the mask rides in the dK/dV half's score MFMAs -- the one-launch 64-wide form (21.7 vs 22.6 us; (16,12,512): 65.7 vs 72.1)
         (dict(B=4, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),                   # ... not beyond (45.9 us either way)
         (dict(B=4, H=12, M=2048, N=2048, **rpe), dict(fwd="64row-mixed", dq="64row", dkdv="64key", fused="1")),   # 1.5 64-row waves per SIMD: 256-row and key-split workgroups in one launch
@@ -312,7 +315,6 @@ def test_dispatch_rules_are_pinned():
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
         (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:20")),         # (round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
-        (dict(B=4, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:4")),
         (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
         (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
@@ -347,7 +349,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=8, M=512, N=512, **rpe), dict(fwd="32row-split", dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=16, M=2048, N=2048, **rpe), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),
         (dict(B=3, H=5, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),         # an under-filled chip (240 workgroups), causal without bias: the one-launch form (56.5 vs 70.9 us)
-        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
+        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),   # (1024 workgroups, plain causal from 2048 keys: the one-launch form since the closing audit of round 5)
         (dict(B=2, H=8, M=128, N=128), dict(fwd="32row", fused="1")),                                     # config 1's shape
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="64row", dq="32row", dkdv="32key")),            # head_dim 128 (round 5): the forward on the pipelined body, one wave per SIMD
