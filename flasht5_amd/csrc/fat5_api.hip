@@ -484,7 +484,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // (4,12,1024) 64.6 vs 60.8, (4,12,2048) 156.0 vs 174.5, (4,12,4096) 433.7 vs 428.1, (16,12,512) 76.5 vs 94.2, (16,12,1024) 208.0 vs 210.1
     const bool ctab = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
     // (round-4 audit: (2,12,2048) causal 80.9 vs 92.9 us -- the 384-workgroup exception holds at <= 1024 keys only; (8,12,2048) causal, 1536 workgroups: 269.8 vs 283.4)
-    const long max_wg = (ctab && p->N <= 2048) ? cu_scaled(1536) : FUSED64_MAX_WG;
+    // (profiles/r05d_dispatch_audit_causal_bwd.log, longest-first order: causal (4,12,4096), 1536 workgroups, one launch 369.3 vs 387.8 us, T5 bias 382.6 vs 414.4;
+    //  (2,32,4096), 2048 workgroups, T5 bias 506.1 vs 534.4, none 486.3 vs 493.5 -> causal problems up to 2048 workgroups)
+    const long max_wg = (ctab && p->N <= 2048) ? cu_scaled(1536) : ((p->causal && (ctab || p->bias_mode == FAT5_BIAS_NONE)) ? cu_scaled(2048) : FUSED64_MAX_WG);
     // (round 5, no bias: the dK/dV half's diagonal steps are pipelined (mask in the C operand) -- (16,12,512) causal 65.7 vs 72.1 us, (4,12,512) 21.7 vs 22.6;
     //  (4,12,1024) 45.9 either way -> up to 512 keys)
     // (closing audit of round 5, after causal launches went longest-first -- profiles/r05c_dispatch_audit_H12.log: T5 bias (4,12,1024), 384 workgroups, 44.6 one launch vs

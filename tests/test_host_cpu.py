@@ -315,7 +315,7 @@ def test_dispatch_rules_are_pinned():
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
         (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:20")),         # (round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
-        (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="32row", dkdv="64key-mixed:4")),
+        (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),   # (1536 workgroups: one launch 369.3 vs 387.8 us with the longest-first order, profiles/r05d_dispatch_audit_causal_bwd.log)
         (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
         (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),
