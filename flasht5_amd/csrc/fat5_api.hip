@@ -250,6 +250,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                         //  (round-4 audit, profiles/r04_dispatch_audit.log: the non-causal 1.5-waves-per-SIMD exception at <= 512 keys is gone -- (16,12,512) T5 bias 23.3
                         //   key-split vs 25.0 us for the 32-row body, 21.7 vs 22.0 without bias)
                         !(p->N <= 512 && p->causal && !ctab) &&
+                        // (closing audit of round 5, profiles/r05c_dispatch_audit_H12.log: (2,12,1024) causal, 384 waves -- 15.5 vs 12.5 us for the 32-row body, T5 bias 14.8 vs 13.4;
+                        //  (4,12,1024) causal, 768 waves, 15.6 either way -> causal problems of 513 .. 2047 keys from 768 waves on)
+                        !(p->causal && p->N > 512 && p->N < 2048 && waves64 < cu_scaled(768)) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     c.fwd64 = true;

@@ -297,6 +297,8 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
         (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="64row", dkdv="64key", fused="1")),  # (384 workgroups: an exception until causal launches went longest-first -- 44.6 vs 49.6 us, profiles/r05c_dispatch_audit_H12.log)
+        (dict(B=2, H=12, M=1024, N=1024, causal=True), dict(fwd="32row-split")),                           # forward, causal, 384 waves of 64 rows at 1024 keys: the 32-row body (12.5 vs 15.5 us)
+        (dict(B=4, H=12, M=1024, N=1024, causal=True), dict(fwd="64row-ksplit")),                          # ... 768 waves: the pipelined body
         (dict(B=8, H=12, M=512, N=512, causal=True, **rpe), dict(dq="32row")),                            # ... the exception holds below 1024 keys
         (dict(B=4, H=12, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),        # plain causal from 2048 keys on: 117.4 vs 127.7 us (same audit)
         (dict(B=2, H=12, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),        # ... 63.5 vs 70.3
