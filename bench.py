@@ -122,21 +122,21 @@ def graph_time(fn, it=20):
                 fn()
     torch.cuda.current_stream().wait_stream(side)
     # wall-clock pre-warm like event_stats (the first milliseconds after an idle gap run at the idle clock: three replays of a 30 us kernel are not
-    # enough to leave it), then the median of three timed replays
+    # enough to leave it), then the median of five timed replays
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.1:
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
     ts = []
-    for _ in range(3):
+    for _ in range(5):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         g.replay()
         e.record()
         torch.cuda.synchronize()
         ts.append(s.elapsed_time(e) / it * 1e-3)
-    return sorted(ts)[1]
+    return sorted(ts)[2]
 
 
 def rowwise_bench(device):
@@ -184,22 +184,30 @@ def rowwise_bench(device):
     for p_ in params:
         p_.grad = (torch.randn_like(p_) * 0.01)
     opt = AdamWScale(params, lr=1e-3, weight_decay=0.01, kahan_sum=True)
-    for _ in range(3):
+    # (one un-warmed sample of five steps read 1.82 ms where every other run reads 1.17) -- wall-clock pre-warm, then the
+    #  median of seven separately event-timed steps, min / max beside it
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.2:
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize()
+    dev_t, wall_t = [], []
+    for _ in range(7):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        s_.record()
         opt.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s_.record()
-    for _ in range(5):
-        opt.step()
-    e_.record()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / 5
+        e_.record()
+        torch.cuda.synchronize()
+        wall_t.append(time.perf_counter() - t0)
+        dev_t.append(s_.elapsed_time(e_) * 1e-3)
+    wall = sorted(wall_t)[3]
     n_el = sum(p_.numel() for p_ in params)
     byt = n_el * 2 * 10  # sumsq pass reads p; update reads p, g, m, v, k and writes p, m, v, k
-    dev_s = s_.elapsed_time(e_) / 5 * 1e-3
+    dev_s = sorted(dev_t)[3]
     out["adamw_scale_fat5_base"] = {"params_M": round(n_el / 1e6, 1), "tensors": len(params), "ms_per_step_wall": round(wall * 1e3, 3),
-                                    "ms_per_step_device": round(dev_s * 1e3, 3), "GBs": round(byt / dev_s / 1e9, 1),
+                                    "ms_per_step_device": round(dev_s * 1e3, 3), "ms_per_step_device_min_max": [round(min(dev_t) * 1e3, 3), round(max(dev_t) * 1e3, 3)],
+                                    "timing": "median of 7 event-timed steps after a 0.2 s pre-warm", "GBs": round(byt / dev_s / 1e9, 1),
                                     "frac": round(byt / dev_s / 1e9 / PEAK_HBM_GBS, 3),
                                     "bytes_model": "10 x 2 B per element (bf16 + Kahan): p twice, g, m, v, k read; p, m, v, k written"}
     del params, opt
@@ -355,25 +363,34 @@ def cfg5_step_flops(cfg, B, S, T):
 
 
 def n3_bench(device):
-    """SURVEY 8(f) n3's fusions, kernel time by graph replay (bf16): pre-norm inside the projection GEMM against norm kernel +
-    library GEMM; residual add as GEMM epilogue; chunked lm_head -> loss against the full-logits form (time and peak memory)"""
+    """SURVEY 8(f) n3's fusions, kernel time by graph replay (bf16): the stacked projections behind the pre-norm (ONE library GEMM for q | k | v and for
+    wi_0 | wi_1: flasht5_amd/fused_linear.py) against the reference's op sequence (layer_norm, then one nn.Linear per weight, modeling_flash_t5.py:304-318,
+    :159-160); the residual add in the GEMM epilogue against add + linear; chunked lm_head -> loss against the full-logits form (time and peak memory).
+    Round 6: every GEMM here is a library GEMM -- the hand-written `fat5_linear_fused` of rounds 3-5 (32-34 us for norm + QKV where norm kernel + library
+    GEMM take 25-26) is gone."""
     from flasht5_amd import rmsnorm_linear, linear_residual, fast_rms_layernorm, lm_head_cross_entropy, cross_entropy_loss
     out = {}
     M, K = 4096, 768
     x = torch.randn(M, K, device=device).bfloat16()
     g = torch.ones(K, device=device).bfloat16()
     with torch.no_grad():
-        for N, tag in ((2304, "qkv"), (4096, "wi01")):
-            W = (torch.randn(N, K, device=device) / K ** 0.5).bfloat16()
-            tf = graph_time(lambda: rmsnorm_linear(x, g, W, 1e-6))
-            ts = graph_time(lambda: torch.nn.functional.linear(fast_rms_layernorm(x, g, 1e-6), W))
+        for ns, tag in (((768, 768, 768), "qkv"), ((2048, 2048), "wi01")):
+            ws = tuple((torch.randn(n, K, device=device) / K ** 0.5).bfloat16() for n in ns)
+            N = sum(ns)
+
+            def separate():
+                y = fast_rms_layernorm(x, g, 1e-6)
+                return [torch.nn.functional.linear(y, w) for w in ws]
+            tf = graph_time(lambda: rmsnorm_linear(x, g, ws, 1e-6))
+            ts = graph_time(separate)
             out[f"rmsnorm_linear_{tag}_{M}x{N}x{K}"] = {"fused_us": round(tf * 1e6, 2), "separate_us": round(ts * 1e6, 2),
-                                                       "fused_tflops": round(2.0 * M * N * K / tf / 1e12, 1)}
+                                                       "fused_tflops": round(2.0 * M * N * K / tf / 1e12, 1),
+                                                       "what": f"fused = stack launch + norm kernel + ONE library GEMM (N = {N}); separate = norm kernel + {len(ns)} library GEMMs (the reference's sequence)"}
         W = (torch.randn(K, K, device=device) / K ** 0.5).bfloat16()
         r = torch.randn(M, K, device=device).bfloat16()
         tf = graph_time(lambda: linear_residual(x, W, r))
         ts = graph_time(lambda: r + torch.nn.functional.linear(x, W))
-        out[f"linear_residual_{M}x{K}x{K}"] = {"fused_us": round(tf * 1e6, 2), "separate_us": round(ts * 1e6, 2)}
+        out[f"linear_residual_{M}x{K}x{K}"] = {"fused_us": round(tf * 1e6, 2), "separate_us": round(ts * 1e6, 2), "what": "fused = torch.addmm (the add in the library GEMM's epilogue)"}
     # the config-5 step (FAT5-base, B = 4, 1024 / 512 tokens, one GPU) forward + backward in its three formulations: wall time (the eager
     # step is host-bound), kernel launches and the stand-alone RMSNorm launches among them, per step
     from flasht5_amd import FAT5Config, FAT5ForConditionalGeneration
@@ -617,6 +634,24 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def launch_plan(world, graph_steps, bucket, no_graph, steps, want_reduce=True):
+    """How the timed region is launched -- ONE rule for every N (the 1 -> N curve must compare one method): U steps per HIP-graph
+    replay (--graph-steps, default 16; a nearby divisor of --steps), and with more than one rank the all-reduce of EVERY step's bias(-table) gradient
+    captured inside that graph (U collectives per replay: `allreduce` == "in-graph").  Returns what the JSON line reports; `allreduce` falls back to
+    "per-step" (one replay + one all-reduce enqueued from Python per step) only when the collective cannot be captured (gloo dry runs; a failing
+    capture), and is "bucketed" with --bucket-allreduce."""
+    U = 1 if no_graph else max(1, graph_steps)
+    if U > 1 and steps % U:
+        div = [u for u in range(8, 33) if steps % u == 0]
+        if div:
+            U = min(div, key=lambda u: (abs(u - U), u))
+    mode = None
+    if world > 1 and want_reduce:
+        mode = "bucketed" if (bucket and U > 1) else ("in-graph" if U > 1 else "per-step")
+    return {"steps_per_replay": U, "allreduce": mode,
+            "launch": ("eager C-ABI calls" if no_graph else f"hipGraph replay, {U} step(s) per replay")}
+
+
 def drive_steps(steps, U, one_step, replay_u, reducer, grad, stash):
     """The loop of the timed region: exactly `steps` steps of the local path and the exchange of each step's bias(-table) gradient.
     U == 1 (the default with N > 1 ranks): after every step `grad` goes into ONE all-reduce (asynchronous, double-buffered: it overlaps
@@ -674,34 +709,52 @@ def main():
     if os.environ.get("FAT5_BENCH_RENDEZVOUS_ONLY") == "1":
         # control-flow check that runs without a GPU (tests/test_distributed_cpu.py): rendezvous + one all-reduce over gloo
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)])
-        dist.all_reduce(t)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.all_reduce(t)
         # the N > 1 loop of the timed region with a stand-in for the local step (the HIP path needs a GPU): what is under test is how
         # many collectives a step costs
         from flasht5_amd.sharding import OverlappedGradReduce
         grad = torch.zeros(32, H)
-        U = max(1, args.graph_steps) if args.bucket_allreduce else 1
-        stash = torch.zeros((U, 32, H)) if U > 1 else None
-        cnt = {"i": 0}
+        lp = launch_plan(world, args.graph_steps, args.bucket_allreduce, args.no_graph, args.steps)
+        U = lp["steps_per_replay"]
+        stash = torch.zeros((U, 32, H)) if lp["allreduce"] == "bucketed" else None
+        cnt = {"i": 0, "ar": 0}
 
         def one_step():
             cnt["i"] += 1
             grad.fill_(float(cnt["i"] * (rank + 1)))
 
-        def replay_u():
+        def replay_u():  # stand-in for one replay of the U-step graph
             for u in range(U):
                 one_step()
-                stash[u].copy_(grad)
+                if stash is not None:
+                    stash[u].copy_(grad)
+                if lp["allreduce"] == "in-graph":  # (the captured collective of step u)
+                    dist.all_reduce(grad)
+                    cnt["ar"] += 1
+                    assert float(grad[0, 0]) == cnt["i"] * sum(r + 1 for r in range(world))  # this step's own gradient, summed over the ranks
 
-        red = OverlappedGradReduce(stash if stash is not None else grad)
-        n_ar = drive_steps(args.steps, U, one_step, replay_u if U > 1 else None, red, grad, stash)
+        if lp["allreduce"] == "in-graph":
+            for _ in range(args.steps // U):
+                replay_u()
+            for _ in range(args.steps % U):
+                one_step()
+                dist.all_reduce(grad)
+                cnt["ar"] += 1
+            n_ar = cnt["ar"]
+        else:
+            red = OverlappedGradReduce(stash if stash is not None else grad)
+            n_ar = drive_steps(args.steps, U, one_step, replay_u if U > 1 else None, red, grad, stash)
         if rank == 0:
             print(json.dumps({"rendezvous": world, "n_gpus": world, "gpus_arg": args.gpus, "sum_of_ranks_plus_1": t.item(),
-                              "scaling": args.scaling, "steps": args.steps, "allreduces": n_ar,
-                              "allreduces_per_step": round(n_ar / args.steps, 4)}), flush=True)
-        dist.barrier()
-        dist.destroy_process_group()
+                              "scaling": args.scaling, "steps": args.steps, "allreduces": n_ar, "steps_run": cnt["i"],
+                              "allreduces_per_step": round(n_ar / args.steps, 4), "launch": lp["launch"],
+                              "steps_per_replay": U, "allreduce": lp["allreduce"]}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
@@ -753,30 +806,70 @@ def main():
         torch.cuda.synchronize()
     from flasht5_amd.sharding import OverlappedGradReduce
     want_reduce = world > 1 and mode != "none"
-    # several steps per replay: the same launches in the same order, one host call per U steps.  With more than one rank every step's
-    # bias(-table) gradient is kept (one stream-ordered copy per step inside the graph, what the reducer's staging copy is at U = 1) and
-    # the U of them travel in ONE all-reduce per replay: every step's gradient is reduced exactly once, in buckets of U.
-    U = max(1, args.graph_steps) if graph is not None else 1
-    if want_reduce and not args.bucket_allreduce:
-        U = 1  # north star: "a single RCCL all-reduce of the bias gradient" per backward -- every step's gradient leaves in its own collective
-    if U > 1 and args.steps % U:  # a step count that is not a multiple: a nearby replay length that divides it, so no step is left to single replays
-        div = [u for u in range(8, 33) if args.steps % u == 0]
-        if div:
-            U = min(div, key=lambda u: (abs(u - U), u))
-    graph_u, stash = None, None
-    if U > 1:
-        if want_reduce:
-            stash = torch.zeros((U,) + tuple(plan.dbias.shape), dtype=torch.float32, device=device)
-        graph_u = torch.cuda.CUDAGraph()
+    # ONE launch rule for every N (launch_plan): U steps per replay -- the same launches in the same order, one host call per U steps -- and with more
+    # than one rank the all-reduce of every step's bias(-table) gradient INSIDE the captured graph (RCCL collectives are stream operations: U of them per
+    # replay, each between its step's backward and the next step's forward, in place on the gradient).  --bucket-allreduce: the U gradients are kept (one
+    # stream-ordered copy per step inside the graph) and travel in ONE all-reduce per replay instead.
+    lp = launch_plan(world, args.graph_steps, args.bucket_allreduce, graph is None, args.steps, want_reduce)
+    U = lp["steps_per_replay"]
+    graph_u, stash, ar_fallback = None, None, None
+
+    def capture_u(with_allreduce):
+        g_ = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
-            with torch.cuda.graph(graph_u, stream=side):
+            with torch.cuda.graph(g_, stream=side):
                 for u in range(U):
                     step_local()
                     if stash is not None:
                         stash[u].copy_(plan.dbias)
+                    if with_allreduce:
+                        dist.all_reduce(plan.dbias)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-    reducer = OverlappedGradReduce(stash if stash is not None else plan.dbias) if want_reduce else None
+        return g_
+
+    def all_ranks_agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    if U > 1:
+        if lp["allreduce"] == "bucketed":
+            stash = torch.zeros((U,) + tuple(plan.dbias.shape), dtype=torch.float32, device=device)
+        if lp["allreduce"] == "in-graph":
+            ok, why = True, None
+            if share:
+                ok, why = False, "gloo dry run on one GPU: a host-side collective cannot be captured"
+            if ok:
+                try:
+                    with torch.cuda.stream(side):
+                        dist.all_reduce(plan.dbias)  # (communicator and its streams exist before the capture starts)
+                    torch.cuda.synchronize()
+                    graph_u = capture_u(True)
+                except Exception as e:  # noqa: BLE001  (capture refused: every rank must learn it -- see all_ranks_agree)
+                    ok, why, graph_u = False, f"capture failed: {str(e)[:120]}", None
+                    torch.cuda.synchronize()
+            if not share:
+                agreed = all_ranks_agree(ok)
+                if ok and not agreed:
+                    ok, why, graph_u = False, "capture failed on another rank", None
+            if ok:
+                # the replayed collectives must give what the eager ones give: one step + one eager all-reduce against the last step of one replay
+                step_local()
+                want_t = plan.dbias.clone()
+                dist.all_reduce(want_t)
+                graph_u.replay()
+                torch.cuda.synchronize()
+                good = bool(torch.allclose(plan.dbias, want_t, rtol=1e-3, atol=1e-3 * float(want_t.abs().max())))
+                if not all_ranks_agree(good):
+                    ok, why, graph_u = False, "replayed all-reduce differs from the eager one", None
+            if not ok:
+                ar_fallback = why
+                lp = dict(lp, allreduce="per-step", steps_per_replay=1, launch="hipGraph replay, 1 step(s) per replay")
+                U = 1
+        if U > 1 and graph_u is None:
+            graph_u = capture_u(False)
+    reducer = OverlappedGradReduce(stash if stash is not None else plan.dbias) if (want_reduce and lp["allreduce"] != "in-graph") else None
 
     def one_step():
         if graph is not None:
@@ -797,16 +890,34 @@ def main():
                 step_local()
         torch.cuda.synchronize()
 
-    def timed(use_bucket):
-        """exactly args.steps steps between two barriers; returns (max-over-ranks seconds, all-reduces submitted by this rank inside the region)"""
-        u = U if (use_bucket and graph_u is not None) else 1
-        drive_steps(args.warmup, 1, one_step, None, reducer if u == 1 else None, plan.dbias, None)
+    def run_region(steps, form):
+        """exactly `steps` steps in launch form `form` ("replay-u": U steps per replay; "per-step"); returns the all-reduces this rank submitted"""
+        if form == "replay-u" and lp["allreduce"] == "in-graph":
+            for _ in range(steps // U):
+                graph_u.replay()  # U steps, U captured all-reduces
+            n = (steps // U) * U
+            for _ in range(steps % U):  # (leftover steps: one replay + one eager all-reduce each)
+                one_step()
+                dist.all_reduce(plan.dbias)
+                n += 1
+            return n
+        if form == "replay-u" and graph_u is not None:
+            return drive_steps(steps, U, one_step, graph_u.replay, reducer, plan.dbias, stash)
+        return drive_steps(steps, 1, one_step, None, reducer, plan.dbias, None)
+
+    def timed(form, red=None):
+        """exactly args.steps steps between two barriers; returns (max-over-ranks seconds, all-reduces submitted by this rank inside the region, host seconds spent enqueueing)"""
+        nonlocal reducer
+        if red is not None:
+            reducer = red
+        run_region(args.warmup, form)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = drive_steps(args.steps, u, one_step, graph_u.replay if u > 1 else None, reducer, plan.dbias, stash)
+        n = run_region(args.steps, form)
+        t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -815,16 +926,15 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
-        return el, n
+        return el, n, t_host
 
-    elapsed, n_ar = timed(True)
+    elapsed, n_ar, host_s = timed("replay-u")
     per_step_form = None
     if graph_u is not None:
-        # the other launch form beside the headline: one replay (and, N > 1, one all-reduce) per step
-        if reducer is not None:
-            reducer = OverlappedGradReduce(plan.dbias)
-        e1, n1 = timed(False)
-        per_step_form = {"ms_per_step": round(e1 / args.steps * 1e3, 5), "launch": "hipGraph replay, 1 step per replay"}
+        # the other launch form beside the headline: one replay (and, N > 1, one all-reduce enqueued from Python) per step
+        e1, n1, h1 = timed("per-step", OverlappedGradReduce(plan.dbias) if want_reduce else None)
+        per_step_form = {"ms_per_step": round(e1 / args.steps * 1e3, 5), "launch": "hipGraph replay, 1 step per replay",
+                         "host_enqueue_ms_per_step": round(h1 / args.steps * 1e3, 5)}
         if want_reduce:
             per_step_form["allreduces_per_step"] = round(n1 / args.steps, 4)
     ms_per_step = elapsed / args.steps * 1e3
@@ -852,15 +962,22 @@ def main():
                                    f"32-bucket T5 RPE bias ({mode} mode), sm_scale 0.125, (B,S,H,D)-strided inputs",
                        "global_batch": B if strong else B * world, "seq_len": S,
                        "parallelism": (f"units{world} ({units[1]} of {B * H} (batch, head) units per GPU)" if strong else f"dp{world}"),
-                       "bias_mode": mode, "launch": (f"hipGraph replay, {U} step(s) per replay" if graph is not None else "eager C-ABI calls")},
+                       "bias_mode": mode, "launch": lp["launch"]},
             "frac_of_peak": round(value / (PEAK_BF16_TFLOPS * world), 4),
             "per_gpu_tflops": round(value / world, 2),
+            # host time spent enqueueing the timed region / steps (graph replays and, in the per-step form, collectives): the loop is device-bound while this stays below ms_per_step
+            "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 5),
         }
         if want_reduce:
             # collectives this rank submitted inside the timed region / steps: 1.0 = the north star's "single RCCL all-reduce of the bias
-            # gradient" per backward (the default); 1/U only with --bucket-allreduce
+            # gradient" per backward (the default: every step's own all-reduce, captured in the graph beside its kernels); 1/U only with --bucket-allreduce
             out["allreduces_per_step"] = round(n_ar / args.steps, 4)
-            out["allreduce_mode"] = "bucketed: one per replay of %d steps" % U if (args.bucket_allreduce and U > 1) else "one per step"
+            out["allreduce_mode"] = {"in-graph": "one per step, captured inside the HIP graph (%d per replay)" % U,
+                                     "bucketed": "bucketed: one per replay of %d steps" % U,
+                                     "per-step": "one per step, enqueued from Python after each replay"}[lp["allreduce"]]
+            out["allreduce_in_graph"] = lp["allreduce"] == "in-graph"
+            if ar_fallback is not None:
+                out["allreduce_in_graph_fallback"] = ar_fallback
         if per_step_form is not None:
             out["one_replay_per_step"] = per_step_form
         if ar_ms is not None:

@@ -48,7 +48,7 @@ EXPORTS = (
     "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages", "fat5_attn_describe", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
-    "fat5_ce_fwd", "fat5_ce_bwd", "fat5_ce_fwd_bwd", "fat5_linear_fused", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_fold_weights_bwd_scratch_bytes", "fat5_rmsnorm_unit_bwd", "fat5_gated_act_fwd", "fat5_gated_act_bwd",
+    "fat5_ce_fwd", "fat5_ce_bwd", "fat5_ce_fwd_bwd", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_fold_weights_bwd_scratch_bytes", "fat5_rmsnorm_unit_bwd", "fat5_gated_act_fwd", "fat5_gated_act_bwd",
     "fat5_adamw_scale_step", "fat5_adamw_scale_step_clipped", "fat5_adamw_scale_step_dev", "fat5_adamw_grad_sumsq", "fat5_sizeof_adamw_tensor",
 )
 
@@ -95,8 +95,6 @@ def load():
     lib.fat5_add_rmsnorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp, ctypes.c_size_t, vp]
     lib.fat5_ce_fwd.restype = ctypes.c_int
     lib.fat5_ce_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, i64, i32, i32, vp]
-    lib.fat5_linear_fused.restype = ctypes.c_int
-    lib.fat5_linear_fused.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp]
     lib.fat5_fold_weights_bwd.restype = ctypes.c_int
     lib.fat5_fold_weights_bwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, i32, vp, ctypes.c_size_t, vp]
     lib.fat5_fold_weights_bwd_scratch_bytes.restype = ctypes.c_size_t

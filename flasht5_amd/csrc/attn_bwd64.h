@@ -402,6 +402,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // rows 8 jj + 4 hi + (0..3), jj = 2 t2 + j2, at its key of block kb: that read, twice, is the B operand (jj, kb) -- and the selector operands E(jj)
   [[maybe_unused]] uint32_t btr[2][2] = {{0u, 0u}, {0u, 0u}};
   [[maybe_unused]] u32x4 selA[4];
+  // (the raw bias words are MFMA operands: -inf entries are clamped in their packed 16-bit form first -- -inf * 0 in the selector product would be NaN: attn_common.h)
+  [[maybe_unused]] const uint32_t blim2 = bias_mfma_limit<BF16>(a.scale);
   if constexpr (DENSE) {
     // E(jj): A operand, lane = row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3), holding 1/scale's leading 16 bits for j < 4 and the next 16 for j >= 4
     const float invf = 1.f / a.scale;
@@ -516,13 +518,14 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) Sx[kb] = mfma32<BF16>(selA[t2], lds_rd_tr(btr[0][kb] + so + (uint32_t)(2048 * t2), btr[1][kb] + so + (uint32_t)(2048 * t2)), Sx[kb]);
+          for (int kb = 0; kb < 2; ++kb)
+            Sx[kb] = mfma32<BF16>(selA[t2], bias_clamp_frag(lds_rd_tr(btr[0][kb] + so + (uint32_t)(2048 * t2), btr[1][kb] + so + (uint32_t)(2048 * t2)), blim2), Sx[kb]);
       } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
-            const u32x2 bh_ = lds_rd_tr_half(btr[jj & 1][kb] + so + (uint32_t)(2048 * (jj >> 1)));
+            const u32x2 bh_ = bias_clamp_frag(lds_rd_tr_half(btr[jj & 1][kb] + so + (uint32_t)(2048 * (jj >> 1))), blim2);
             Sx[kb] = mfma32<BF16>(selA[jj], u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, Sx[kb]);
           }
       }
@@ -777,6 +780,16 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else if constexpr (g == 17) bbh[0][3] = lds_rd_tr_half(btr[1][0] + o_next + 2048u);
         else if constexpr (g == 18) bbh[1][2] = lds_rd_tr_half(btr[0][1] + o_next + 2048u);
         else if constexpr (g == 19) bbh[1][3] = lds_rd_tr_half(btr[1][1] + o_next + 2048u);
+        // ... clamped three gaps after their reads (two v_pk_min_u16 per fragment), ahead of the MFMAs of gaps 20..23 that take them
+        if constexpr (g == 16) bbh[0][0] = bias_clamp_frag(bbh[0][0], blim2);
+        else if constexpr (g == 17) {
+          bbh[0][1] = bias_clamp_frag(bbh[0][1], blim2);
+          bbh[1][0] = bias_clamp_frag(bbh[1][0], blim2);
+        } else if constexpr (g == 18) bbh[1][1] = bias_clamp_frag(bbh[1][1], blim2);
+        else if constexpr (g == 19) bbh[0][2] = bias_clamp_frag(bbh[0][2], blim2);
+        else if constexpr (g == 20) bbh[0][3] = bias_clamp_frag(bbh[0][3], blim2);
+        else if constexpr (g == 21) bbh[1][2] = bias_clamp_frag(bbh[1][2], blim2);
+        else if constexpr (g == 22) bbh[1][3] = bias_clamp_frag(bbh[1][3], blim2);
         // the gap's second MFMA: key block 1
         if constexpr (!ONE && g >= 16 && g < 24) {
           __builtin_amdgcn_sched_barrier(0);

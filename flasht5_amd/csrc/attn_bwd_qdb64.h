@@ -299,6 +299,7 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
   }
   // selector operands E(jj) (B: lane = query row lq; k-slot (hi, j) <-> bias row 8 jj + 4 hi + (j & 3), 1/scale's leading 16 bits for j < 4, the next 16 for j >= 4)
   u32x4 selB[4];
+  const uint32_t blim2 = bias_mfma_limit<BF16>(a.scale);  // (packed clamp of the bias words ahead of their MFMAs)
   {
     const float invf = 1.f / a.scale;
     uint32_t ih, il;
@@ -398,14 +399,14 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
           const uint32_t o = bo + (uint32_t)(qb * 2048 + t2 * 1024);
-          Sx[qb] = mfma32<BF16>(lds_rd_tr(btA[0] + o, btA[1] + o), selB[t2], Sx[qb]);
+          Sx[qb] = mfma32<BF16>(bias_clamp_frag(lds_rd_tr(btA[0] + o, btA[1] + o), blim2), selB[t2], Sx[qb]);
         }
     } else {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-          const u32x2 bh_ = lds_rd_tr_half(btA[jj & 1] + bo + (uint32_t)(qb * 2048 + (jj >> 1) * 1024));
+          const u32x2 bh_ = bias_clamp_frag(lds_rd_tr_half(btA[jj & 1] + bo + (uint32_t)(qb * 2048 + (jj >> 1) * 1024)), blim2);
           Sx[qb] = mfma32<BF16>(u32x4{bh_[0], bh_[1], bh_[0], bh_[1]}, selB[jj], Sx[qb]);
         }
     }
@@ -607,6 +608,11 @@ FAT5_DEV void attn_bwd_qdb64_body(const AttnArgs& a, void* dbias_out, const int 
         if constexpr (g < 14) Sn[1] = mfma32<BF16>(kf[g - 10], qf[1][g - 10], Sn[1]);
         else Sn[1] = mfma32<BF16>(bfrag1(1, g - 14), selB[g - 14], Sn[1]);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      // (the bias words are MFMA operands: clamped in their packed form two gaps after their reads, two gaps ahead of their MFMAs -- -inf * 0 would be NaN: attn_common.h)
+      if constexpr (g >= 10 && g < 14) {
+        bf[0][g - 10] = bias_clamp_frag(bf[0][g - 10], blim2);
+        bf[1][g - 10] = bias_clamp_frag(bf[1][g - 10], blim2);
       }
       // ---- the dbias tile of step i-1 leaves ----
       if constexpr (g == 14 && !(FAT5_QDB_ABL & 1)) x_store(acc, row_ok ? dvo : 0x80000000u, t >= 1 ? (uint32_t)((t - 1) * 32 * ESZ) : dbrec);

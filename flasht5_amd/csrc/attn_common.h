@@ -150,6 +150,31 @@ FAT5_DEV uint32_t bias_clamp2(uint32_t w) {  // two packed bias values
 template <bool BF16>
 FAT5_DEV uint16_t bias_clamp1(uint16_t h) { return BF16 ? (h < (uint16_t)0xFF16u ? h : (uint16_t)0xFF16u) : h; }
 FAT5_DEV float bias_log2(float b) { return b * kLog2e; }  // (b already clamped in its 16-bit form)
+// Bias on the matrix pipe (S' = Q K^T + E B with a 0 / (1 / scale) selector E: attn_bwd64.h, attn_bwd_qdb64.h): the raw 16-bit bias words are MFMA operands, so a
+// -inf entry (an additive mask written as -inf instead of finfo.min) would meet the selector's zeros as -inf * 0 = NaN and poison every score of its k-slot group
+// (ADVICE r5).  The words are clamped in their packed form first, one v_pk_min_u16 per two values like bias_clamp2: bf16 to -min(2e38, 2e38 |scale|) -- the product
+// with 1 / scale then stays finite in fp32 as well --, fp16 to finfo.min (-65504 / scale is far inside fp32).  NaN words with the sign bit set clamp too; positive
+// values are untouched.  These bodies recompute p = exp2(S' c2) with -L / scale already inside S': a masked key ends at ~ -2e38 -> p = 0, no difference of two huge
+// numbers is ever formed.  (The FORWARD keeps its per-element bias add -- round 6 tried the selector form in the 32-row body, profiles/r06_dense_fwd_ab.log: -4 % at
+// (4,12,512), +4 % at (4,12,2048), +11 % at the reference's B = 16 causal shape with its two-term scale 1.3 -- the body is not VALU-bound at two waves per SIMD -- and
+// a row masked ENTIRELY by finfo.min came out wrong: the MFMA accumulation of q.k onto -2e38 does not absorb the small term symmetrically the way the fp32 FMA's
+// round-to-nearest does (results one ulp = 2e31 apart by the sign of q.k), so x - max(x) is no longer 0 on such a row.)
+template <bool BF16>
+FAT5_DEV uint32_t bias_mfma_limit(float scale) {
+  if constexpr (BF16) {
+    const uint32_t h = __float_as_uint(-fminf(2.0e38f, 2.0e38f * fabsf(scale))) >> 16;  // (truncated: the smaller magnitude)
+    return h | (h << 16);
+  } else {
+    return 0xFBFFFBFFu;
+  }
+}
+FAT5_DEV uint32_t pk_min_u16(uint32_t w, uint32_t lim2) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, w), __builtin_bit_cast(u16x2_t, lim2)));
+}
+FAT5_DEV u32x2 bias_clamp_frag(u32x2 f, uint32_t lim2) { return u32x2{pk_min_u16(f[0], lim2), pk_min_u16(f[1], lim2)}; }
+FAT5_DEV u32x4 bias_clamp_frag(u32x4 f, uint32_t lim2) {
+  return u32x4{pk_min_u16(f[0], lim2), pk_min_u16(f[1], lim2), pk_min_u16(f[2], lim2), pk_min_u16(f[3], lim2)};
+}
 // backward: a query row with lse below this has every key masked (by the causal rule: -inf; by a finfo.min bias: ~ -2e38);
 // its probabilities are treated as zero (dq = 0 for the row, no contribution to dk / dv / dbias)
 constexpr float kDeadRowLse = -1.0e30f;

@@ -14,7 +14,7 @@
 #include "reduce_kernels.h"
 #include "rowwise_kernels.h"
 #include "adamw_kernels.h"
-#include "linear_fused.h"
+#include "fold_weights.h"
 
 using namespace fat5;
 
@@ -1026,60 +1026,8 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const 
 }
 
 // ============================================================================================
-// Linear with the pre-norm / the residual add fused in
+// Stacked projection weights (fold_weights.h)
 // ============================================================================================
-int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, float* rstd_out, int64_t M, int64_t N, int64_t K,
-                      int64_t lda, int64_t ldw, int64_t ldr, int64_t ldo, int norm, float eps, int dtype, void* stream_) {
-  if (!a || !w || !out) return fail(FAT5_EINVAL, "linear_fused: null pointer");
-  if (dtype != FAT5_F16 && dtype != FAT5_BF16) return fail(FAT5_EINVAL, "linear_fused: 16-bit dtypes only");
-  if (M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffffLL || N > 0x7fffffffLL || K > 0x7fffffffLL) return fail(FAT5_EINVAL, "linear_fused: bad shape");
-  if (K % 64 != 0 || N % 8 != 0) return fail(FAT5_EINVAL, "linear_fused: K must be a multiple of 64 and N of 8 (K = %lld, N = %lld)", (long long)K, (long long)N);
-  if (!aligned16(a) || !aligned16(w) || !aligned16(out) || (res && !aligned16(res)) || lda % 8 || ldw % 8 || ldo % 8 || (res && ldr % 8))
-    return fail(FAT5_EINVAL, "linear_fused: operands must be 16-byte aligned with row strides that are multiples of 8 elements");
-  if (!slice_fits(128, lda, (int)K) || !slice_fits(128, ldw, (int)K)) return fail(FAT5_EINVAL, "linear_fused: a 128-row tile must span less than 2 GiB");
-  LinArgs p;
-  p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.res = (const uint16_t*)res; p.out = (uint16_t*)out; p.rstd_out = rstd_out;
-  p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.eps = eps;
-  const long grid = ((M + 127) / 128) * ((N + 127) / 128);
-  if (grid > 0x7fffffffL) return fail(FAT5_EINVAL, "linear_fused: grid too large");
-  hipStream_t stream = (hipStream_t)stream_;
-  const bool bf16 = dtype == FAT5_BF16;
-  // Stage ring of the kernel (linear_fused.h): two 32-KiB stages leave room for two workgroups per CU -- what a grid of more than 256
-  // tiles wants (measured, tools/lin_tune.py: 4096 x 4096 x 768 38.9 us against 49 us with three or four stages and one workgroup
-  // per CU); a grid that gives every CU at most one tile runs a deeper ring instead (4096 x 768 x 2048: 27.8 against 31.5 us).
-  using LC2 = LinCfgT<64, 2>; using LC3 = LinCfgT<64, 3>; using LC4 = LinCfgT<64, 4>;
-  const int ring = grid > 256 ? 2 : (K >= 1024 ? 4 : (grid > 128 ? 3 : 2));
-#define LIN_LAUNCH_C(BF, NO, RE, CFG)                                                                                           \
-  do {                                                                                                                          \
-    auto kern = linear_fused_kernel<BF, NO, RE, CFG>;                                                                           \
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CFG::SMEM); \
-    if (ea != hipSuccess) return hip_fail(ea, "linear_fused attribute");                                                        \
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), CFG::SMEM, stream, p);                                            \
-  } while (0)
-#define LIN_LAUNCH(BF, NO, RE)                                                                                                  \
-  do {                                                                                                                          \
-    if (ring == 4) LIN_LAUNCH_C(BF, NO, RE, LC4);                                                                               \
-    else if (ring == 3) LIN_LAUNCH_C(BF, NO, RE, LC3);                                                                          \
-    else LIN_LAUNCH_C(BF, NO, RE, LC2);                                                                                         \
-  } while (0)
-  if (bf16) {
-    if (norm && res) LIN_LAUNCH(true, true, true);
-    else if (norm) LIN_LAUNCH(true, true, false);
-    else if (res) LIN_LAUNCH(true, false, true);
-    else LIN_LAUNCH(true, false, false);
-  } else {
-    if (norm && res) LIN_LAUNCH(false, true, true);
-    else if (norm) LIN_LAUNCH(false, true, false);
-    else if (res) LIN_LAUNCH(false, false, true);
-    else LIN_LAUNCH(false, false, false);
-  }
-#undef LIN_LAUNCH_C
-#undef LIN_LAUNCH
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "linear_fused launch");
-  return FAT5_OK;
-}
-
 int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0, int64_t ld1,
                       int64_t ld2, const void* g, void* out, int64_t K, int dtype, void* stream_) {
   if (!w0 || !out || n0 <= 0 || n1 < 0 || n2 < 0 || (n1 > 0 && !w1) || (n2 > 0 && !w2)) return fail(FAT5_EINVAL, "fold_weights: bad arguments");

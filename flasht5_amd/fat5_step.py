@@ -52,8 +52,8 @@ class FAT5Config:
     crossentropy_inplace_backward: bool = True
     fuse_lm_head_ce: bool = False          # lm_head + loss in row chunks: the (B*T, vocab) logits are never materialised
     fuse_add_norm: bool = False            # every residual add runs inside the next pre-norm (fused_add_rms_layernorm): same bits, fewer passes
-    fuse_norm_linear: bool = False         # pre-norm inside the projection GEMM, residual add as the output projection's epilogue
-                                           # (fused_linear.py / fat5_linear_fused): no stand-alone norm or add launch in the blocks
+    fuse_norm_linear: bool = False         # stacked projections (q | k | v, wi_0 | wi_1: one library GEMM each, packed gradients), the residual add in the
+                                           # output projection's GEMM epilogue, fused backward passes around them (fused_linear.py)
     fuse_gated_act: bool = True            # act(wi_0 x) * wi_1 x in one kernel forward, one backward (gated_act.py / fat5_gated_act_*)
     is_decoder: bool = False
 

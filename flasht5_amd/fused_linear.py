@@ -1,15 +1,21 @@
-"""Linear layers with the T5 pre-norm / the residual add fused in -- host side of `fat5_linear_fused`
-(csrc/linear_fused.h: a hand-written gfx950 MFMA GEMM whose prologue forms the RMSNorm row statistics from the A tiles on their
-way through LDS and whose epilogue applies them / adds the residual).
+"""Projections with the T5 pre-norm / the residual add attached.
 
     rmsnorm_linear(x, norm_weight, weight, eps)   == F.linear(fast_rms_layernorm(x, norm_weight, eps), weight)
         reference: `normed = self.layer_norm(hidden_states)` then Wq / Wk / Wv (src/model/modeling_flash_t5.py:304-318, :95-98);
-        likewise layer_norm -> wi_0 / wi_1 (:159-160).  The normalised activation is neither written in the forward nor kept for
-        the backward (autograd would keep it as the Linear's input): the backward rebuilds x * rstd from x and the saved rstd.
+        likewise layer_norm -> wi_0 / wi_1 (:159-160).  Up to three weights applied to the SAME normalised input run as ONE library GEMM
+        on their stack; the backward forms every weight gradient in one GEMM and the norm's input gradient, the residual path's gradient
+        and x * rstd in one pass (fat5_rmsnorm_unit_bwd).
     linear_residual(a, weight, residual)          == residual + F.linear(a, weight)
-        reference: `hidden_states + self.o(...)` / `hidden_states + self.wo(...)` (:316, :162-163), rounded twice like the two ops.
+        reference: `hidden_states + self.o(...)` / `hidden_states + self.wo(...)` (:316, :162-163): the add rides in the library GEMM's
+        epilogue (torch.addmm, beta = 1).
 
-Both differentiable in every tensor argument.  The backward GEMMs are library GEMMs (torch.matmul -> hipBLASLt)."""
+Round 6: the GEMMs are LIBRARY GEMMs (torch.matmul / addmm -> hipBLASLt).  Rounds 3-5 shipped a hand-written MFMA GEMM with the
+norm statistics in its prologue and the residual in its epilogue (`fat5_linear_fused`, csrc/linear_fused.h): parity-green, but 453-669 TF/s
+against hipBLASLt's 690-1020 on the FAT5-base shapes -- norm + QKV 32-34 us fused vs 25-26 us as norm kernel + library GEMM, wi_0 | wi_1
+39-40 vs 30 (BENCH_r03 .. r05 `n3_fusions`) -- so the kernel is gone; what this module keeps is what did pay in the config-5 step: the stacked
+projections (one GEMM for q | k | v and for wi_0 | wi_1, packed gradients) and the fused backward passes around the library GEMMs.
+
+Both differentiable in every tensor argument."""
 from typing import List, Optional, Tuple
 
 import torch
@@ -26,7 +32,7 @@ def _python_path(t):
 
 
 def fused_linear_supported(x, weight):
-    """shapes / dtypes the MFMA kernel takes (fat5_linear_fused): 16-bit, K a multiple of 64, N of 8"""
+    """shapes / dtypes the stacked path takes (fat5_fold_weights / fat5_rmsnorm_unit_bwd / fat5_fold_weights_bwd): 16-bit, K a multiple of 64, N of 8"""
     return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype and weight.dim() == 2 and
             x.shape[-1] == weight.shape[1] and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0)
 
@@ -36,39 +42,9 @@ def _rows(t):
     return t2 if (t2.stride(-1) == 1 and t2.data_ptr() % 16 == 0 and t2.stride(0) % 8 == 0) else t2.contiguous()
 
 
-# The four kernels below are registered as `fat5::` custom ops with fake (shape-only) implementations, like every other kernel of
+# The kernels below are registered as `fat5::` custom ops with fake (shape-only) implementations, like every other kernel of
 # the library (the reference registers each of its kernels with a fake, flash_attention_v2_bias.py:83-89, :219-226): the Python
 # autograd functions of this file trace under FakeTensor / torch.compile (tests/test_fused_linear_gpu.py::test_fused_block_traces).
-@torch.library.custom_op("fat5::linear_fused", mutates_args=(), device_types="cuda")
-def linear_fused_op(a: torch.Tensor, w: torch.Tensor, res: Optional[torch.Tensor], norm: bool, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """out = [rstd(a) *] a w^T [+ res]; (out, rstd) -- rstd (M,) fp32 when `norm`, else an empty tensor.  a (M, K), w (N, K) rows."""
-    a, w = _rows(a), _wrows(w)
-    res = _rows(res) if res is not None else None
-    M, K = a.shape
-    N = w.shape[0]
-    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    rstd = torch.empty((M if norm else 0,), dtype=torch.float32, device=a.device)
-    if M == 0:
-        return out, rstd
-    with _lib.on_device(a.device):
-        _lib.check(_lib.load().fat5_linear_fused(
-            a.data_ptr(), w.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
-            rstd.data_ptr() if norm else None, M, N, K, a.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
-            out.stride(0), int(bool(norm)), float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device)), "fat5_linear_fused")
-    return out, rstd
-
-
-@torch.library.register_fake("fat5::linear_fused")
-def _linear_fused_fake(a, w, res, norm, eps):
-    return (torch.empty((a.shape[0], w.shape[0]), dtype=a.dtype, device=a.device),
-            torch.empty((a.shape[0] if norm else 0,), dtype=torch.float32, device=a.device))
-
-
-def _launch(a, w, res, norm, eps, want_rstd):
-    out, rstd = linear_fused_op(a, w, res, bool(norm), float(eps))
-    return out, (rstd if want_rstd else None)
-
-
 def _wrows(w):
     return w if (w.stride(-1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 8 == 0) else w.contiguous()
 
@@ -157,23 +133,24 @@ class RMSNormLinear(torch.autograd.Function):
     """`weights`: one to three (n_i, K) projection weights applied to the SAME normalised input (Wq, Wk, Wv / wi_0, wi_1): the
     outputs come back concatenated along the last dim, the gradients per weight.
 
-    forward : fold (one launch: [W_i] diag g) + the MFMA kernel (rstd formed in-kernel)                      -- 2 launches
-    backward: gy = dout Wg (GEMM) | dx and xhat = x rstd in one pass (fat5_rmsnorm_unit_bwd) | dWg = dout^T xhat (GEMM) |
-              dW_i = dWg g, dg = sum_n dWg W in one launch (fat5_fold_weights_bwd)                           -- 4 launches
+    forward : stack (one launch: [W_i]) + the norm kernel (fat5_rmsnorm_fwd: y, rstd) + ONE library GEMM y [W_i]^T        -- 3 launches
+    backward: fold (one launch: [W_i] diag g) | gy = dout Wg (GEMM) | dx and xhat = x rstd in one pass (fat5_rmsnorm_unit_bwd) |
+              dWg = dout^T xhat (GEMM) | dW_i = dWg g, dg = sum_n dWg W in one launch (fat5_fold_weights_bwd)                  -- 5 launches
     (the separate ops: norm + 3 GEMMs forward; 6 GEMMs + 2 norm-backward kernels + 2 gradient accumulations backward)"""
 
     @staticmethod
     def forward(ctx, x, norm_weight, eps, with_residual, *weights):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        # the norm weight rides in the projection: (x rstd g) W^T = rstd (x (W diag g)^T)
-        wg = fold_weights(weights, norm_weight)
-        out, rstd = _launch(x2, wg, None, True, eps, True)
-        ctx.save_for_backward(x2, norm_weight, rstd, wg, *weights)  # (wg: a few MB per layer -- the normalised activation is what is NOT kept)
+        from .rms_norm import rmsnorm_fwd
+        y, rstd = rmsnorm_fwd(x2, norm_weight, eps)  # rounded to the activation dtype like the reference's layer_norm output
+        wc = weights[0] if len(weights) == 1 else fold_weights(weights, None)
+        out = y @ wc.t()
+        ctx.save_for_backward(x2, norm_weight, rstd, *weights)  # (the normalised activation is NOT kept: the backward rebuilds x * rstd from x and rstd)
         ctx.shape = shape
         ctx.with_residual = bool(with_residual)
         ctx.set_materialize_grads(False)  # (an unused output's gradient arrives as None, not as a zero-filled tensor)
-        out = out.reshape(*shape[:-1], wg.shape[0])
+        out = out.reshape(*shape[:-1], wc.shape[0])
         if with_residual:
             # x handed back as a second output: the sub-layer adds IT to its result (h + f(norm(h))), so the gradient of that
             # residual path arrives here and joins dx inside fat5_rmsnorm_unit_bwd instead of in an add kernel of autograd's
@@ -182,9 +159,10 @@ class RMSNormLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dres=None):
-        x2, g, rstd, wg, *weights = ctx.saved_tensors
+        x2, g, rstd, *weights = ctx.saved_tensors
         if dout is None:  # only the residual alias was used
             return (dres, None, None, None, *([None] * len(weights)))
+        wg = fold_weights(weights, g)  # [W_i] diag(g): dL/dxhat = dout Wg
         if dres is not None:
             dres = (dres if dres.dtype == x2.dtype else dres.to(x2.dtype)).reshape(-1, dres.shape[-1])
         d2 = dout.reshape(-1, dout.shape[-1])
@@ -207,7 +185,7 @@ class LinearResidual(torch.autograd.Function):
     def forward(ctx, a, weight, residual):
         shape = residual.shape
         a2, r2 = a.reshape(-1, a.shape[-1]), residual.reshape(-1, shape[-1])
-        out, _ = _launch(a2, weight, r2, False, 0.0, False)
+        out = torch.addmm(r2, a2, weight.t())  # (the residual add in the library GEMM's epilogue)
         ctx.save_for_backward(a2, weight)
         ctx.ashape = a.shape
         return out.reshape(shape)
@@ -222,10 +200,10 @@ class LinearResidual(torch.autograd.Function):
 
 
 def rmsnorm_linear(x, norm_weight, weight, eps=1e-6, return_residual=False):
-    """F.linear(fast_rms_layernorm(x, norm_weight, eps), weight) in one MFMA kernel; x (..., K), weight (N, K) -> (..., N).
+    """F.linear(fast_rms_layernorm(x, norm_weight, eps), weight); x (..., K), weight (N, K) -> (..., N).
     `weight` may be a tuple of up to three weights applied to the same normalised input (Wq, Wk, Wv / wi_0, wi_1): their outputs
-    come back concatenated along the last dim (one GEMM).  Shapes the kernel does not take (K % 64, N % 8, fp32) run the two
-    HIP / library ops one after the other.
+    come back concatenated along the last dim (one library GEMM on the stacked weight).  Shapes the stacked path does not take
+    (K % 64, N % 8, fp32) run the norm and one GEMM per weight.
     return_residual: also return `x` itself (an alias) -- the tensor the caller adds to the sub-layer's result, `h + f(norm(h))`: the
     gradient of that residual path then joins the norm's input gradient inside the backward kernel (no add kernel)."""
     if not x.is_cuda:
@@ -245,7 +223,7 @@ def rmsnorm_linear(x, norm_weight, weight, eps=1e-6, return_residual=False):
 
 
 def linear_residual(a, weight, residual):
-    """residual + F.linear(a, weight) with the add as the GEMM's epilogue (rounded twice, like the two separate ops)."""
+    """residual + F.linear(a, weight) with the add as the library GEMM's epilogue (torch.addmm)."""
     if not a.is_cuda:
         raise RuntimeError("flasht5_amd operators need tensors on the HIP device (no CPU fallback)")
     if not fused_linear_supported(a, weight) or residual.dtype != a.dtype or residual.shape[-1] != weight.shape[0]:

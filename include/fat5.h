@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 113 /* 0.1.3 (113: head_dim 16 native, FAT5_V_DBIAS_NOSPLIT; 112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+#define FAT5_VERSION 114 /* 0.1.4 (114: fat5_linear_fused removed, -inf-safe bias operands in the bodies that add the bias on the matrix pipe; 113: head_dim 16 native, FAT5_V_DBIAS_NOSPLIT; 112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
                             AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_*, fat5_adamw_scale_step_dev */
 
 enum fat5_status {
@@ -196,24 +196,16 @@ int fat5_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* 
                      size_t workspace_bytes, void* hip_stream);
 
 /*
- * Linear layer with the T5 pre-norm and / or the residual add fused in.  Replaces the op pairs
- * layer_norm -> Wq / Wk / Wv (src/model/modeling_flash_t5.py:304-318, :95-98) and hidden + wo(...) (:159-164, :316):
- *   out[m][n] = rowscale[m] * sum_k a[m][k] * w[n][k]  (+ res[m][n])
- * a: (M, K), w: (N, K) = an nn.Linear weight as stored, out / res: (M, N); dtype FAT5_F16 | FAT5_BF16 for all four; fp32
- * accumulation.  norm != 0: rowscale[m] = rsqrt(mean_k a[m][k]^2 + eps) formed inside the kernel (also written to rstd_out
- * (M,) fp32 when not NULL) -- pass w = W * diag(norm_weight) and the result is Linear(RMSNorm(a)) without the normalised
- * activation ever being written; norm == 0: rowscale = 1.  res != NULL: out = res + round(a w^T), rounded twice like the two
- * separate ops; res may alias out.  K must be a multiple of 64, N of 8; 16-byte aligned bases, strides multiples of 8 elements.
+ * Stacked projections of a T5 block: layer_norm -> Wq / Wk / Wv (src/model/modeling_flash_t5.py:304-318, :95-98) and
+ * layer_norm -> wi_0 / wi_1 (:159-160) as ONE library GEMM on the stacked weight.  (Versions <= 113 exported fat5_linear_fused, a hand-written
+ * MFMA GEMM with the norm in its prologue: slower than the library GEMM on every FAT5-base shape, removed in 114.)
  */
-int fat5_linear_fused(const void* a, const void* w, const void* res, void* out, float* rstd_out, int64_t M, int64_t N, int64_t K,
-                      int64_t a_row_stride, int64_t w_row_stride, int64_t res_row_stride, int64_t out_row_stride, int norm, float eps,
-                      int dtype, void* hip_stream);
-/* The folded projection weight for fat5_linear_fused(norm = 1), in one launch: out = [w0; w1; w2] (rows stacked: (n0 + n1 + n2, K),
+/* The stacked projection weight in one launch: out = [w0; w1; w2] (rows stacked: (n0 + n1 + n2, K),
  * contiguous) with every row multiplied elementwise by the norm weight g (K,) (g == NULL: the plain stack) -- e.g. Wq, Wk, Wv of a
  * T5 attention block and its layer_norm weight.  n1 / n2 may be 0.  All tensors share `dtype` (16-bit); products rounded once. */
 int fat5_fold_weights(const void* w0, const void* w1, const void* w2, int64_t n0, int64_t n1, int64_t n2, int64_t ld0, int64_t ld1,
                       int64_t ld2, const void* g, void* out, int64_t K, int dtype, void* hip_stream);
-/* Backward pieces of fat5_linear_fused(norm = 1) (the two gradient GEMMs are plain GEMMs):
+/* Backward pieces of Linear(RMSNorm(x; g), [w0; w1; w2]) around its two library GEMMs:
  *  - fat5_rmsnorm_unit_bwd: gy = dout (W diag g) = dL/dxhat, xhat = x * rstd ->  dx = (gy - xhat * mean_k(xhat * gy)) * rstd (the
  *    backward of rms_norm.py:113-124 with unit weight), and xhat itself -- the operand of the dout^T xhat GEMM -- in the same pass;
  *    x_dtype tensors, n <= 2048 (16-bit) / 1024 (fp32).  dres (optional, NULL = none): the gradient arriving at x along the

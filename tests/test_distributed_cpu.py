@@ -156,21 +156,51 @@ def test_bench_gpus_flag_spawns_the_ranks():
         assert out["allreduces"] == 2 and out["allreduces_per_step"] == 1.0
 
 
-def test_bench_allreduce_count_per_step_and_bucketed():
-    """north star: "a single RCCL all-reduce of the bias gradient" per backward.  bench.py's N > 1 loop (drive_steps) over gloo: the default
-    submits exactly one all-reduce per step; --bucket-allreduce --graph-steps 4 one per replay of four steps (and one per leftover step)."""
+def _bench_line(gpus, extra, steps=12):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["FAT5_BENCH_RENDEZVOUS_ONLY"] = "1"
-    for extra, want in (([], 10), (["--bucket-allreduce", "--graph-steps", "4"], 2 + 2)):
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1"] + extra,
-                           env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-        assert out["allreduces"] == want and out["allreduces_per_step"] == round(want / 10, 4), out
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", "1"] + extra,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+
+
+def test_bench_allreduce_count_per_step_and_bucketed():
+    """north star: "a single RCCL all-reduce of the bias gradient" per backward.  bench.py's N > 1 control flow over gloo (the stand-in replay runs the
+    collectives a captured graph would hold): the default keeps U steps per replay with ONE all-reduce per step inside it; --bucket-allreduce one per
+    replay; --graph-steps 1 one replay + one all-reduce per step from Python (drive_steps)."""
+    out = _bench_line(2, [])
+    assert out["allreduce"] == "in-graph" and out["steps_per_replay"] == 12 and out["allreduces"] == 12 and out["allreduces_per_step"] == 1.0, out
+    out = _bench_line(2, ["--graph-steps", "4"])
+    assert out["steps_per_replay"] == 4 and out["allreduces"] == 12 and out["steps_run"] == 12, out
+    out = _bench_line(2, ["--bucket-allreduce", "--graph-steps", "4"])
+    assert out["allreduce"] == "bucketed" and out["allreduces"] == 3 and out["allreduces_per_step"] == 0.25, out
+    out = _bench_line(2, ["--graph-steps", "1"])
+    assert out["allreduce"] == "per-step" and out["allreduces"] == 12 and out["allreduces_per_step"] == 1.0, out
+    out = _bench_line(2, [], steps=10)  # a step count with leftovers: 10 = one replay of 10 (the nearest divisor in 8..32)
+    assert out["steps_per_replay"] == 10 and out["allreduces"] == 10, out
+
+
+def test_bench_one_launch_method_for_every_n():
+    """the 1 -> N curve compares ONE method -- the N = 1 and N = 2 lines carry the same `launch` (U steps per replay) and the N = 2
+    line exactly one all-reduce per step inside that form"""
+    for extra in ([], ["--graph-steps", "4"], ["--no-graph"]):
+        one, two = _bench_line(1, extra), _bench_line(2, extra)
+        assert one["launch"] == two["launch"] and one["steps_per_replay"] == two["steps_per_replay"], (one, two)
+        assert one["allreduces"] == 0 and one["allreduce"] is None
+        assert two["allreduces_per_step"] == 1.0 and two["steps_run"] == 12
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_lp", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n in (1, 2, 4, 8):  # the driver's command line: --steps K --warmup W only
+        lp = bench.launch_plan(n, 16, False, False, 1000)
+        assert lp["launch"] == "hipGraph replay, 20 step(s) per replay" and lp["allreduce"] == (None if n == 1 else "in-graph")
 
 
 def _drive_worker(rank, world, port):

@@ -34,7 +34,7 @@ def test_exports_match_header(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fat5_version() == 113
+    assert lib.fat5_version() == 114
     assert lib.fat5_sizeof_attn_params() == ctypes.sizeof(_lib.AttnParams)
 
 
