@@ -45,7 +45,7 @@ class AttnParams(ctypes.Structure):
 
 
 EXPORTS = (
-    "fat5_version", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
+    "fat5_version", "fat5_chip_cus", "fat5_last_error", "fat5_sizeof_attn_params", "fat5_attn_fwd", "fat5_attn_bwd_workspace_bytes", "fat5_attn_bwd", "fat5_attn_bwd_launches",
     "fat5_attn_bwd_stages", "fat5_attn_describe", "fat5_rpe1d_from_table",
     "fat5_rmsnorm_fwd", "fat5_rmsnorm_bwd_workspace_bytes", "fat5_rmsnorm_bwd", "fat5_add_rmsnorm_fwd", "fat5_add_rmsnorm_bwd",
     "fat5_ce_fwd", "fat5_ce_bwd", "fat5_ce_fwd_bwd", "fat5_fold_weights", "fat5_fold_weights_bwd", "fat5_fold_weights_bwd_scratch_bytes", "fat5_rmsnorm_unit_bwd", "fat5_gated_act_fwd", "fat5_gated_act_bwd",
@@ -139,6 +139,7 @@ V_FWD64_MIX_ON, V_FWD64_MIX_OFF = 524288, 1048576
 V_FUSED64_ON, V_FUSED64_OFF = 65536, 131072
 V_DBIAS_NOSPLIT = 262144
 V_QDB64_ON, V_QDB64_OFF = 2097152, 4194304
+V_QDIAG_ON, V_QDIAG_OFF = 8388608, 16777216  # T5 bias, one-launch backward: the per-diagonal sums of the table gradient in the dQ workgroups always / never
 _variant = 0  # what the host mirror writes into every descriptor it builds; 0 = the library's own choice (production)
 
 

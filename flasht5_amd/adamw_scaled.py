@@ -83,6 +83,7 @@ class AdamWScale(Optimizer):
                 raise RuntimeError("AdamWScale: this optimizer already holds a captured step; destroy that graph and call "
                                    "release_captured_step() before capturing another one")
             self._graph_jobs, self._graph_keep = [], []
+            self._capture_generation = getattr(self, "_capture_generation", 0) + 1  # (ownership token of THIS capture: capture_token())
         jobs = []  # one per (group, device, dtype, kahan) bucket: descriptor table on the device, launched below
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -229,11 +230,21 @@ class AdamWScale(Optimizer):
                                        "and call release_captured_step() first")
                 self._graph_arena = {dev: [torch.empty(nb, dtype=torch.uint8, device=dev), 0] for dev, nb in need.items()}
 
-    def release_captured_step(self):
-        """Forget the captured step (the caller has destroyed every graph that holds it): its arena bytes may be handed out again."""
+    def capture_token(self):
+        """Ownership token of the captured step this optimizer currently holds (0: none).  Whoever captured keeps the token and hands it to
+        `release_captured_step(token)`: a holder whose capture was already released -- and replaced by a newer one -- then releases nothing
+        (an old GraphedTrainStep collected late must not clear the arena a live graph reads)."""
+        return getattr(self, "_capture_generation", 0) if getattr(self, "_graph_jobs", None) else 0
+
+    def release_captured_step(self, token=None):
+        """Forget the captured step (the caller has destroyed every graph that holds it): its arena bytes may be handed out again.
+        token (from `capture_token()` right after the capture): release only if the optimizer still holds THAT capture; None: unconditionally."""
+        if token is not None and token != self.capture_token():
+            return False
         self._graph_jobs, self._graph_keep = [], []
         for a in getattr(self, "_graph_arena", {}).values():
             a[1] = 0
+        return True
 
     def _upload(self, device, table):
         """descriptor table -> device, ASYNCHRONOUSLY: through one of eight rotating pinned staging buffers (a copy from pageable memory

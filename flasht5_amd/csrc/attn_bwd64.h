@@ -101,10 +101,13 @@ FAT5_DEV float asm_mul(float a, float b) {
 // 128-key units: attn_bwd_kv64_mixed_kernel)
 // ONE (DENSE only): 1 / scale is itself a 16-bit value (1: T5, 8: the default 1 / sqrt(64)) -- one selector term, 16 bias rows per MFMA: two bias MFMAs per key
 // block and step instead of four (the launcher checks the scale; +5 % on the kernel for the general two-term form)
-template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false, bool ONE = false>
+// NODIAG (round 6; the dK/dV half of a one-launch backward whose dQ half forms the table gradient's diagonal sums: attn_bwd_q64_body<..., QDG>): nothing of the
+// per-diagonal machinery below -- element operations, finish / hand-over, far-bin MFMAs, LDS arrays, partial rows -- is generated
+template <int D, bool BF16, int BIAS, bool HALF, bool SELF = false, bool ONE = false, bool NODIAG = false>
 FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, const int nblk, const int part_row, const bool part_zero_next) {
   static_assert(D == 64, "gap schedule written for D = 64");
   constexpr bool DENSE = BIAS == FAT5_BIAS_DENSE;
+  constexpr bool DG = BIAS == FAT5_BIAS_RPE1D && !NODIAG;  // this body forms the per-diagonal sums of the table gradient
   FAT5_STAMP(0);
   using Cfg = Bwd64Cfg<D, HALF, SELF, DENSE>;
   constexpr int BNK = Cfg::BNK, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
@@ -190,15 +193,17 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   bool diag_run = false;  // (wave-uniform) a run is open: dcar / dprev0 hold partial diagonals of the step at diag_mb
   int diag_mb = 0;
   // borrow masks of the pinned form (destination lane: position p' of its row of 16 took its value from p' + ql0 - 16 of the row above in key order)
-  float dmask[7];
+  float dmask[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (DG) {
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int ql0 = i < 3 ? i + 1 : i + 5;  // 1, 2, 3, 8, 9, 10, 11
-    dmask[i] = ((l & 15) + ql0 >= 16) ? 1.f : 0.f;
-    asm volatile("" : "+v"(dmask[i]));
+    for (int i = 0; i < 7; ++i) {
+      const int ql0 = i < 3 ? i + 1 : i + 5;  // 1, 2, 3, 8, 9, 10, 11
+      dmask[i] = ((l & 15) + ql0 >= 16) ? 1.f : 0.f;
+      asm volatile("" : "+v"(dmask[i]));
+    }
   }
   float far_neg = 0.f, far_pos = 0.f;
-  const bool want_drpe = (BIAS == FAT5_BIAS_RPE1D) && (a.drpe_part != nullptr);
+  const bool want_drpe = DG && (a.drpe_part != nullptr);
   float* const dsum = sD0 + (2 * w + hi) * n1 + a.R - 4 * hi + lq;  // (this lane's diagonal base + lane - 4 hi at dsum[base])
   float* const dtrash = sD0 + 2 * Cfg::NW * n1 + tid;
   // E: the finished sums of the diagonals base + (lane & 31) - 4 hi
@@ -360,7 +365,8 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + rg * Cfg::RING + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};
   if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 8)) {
     rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * n1, a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
-    for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
+    if constexpr (DG)
+      for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
   }
   wait_dma_all();
   __syncthreads();
@@ -602,13 +608,13 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         PB[kb][t2] = pack8<BF16>(p, t2);
         DS[kb][t2] = pack8<BF16>(s, t2);
       }
-      if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+      if constexpr (DG) {
         // the block's dS (fp32, masked elements zero) onto its diagonals; whole blocks beyond the band included
         diag_step_zero(gst[kb]);
         static_for<16>([&](auto ri) { diag_elem<decltype(ri)::value>(gst[kb], s[decltype(ri)::value], l & 15); });
       }
     }
-    if constexpr (BIAS == FAT5_BIAS_RPE1D) diag_step_end(gst, mb);
+    if constexpr (DG) diag_step_end(gst, mb);
   };
 
   // the stages of one iteration one after the other (band / masked steps)
@@ -658,7 +664,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     // BAND: the step's dS onto its diagonals (diag_sum.h), element e three gaps after its exponent argument: one rotating add for
     // everything, one rotating multiply-add by the borrow mask (both read Dv[e], written one gap earlier: no DPP hazard)
     [[maybe_unused]] DiagStep dst[2];
-    if constexpr (BAND) {
+    if constexpr (BAND && DG) {
       diag_step_zero(dst[0]);
       diag_step_zero(dst[1]);
     }
@@ -824,14 +830,14 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
         else if constexpr (g == 28) tadr0 = tab_addr(0, (mt0 + j + 1) * 32);  // the next step: rows 32 further down, window 32 entries lower
         else if constexpr (g == 29) TN0 = lds_rd128(tadr0);
       }
-      if constexpr (BAND && g >= 3 && !(FAT5_ABL & 1)) diag_el.template operator()<g - 3>();
+      if constexpr (BAND && DG && g >= 3 && !(FAT5_ABL & 1)) diag_el.template operator()<g - 3>();
       if constexpr (g == 31) {  // the tail of the step: its last elements finish inside this iteration (dependent ops back to back)
         Pv[31] = asm_exp2(X[31]);
         Dv[30] = asm_mul(Pv[30], DP[1][14]);
         pack_pair.template operator()<28>();
         Dv[31] = asm_mul(Pv[31], DP[1][15]);
         pack_pair.template operator()<30>();
-        if constexpr (BAND && !(FAT5_ABL & 1)) {
+        if constexpr (BAND && DG && !(FAT5_ABL & 1)) {
           diag_el.template operator()<29>();
           diag_el.template operator()<30>();
           asm volatile("s_nop 1" ::: "memory");  // (Dv[31] was written two instructions ago: DPP operands need two wait states)
@@ -842,7 +848,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       // far-bin sum of the step's dS: one 16x16x32 MFMA (16 cycles of the pipe, inside the gap's slack) per four packed words once they
       // are complete — 16 v_dot2c_f32_bf16 per step measured 9 % of this kernel. The last group's words come from the asm ops just
       // above (no hazard padding for asm producers: two wait states by hand)
-      if constexpr (BIAS == FAT5_BIAS_RPE1D && !BAND && !(FAT5_ABL & 32) && (g == 12 || g == 20 || g == 28 || g == 31)) {
+      if constexpr (DG && !BAND && !(FAT5_ABL & 32) && (g == 12 || g == 20 || g == 28 || g == 31)) {
         constexpr int grp = g == 31 ? 3 : (g - 12) >> 3;
         if constexpr (g == 31) asm volatile("s_nop 1" ::: "memory");
         // (asm, accumulating in place: a builtin may pick a fresh destination, and a C operand that is not the destination is still
@@ -864,7 +870,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
     }
     TRD = u32x4{tnd[0][0], tnd[0][1], tnd[1][0], tnd[1][1]};
     TRQ = u32x4{tnq[0][0], tnq[0][1], tnq[1][0], tnq[1][1]};
-    if constexpr (BAND && BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 2)) {
+    if constexpr (BAND && DG && !(FAT5_ABL & 2)) {
       const int mb = (mt0 + j) * 32;
       asm volatile("s_nop 1" : "+v"(dst[1].u1), "+v"(dst[1].b1));  // (asm producers: see above)
       diag_step_end(dst, mb);
@@ -925,10 +931,10 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
       // first and the last step of a trip decide for all four.  Steps that do not fill an aligned trip run the general iteration.
       while (j + 4 <= nsteps && (j & 3) == 0 && classify(j, side) && classify(j + 3, side3) && side3 == side) {
         const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
-        if constexpr (BIAS == FAT5_BIAS_RPE1D) diag_flush();
+        if constexpr (DG) diag_flush();
         static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(j + decltype(si)::value, cst); });
         j += 4;
-        if constexpr (BIAS == FAT5_BIAS_RPE1D) {
+        if constexpr (DG) {
           asm volatile("s_nop 15" : "+v"(facc4));  // (asm MFMA -> VALU read of its result: no padding is generated; tied to the tuple so that no read moves above it)
           const float fsum = ((facc4[0] + facc4[1]) + (facc4[2] + facc4[3])) * 0.0625f;
           facc4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -969,7 +975,7 @@ FAT5_DEV void attn_bwd_kv64_body(const AttnArgs& a, const int b, const int h, co
   // ---- partial per-diagonal sums of this key block.  Staged 256-key form: AFTER the dK / dV rows are on their way (the stores drain
   // while the partial rows are summed; the images and the diagonal arrays are different LDS areas) ----
   auto partial_rows = [&]() {
-    if constexpr (BIAS == FAT5_BIAS_RPE1D && !(FAT5_ABL & 16)) {
+    if constexpr (DG && !(FAT5_ABL & 16)) {
       if (want_drpe) {
         diag_flush();
         far_neg = wave_sum(far_neg);
@@ -1117,14 +1123,25 @@ struct BwdQ64Cfg {
   // lines per instruction: 13.5 k cycles of prologue measured (tools/trace64.py), a third of the kernel at 512 keys.
   static constexpr int STG_T = 64 * 2 * D;      // one tensor's 64 rows of one wave
   static constexpr int STG = NW * 3 * STG_T;
-  static size_t smem(int R, int bias_mode, bool stage = false) {
-    return RING + (stage ? STG : 0) + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0);
+  // qdg: the body also forms the table gradient's per-diagonal sums (QDG below): one private array of 2R+1 sums per (wave, half-wave) + one scratch word per thread
+  static size_t smem(int R, int bias_mode, bool stage = false, bool qdg = false) {
+    return RING + (stage ? STG : 0) + (bias_mode == FAT5_BIAS_RPE1D ? rpe_table_bytes(R) + 16 : 0) +
+           (qdg && bias_mode == FAT5_BIAS_RPE1D ? ((size_t)(2 * R + 1) * 4 * 2 * NW + NT * 4 + 63) / 64 * 64 : 0);
   }
 };
 
-template <int D, bool BF16, int BIAS>
+// QDG (round 6; T5 bias only): the per-diagonal sums of dS -- the gradient of the bias generator, drpe1d[h][d] = sum over (q, k) with k - q = d of dS[q][k] -- are
+// formed HERE instead of in the dK/dV body (attn_bwd_kv64_body<..., NODIAG>).  Why: in the one-launch backward of a short sequence (attn_bwd_fused64_kernel, cfg2:
+// 96 dK/dV + 96 dQ workgroups, all resident) the launch lasts as long as its LONGEST workgroup, and that is a dK/dV one -- 57.4 k cycles against 41.0 k for dQ
+//  -- of which the diagonal machinery is ~8 k; here it rides in the shorter workgroup.  The arithmetic is diag_sum.h's, MIRRORED: this body holds dS^T
+// (lane = query row, register r <-> key crow(r, hi)), the dK/dV body dS (lane = key, register <-> query row), so with d' = row - key = -d and
+// base' = (first row of the query block) - (first key of the step) an element lies on d' = base' + 16 a + p - 16 qh - ql0 - 4 hi -- the formula of diag_sum.h with the
+// roles of rows and keys exchanged.  A step moves 32 keys up: base' - 32, the same hand-over between consecutive steps; query block 1 of a step has the homes
+// query block 0 had one step earlier.  Sums leave at index R - d' of the wave's private arrays (d' >= R: the far-negative bin, d' <= -R: the far-positive one).
+template <int D, bool BF16, int BIAS, bool QDG = false>
 FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   static_assert(D == 64 && BIAS != FAT5_BIAS_DENSE, "gap schedule written for D = 64, bias none / rpe1d");
+  static_assert(!QDG || BIAS == FAT5_BIAS_RPE1D, "the diagonal sums belong to the T5 bias");
   FAT5_STAMP(0);
   using Cfg = BwdQ64Cfg<D>;
   constexpr int BM = Cfg::BM, NT = Cfg::NT, IMG = Cfg::IMG, SLOT = Cfg::SLOT;
@@ -1196,6 +1213,14 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         qf[qb][kk] = *reinterpret_cast<const u32x4*>(qb_ + (int64_t)qrow_c * a.qs[2] + 16 * kk + 8 * hi);
         dof[qb][kk] = *reinterpret_cast<const u32x4*>(dob_ + (int64_t)qrow_c * a.dos[2] + 16 * kk + 8 * hi);
         off_[qb][kk] = *reinterpret_cast<const u32x4*>(ob_ + (int64_t)qrow_c * a.os[2] + 16 * kk + 8 * hi);
+        if constexpr (QDG) {
+          // rows past M hold copies of row M - 1 here (the staged form gets zeros from the descriptor): with dO = O = 0 their dP', delta and so their dS are
+          // exact zeros -- the diagonal sums must not see them (their dQ is never stored either way)
+          if (qw0 + 32 * qb + lq >= M) {
+            dof[qb][kk] = u32x4{0u, 0u, 0u, 0u};
+            off_[qb][kk] = u32x4{0u, 0u, 0u, 0u};
+          }
+        }
       }
     }
   }
@@ -1247,6 +1272,55 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     for (int qb = 0; qb < 2; ++qb) sTa[qb] = sT + ((a.R - (qw0 + 32 * qb + lq)) & 3) * rpe_n1p(a.R);
   }
 
+  // ---- QDG: state of the per-diagonal sums (see the dK/dV body; everything mirrored: rows <-> keys) ----
+  [[maybe_unused]] const int n1 = 2 * a.R + 1;
+  [[maybe_unused]] float* const sD0 = sT - kRpePad + 4 * rpe_n1p(a.R);  // behind the four table copies: 2 NW private arrays of n1 sums, then one scratch word per thread
+  [[maybe_unused]] DiagCarry dcar[2];
+  diag_carry_zero(dcar[0]);
+  diag_carry_zero(dcar[1]);
+  [[maybe_unused]] float dprev0 = 0.f;
+  [[maybe_unused]] bool diag_run = false;  // (wave-uniform) a run is open: dcar / dprev0 hold partial diagonals of the step at diag_nb
+  [[maybe_unused]] int diag_nb = 0;
+  [[maybe_unused]] float dmask[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (QDG) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int ql0 = i < 3 ? i + 1 : i + 5;  // 1, 2, 3, 8, 9, 10, 11
+      dmask[i] = ((l & 15) + ql0 >= 16) ? 1.f : 0.f;
+      asm volatile("" : "+v"(dmask[i]));
+    }
+  }
+  [[maybe_unused]] float far_neg = 0.f, far_pos = 0.f;
+  [[maybe_unused]] const bool want_drpe = QDG && (a.drpe_part != nullptr);
+  [[maybe_unused]] float* const dsum = sD0 + (2 * w + hi) * n1 + a.R + 4 * hi - lq;  // (diagonal d' = base' + lane - 4 hi, i.e. d = -d', at dsum[-base'])
+  [[maybe_unused]] float* const dtrash = sD0 + 2 * Cfg::NW * n1 + tid;
+  // E: the finished sums of the diagonals d' = base + (lane & 31) - 4 hi
+  [[maybe_unused]] auto diag_store = [&](const float E, const int base) {
+    const int dm = base + lq - 4 * hi;
+    far_neg += dm >= a.R ? E : 0.f;    // d = -d' <= -R
+    far_pos += dm <= -a.R ? E : 0.f;   // d >= R
+    *((dm > -a.R && dm < a.R) ? dsum - base : dtrash) = E;
+  };
+  // end of the key step at nb: st[qb] = the step's accumulators of query block qb
+  [[maybe_unused]] auto diag_step_end = [&](const DiagStep (&st)[2], const int nb) {
+    const float F0 = diag_finish_halves(dcar[0], st[0], l), F1 = diag_finish_halves(dcar[1], st[1], l);
+    diag_store(F1 + dprev0, qw0 + 32 - nb);
+    dprev0 = F0;
+    diag_run = true;
+    diag_nb = nb;
+  };
+  [[maybe_unused]] auto diag_flush = [&]() {
+    if (diag_run) {
+      diag_store(dcar[1].cur + dprev0, qw0 - diag_nb);
+      diag_store(dcar[0].cur, qw0 - diag_nb - 32);
+      diag_carry_zero(dcar[0]);
+      diag_carry_zero(dcar[1]);
+      dprev0 = 0.f;
+      diag_run = false;
+    }
+  };
+  [[maybe_unused]] f32x4 facc4 = {0.f, 0.f, 0.f, 0.f};  // far-bin sums of the pipelined far steps on the matrix pipe (see the dK/dV body)
+
   f32x16 dq[2][DB];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -1287,6 +1361,8 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
   FAT5_STAMP(7);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
+  if constexpr (QDG)
+    for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
   FAT5_STAMP(8);
   wait_dma_all();
   __syncthreads();
@@ -1388,6 +1464,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   };
   // general softmax stage of the key step at nb: S, DP -> DSB
   auto softmax_generic = [&](const int nb) {
+    [[maybe_unused]] DiagStep gst[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16& s = S[qb];
@@ -1422,7 +1499,13 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) DSB[qb][t2] = pack8<BF16>(s, t2);
+      if constexpr (QDG) {
+        // the block's dS (fp32, masked elements zero; rows past M carry dO = 0, delta = 0 -> dS = 0) onto its diagonals; whole blocks beyond the band included
+        diag_step_zero(gst[qb]);
+        static_for<16>([&](auto ri) { diag_elem<decltype(ri)::value>(gst[qb], s[decltype(ri)::value], l & 15); });
+      }
     }
+    if constexpr (QDG) diag_step_end(gst, nb);
   };
   auto generic_iter = [&](const int t) {
     const uint32_t o_prev = (uint32_t)(((t + 3) & 3) * SLOT), o_cur = (uint32_t)((t & 3) * SLOT), o_next = (uint32_t)(((t + 1) & 3) * SLOT);
@@ -1463,6 +1546,18 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     u32x4 T[2][4];
     uint32_t tadr1 = 0u;
     if constexpr (BAND) T[0][0] = TN0;
+    // QDG, band steps: the step's dS onto its diagonals (diag_sum.h), element e one gap after its multiply: one rotating add for everything, one rotating
+    // multiply-add by the borrow mask (both read Dv[e], written a gap earlier: no DPP hazard)
+    [[maybe_unused]] DiagStep dst[2];
+    if constexpr (BAND && QDG) {
+      diag_step_zero(dst[0]);
+      diag_step_zero(dst[1]);
+    }
+    [[maybe_unused]] auto stE_ = [&]<int E>() {
+      constexpr int r = E & 15, ql0 = diag_ql0(r);
+      diag_elem_u<r>(dst[E >> 4], Dv[E]);
+      if constexpr (ql0 != 0) diag_elem_bm<r>(dst[E >> 4], Dv[E], dmask[ql0 < 8 ? ql0 - 1 : ql0 - 5]);
+    };
     auto stA_ = [&]<int E>() {
       if constexpr (BAND) {
         float tn_ = __uint_as_float(T[E >> 4][(E & 15) >> 2][E & 3]);
@@ -1544,6 +1639,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
         static_for<lo(g - 2) - lo(g - 3)>([&](auto ei) {  // stage D: pairs whose odd half was multiplied one gap ago
           constexpr int e = lo(g - 3) + decltype(ei)::value;
           if constexpr ((e & 1) == 1) stD_.template operator()<e - 1>();
+          if constexpr (BAND && QDG) stE_.template operator()<e>();  // (stage E: the element onto its diagonal)
         });
         static_for<lo(g - 1) - lo(g - 2)>([&](auto ei) { stC_.template operator()<lo(g - 2) + decltype(ei)::value>(); });
         static_for<lo(g) - lo(g - 1)>([&](auto ei) { stB_.template operator()<lo(g - 1) + decltype(ei)::value>(); });
@@ -1557,8 +1653,20 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
           });
         }
       }
+      // QDG, far steps: the sum of the step's rounded dS for its far bin on the matrix pipe -- one 16x16x32 MFMA (ones x four packed words: every row of the result
+      // = the column sums) per group of words once it is complete: group k = (query block k >> 1, half k & 1) is packed in gaps 8, 13, 18, 23
+      if constexpr (QDG && !BAND && (g == 9 || g == 14 || g == 19)) {
+        constexpr int grp = (g - 9) / 5;
+        if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(facc4) : "a"(ones4), "v"(DSn[grp >> 1][grp & 1]));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(facc4) : "a"(ones4), "v"(DSn[grp >> 1][grp & 1]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (QDG && !BAND) {
+      asm volatile("s_nop 1" ::: "memory");  // (the last group's words come from the asm ops just above: two wait states by hand)
+      if constexpr (BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(facc4) : "a"(ones4), "v"(DSn[1][1]));
+      else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(facc4) : "a"(ones4), "v"(DSn[1][1]));
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       S[qb] = Sn[qb];
@@ -1568,6 +1676,10 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db) TRK[db] = u32x4{tn[db][0][0], tn[db][0][1], tn[db][1][0], tn[db][1][1]};
+    if constexpr (BAND && QDG) {
+      asm volatile("s_nop 1" : "+v"(dst[1].u1), "+v"(dst[1].b1));  // (asm producers: no hazard padding is generated for them)
+      diag_step_end(dst, t * 32);
+    }
   };
 
   if (nt > 0) {
@@ -1603,8 +1715,15 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       while (t + 4 <= nt && (t & 3) == 0 && classify(t, side) && classify(t + 3, side3) && side3 == side) {
         const float cst = BIAS == FAT5_BIAS_RPE1D ? (side > 0 ? cst_pos : cst_neg) : 0.f;
         const float ad0 = cst + nL2[0], ad1 = cst + nL2[1];
+        if constexpr (QDG) diag_flush();
         static_for<4>([&](auto si) { fast_iter.template operator()<decltype(si)::value, false>(t + decltype(si)::value, ad0, ad1); });
         t += 4;
+        if constexpr (QDG) {
+          asm volatile("s_nop 15" : "+v"(facc4));  // (asm MFMA -> VALU read of its result: no padding is generated; tied to the tuple so that no read moves above it)
+          const float fsum = ((facc4[0] + facc4[1]) + (facc4[2] + facc4[3])) * 0.0625f;
+          facc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (side > 0) far_pos += fsum; else far_neg += fsum;
+        }
       }
       if constexpr (BIAS == FAT5_BIAS_RPE1D) {
         // trips that touch the band but see every key (band-mode iterations)
@@ -1674,38 +1793,62 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
     }
   }
+  if constexpr (QDG) {
+    // ---- partial per-diagonal sums of this row block (after the dQ rows are on their way: the stores drain while the partial row is summed; the images and
+    // the diagonal arrays are different LDS areas): row `mblk` of the a.part_stride partial rows of (b, h) ----
+    if (want_drpe) {
+      diag_flush();
+      far_neg = wave_sum(far_neg);
+      far_pos = wave_sum(far_pos);
+      if (l == 0) {
+        sD0[(2 * w) * n1] += far_neg;
+        sD0[(2 * w) * n1 + 2 * a.R] += far_pos;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: a __syncthreads here would also wait for the dQ stores)
+      __builtin_amdgcn_s_barrier();
+      float* out = a.drpe_part + ((int64_t)(b * a.H + h) * a.part_stride + mblk) * n1;
+      for (int i2 = tid; i2 < n1; i2 += NT) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 2 * Cfg::NW; ++ww) acc += sD0[ww * n1 + i2];
+        out[i2] = acc;
+      }
+    }
+  }
   FAT5_STAMP(6);
 }
 
-template <int D, bool BF16, int BIAS>
+template <int D, bool BF16, int BIAS, bool QDG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_q64_kernel(const AttnArgs a) {
-  attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x);
+  attn_bwd_q64_body<D, BF16, BIAS, QDG>(a, blockIdx.x);
 }
 
 // Both backward kernels in ONE launch for problems whose grids leave the chip's last round mostly empty (mid sequence lengths) or
 // do not fill it at all (cfg2: 96 + 96 workgroups): workgroups [0, n_kv_blocks) run the dK/dV body in its self-sufficient form,
 // the others the dQ body; one workgroup per CU either way (512 registers per lane), the longer ones first.
-template <int D, bool BF16, int BIAS>
+// QDG (round 6, T5 bias): the dQ workgroups form the table gradient's per-diagonal sums, the dK/dV ones none (see attn_bwd_q64_body): taken where every workgroup of
+// the launch is resident at once, i.e. where the launch lasts as long as its longest workgroup -- a dK/dV one
+template <int D, bool BF16, int BIAS, bool QDG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_fused64_kernel(const AttnArgs a) {
   if ((int)blockIdx.x < a.n_kv_blocks) {
     int b, h, nblk;
     decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
-    attn_bwd_kv64_body<D, BF16, BIAS, false, true>(a, b, h, nblk, nblk, false);
+    attn_bwd_kv64_body<D, BF16, BIAS, false, true, false, QDG>(a, b, h, nblk, nblk, false);
   } else {
-    attn_bwd_q64_body<D, BF16, BIAS>(a, blockIdx.x - a.n_kv_blocks);
+    attn_bwd_q64_body<D, BF16, BIAS, QDG>(a, blockIdx.x - a.n_kv_blocks);
   }
 }
 
-template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false>
+template <int D, bool BF16, int BIAS, bool HALF, bool ONE = false, bool NODIAG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void attn_bwd_kv64_kernel(const AttnArgs a) {
   int b, h, nblk;
   decode_unit(a, blockIdx.x, a.n_nblk, b, h, nblk, (FAT5_CAUSAL_ORDER && a.causal) ? 2 : 0);
   // (part_rows2: a 256-key launch over some units of a problem whose other units run half-length -- a unit range of a mixed launch)
   const bool two = !HALF && a.part_rows2;
-  attn_bwd_kv64_body<D, BF16, BIAS, HALF, false, ONE>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);
+  attn_bwd_kv64_body<D, BF16, BIAS, HALF, false, ONE, NODIAG>(a, b, h, nblk, two ? 2 * nblk : nblk, two && 2 * nblk + 1 < a.part_stride);
 }
 
 // Both variants in one launch.  One workgroup per CU (512 registers per lane): `w` 256-key workgroups take ceil(w / 256) rounds, the

@@ -402,6 +402,7 @@ struct AttnArgs {
   int32_t mix_full;         // attn_bwd_kv64_mixed_kernel: (b, h) pairs per XCD that run as 256-key workgroups
   int32_t part_stride;      // 64-key dK/dV bodies: partial diagonal-sum rows per (b, h) (= n_nblk unless 256-key and half-length workgroups share a problem)
   int32_t part_rows2;       // ... and a 256-key workgroup j owns rows 2j, 2j + 1 of them
+  int32_t diag_q;           // one-launch 64-wide backward, T5 bias: the dQ workgroups form the partial diagonal sums (part_stride = their row blocks per (b, h)), the dK/dV ones none
   int32_t unit_begin, unit_count;  // > 0: only units [unit_begin, +unit_count), u = h * B + b (include/fat5.h)
   int32_t batch_inner;      // dense bias shared by the batch: the B workgroups of one (head, tile) run side by side on one XCD
   uint32_t mg_mblk, mg_nblk, mg_H;   // 2^32 / d rounded up for d = n_mblk, n_nblk, H, or 0: the launchers fill them where the workgroup index is small enough for

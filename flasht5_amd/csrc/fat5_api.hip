@@ -7,6 +7,7 @@
 #include <cstring>
 #include <type_traits>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/fat5.h"
 #include "attn_common.h"
@@ -59,22 +60,31 @@ struct BwdLayout {
   int qdb_groups;   // ... ceil(B / 4); > 1: fp32 slabs in the workspace + dbias_partial_reduce_kernel
   int n_nblk;
   int nw_q, nw_kv;
+  bool diag_q;     // T5 bias, one-launch 64-wide backward: the dQ workgroups form the partial diagonal sums (one partial row per 256-row block), the dK/dV ones none
+  int part_rows;   // partial diagonal-sum rows per (b, h) in the workspace
 };
 
 // Compute units of the device the dispatch rules were measured on (MI355X: 256 in 8 XCDs) and of the device in use: the rules' workgroup-count
-// thresholds are rounds of the chip, so they scale with its size.  Read once per process from hipDeviceProp (no hard-coded 256 / 32);
+// thresholds are rounds of the chip, so they scale with its size.  Read once per device ordinal from hipDeviceProp (no hard-coded 256 / 32);
 // without a device -- the host-only dispatch tests -- the reference chip is assumed.
 static int chip_cus() {
-  static const int n = [] {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) {
-      (void)hipGetLastError();
-      return 256;
-    }
-    return pr.multiProcessorCount;
-  }();
-  return n;
+  // per device (a process may drive GPUs of different sizes): the current device's count, read once per ordinal
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  const int slot = dev >= 0 && dev < 64 ? dev : 0;
+  int n = cache[slot].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  cache[slot].store(pr.multiProcessorCount, std::memory_order_relaxed);
+  return pr.multiProcessorCount;
 }
 static inline long cu_scaled(long wgs_at_256) { return wgs_at_256 * chip_cus() / 256; }  // a workgroup-count threshold measured on 256 CUs
 
@@ -163,6 +173,7 @@ void dispatch_dtype(int dt, F&& f) {
 extern "C" {
 
 int fat5_version(void) { return FAT5_VERSION; }
+int fat5_chip_cus(void) { return chip_cus(); }
 const char* fat5_last_error(void) { return g_err; }
 size_t fat5_sizeof_attn_params(void) { return sizeof(fat5_attn_params); }
 
@@ -371,6 +382,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
                          p->unit_count == 0 && !p->cu_seqlens_q && p->N % 8 == 0 && ((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0) &&
                          (p->bias_stride[1] % 8 == 0) && (p->bias_stride[2] % 8 == 0) && (p->B > 1 || p->bias_stride[0] == 0) &&
                          (int64_t)p->M * p->N * (qdb_ngrp > 1 ? 4 : 2) < (int64_t(1) << 31) &&
+                         // (B > 4: one fp32 (H, M, N) slab per group of four batch elements in the workspace -- (16,12,8192) would be 12.9 GB where the batch-inner kernel it
+                         //  replaces needs one 3.2 GB buffer: beyond 4 GiB of slabs the older paths keep the call)
+                         (qdb_ngrp == 1 || (int64_t)qdb_ngrp * p->H * p->M * p->N * 4 <= (int64_t(4) << 30)) &&
                          ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
   // (measured, whole dense backward, both 64-wide bodies against both older ones, us -- profiles/r05_dfused_time2.log: (4,12,768) 60.5 vs 78.5, (8,12,512) 55.1 vs 72.8, (2,12,1024) 71.9 vs 83.5,
   //  (16,12,256) 39.6 vs 47.6; (8,12,256) 36.6 vs 28.9, (4,12,256) 29.8 vs 29.5 -> from 2^23 scores per call on; below that only inside the one-launch form, see dfused64)
@@ -414,7 +428,10 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
       }
       // (causal: workgroups of unequal length -- the finer units of a mixed launch balance better than the uniform model says:
       //  (4,12,4096) causal 218 vs 233 us, T5 bias 271 vs 285; (8,12,4096) 432 vs 445 / 526 vs 549)
-      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure || p->causal)) {
+      // (round 6, after causal launches went longest-first in round 5 -- profiles/r06_audit_s4096.log: the pure 256-key launch now wins on causal problems,
+      //  (8,12,3072) causal 236.0 vs 255.4 us mixed, T5 bias 260.4 vs 280.2; (8,12,4096) 395.6 vs 425.2 / 433.4 vs 460.2; (4,12,6144) 426.9 vs 446.0 / 463.5 vs 481.7:
+      //  the mixed launch deals pair-major -> a causal problem takes it only where the model asks for it, like every other)
+      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure)) {
         L.kv64_mix_pf = best_pf;
         mix_gain = best / makespan(per);
       }
@@ -507,6 +524,16 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     L.nw_kv = 4;
     L.n_nblk = (p->N + 255) / 256;
   }
+  // Round 6: where the whole one-launch backward is resident at once (one workgroup per CU: cfg2's 96 + 96 on 256 CUs) the launch lasts as long as its longest
+  // workgroup -- a dK/dV one, 57.4 k cycles against 41.0 k for dQ at cfg2 -- and ~8 k of those are the table gradient's per-diagonal sums: they move
+  // to the dQ workgroups (attn_bwd_q64_body<..., QDG>; the dK/dV body is compiled without them).  The choice is part of the LAYOUT: a call that runs the stages
+  // one by one launches the same two forms as separate kernels, so the partial rows always come from the same side.
+  {
+    const int qd_env = vsel(p->variant, FAT5_V_QDIAG_ON, FAT5_V_QDIAG_OFF);
+    const long wq = bh * ((p->M + 255) / 256);
+    L.diag_q = L.fused64 && p->bias_mode == FAT5_BIAS_RPE1D && (p->drpe1d || p->drpe_table) && qd_env != 0 &&
+               smem_bwd_fused64_d64(p->rpe_radius, p->bias_mode) <= 160 * 1024 && (qd_env == 1 || wg256 + wq <= chip_cus());
+  }
   // ... and both dense 64-wide bodies in ONE launch (attn_bwd_dfused64_kernel, round 5): the dense counterpart of fused64 -- the row statistics come from
   // bwd_stat2_kernel ahead of the launch instead of from the dK/dV half itself.  Separately the two launches of a short sequence leave most of the chip idle
   // twice ((4,12,512): 96 + 96 workgroups on 256 CUs) and those of a mid one each end in a half-empty round ((4,12,2048): 384 + 384).
@@ -590,8 +617,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     }
   }
   L.drpe_off = off;
+  L.part_rows = L.diag_q ? (p->M + 255) / 256 : L.n_nblk;
   if (p->bias_mode == FAT5_BIAS_RPE1D && (p->drpe1d || p->drpe_table))
-    off = align_up(off + (size_t)bh * L.n_nblk * (2 * p->rpe_radius + 1) * sizeof(float), 256);
+    off = align_up(off + (size_t)bh * L.part_rows * (2 * p->rpe_radius + 1) * sizeof(float), 256);
   L.total = off;
   return FAT5_OK;
 }
@@ -660,9 +688,10 @@ int fat5_attn_describe(const fat5_attn_params* p, char* out, size_t n) {
   char kv[48];
   if (L.kv64 && L.kv64_mix_pf > 0) snprintf(kv, sizeof kv, "64key-mixed:%d", L.kv64_mix_pf);
   else snprintf(kv, sizeof kv, "%s", L.kv64 ? (L.kv64_half ? "64key-half" : "64key") : "32key");
-  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
+  snprintf(out, n, "fwd=%s dq=%s dkdv=%s fused=%d dbias=%s qdiag=%d", fc.fwd64 ? (fc.mixed ? "64row-mixed" : (fc.ksplit ? "64row-ksplit" : "64row")) : (fc.nw == -4 ? "32row-split" : "32row"),
            L.qdb64 ? "64row-batch4" : (L.q64 ? "64row" : "32row"), kv, (fused || L.fused64 || L.dfused64) ? 1 : 0,
-           L.qdb64 ? (L.qdb_groups > 1 ? "dq-kernel+partials" : "dq-kernel") : (L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct")));
+           L.qdb64 ? (L.qdb_groups > 1 ? "dq-kernel+partials" : "dq-kernel") : (L.dbias_inkernel ? "inkernel" : (L.ds_staged ? "staged" : "direct")),
+           L.diag_q ? 1 : 0);  // (qdiag: T5 bias, the table gradient's per-diagonal sums come from the dQ workgroups)
   return FAT5_OK;
 }
 
@@ -758,6 +787,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   a.n_mblk = (p->M + 32 * L.nw_q - 1) / (32 * L.nw_q);
   a.n_nblk = L.n_nblk;
   a.n_kv_blocks = 0;
+  a.diag_q = L.diag_q ? 1 : 0;
+  a.part_stride = L.part_rows;
   const long grid_q = n_units(p) * a.n_mblk, grid_kv = n_units(p) * a.n_nblk;
   const long full_q = bh * a.n_mblk, full_kv = bh * a.n_nblk;  // (variant choice: see fat5_attn_fwd)
   // Short sequences: both grids together fit the chip at two workgroups per CU -> one launch, the two halves run
@@ -771,7 +802,6 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
   } else if (L.fused64 && (stages & FAT5_BWD_DQ) && (stages & FAT5_BWD_DKDV)) {
     // (a call for one stage only runs the same two bodies as separate launches, the row statistics through the workspace)
     a.n_kv_blocks = (int)grid_kv;
-    a.part_stride = a.n_nblk;
     a.stat2 = nullptr;
     hipError_t e = launch_bwd_fused64_d64(a, bf16, p->bias_mode, 4, (int)(grid_q + grid_kv), stream);
     if (e != hipSuccess) return hip_fail(e, "attn_bwd_fused64 launch");
@@ -801,7 +831,6 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
     if (stages & FAT5_BWD_DKDV) {
       launch_fn fn = effD(p) == 32 ? launch_bwd_kv_d32 : (p->D == 64 ? launch_bwd_kv_d64 : launch_bwd_kv_d128);
       if (L.kv64) fn = launch_bwd_kv64_d64;
-      a.part_stride = a.n_nblk;
       hipError_t e = hipSuccess;
       if (L.kv64 && L.kv64_mix_pf > 0 && p->unit_count == 0) {
         // (a.n_nblk counts 128-key rows; the 256-key workgroups cover two of them each)
@@ -870,8 +899,8 @@ int fat5_attn_bwd_stages(const fat5_attn_params* p, int stages, void* stream_) {
       if (ea != hipSuccess) return hip_fail(ea, "drpe_reduce attribute");
     }
     hipLaunchKernelGGL(drpe_reduce_kernel, dim3(p->H), dim3(1024), smem, stream, a.drpe_part, p->drpe1d, p->rpe_bucket,
-                       p->drpe_table, p->B, p->H, a.n_nblk, n1, p->rpe_num_buckets, p->unit_begin, p->unit_count, div_magic(n1, 4L * n1),
-                       div_magic(a.n_nblk, (long)p->B * a.n_nblk));
+                       p->drpe_table, p->B, p->H, L.part_rows, n1, p->rpe_num_buckets, p->unit_begin, p->unit_count, div_magic(n1, 4L * n1),
+                       div_magic(L.part_rows, (long)p->B * L.part_rows));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "drpe_reduce launch");
   }

@@ -385,6 +385,7 @@ class GraphedTrainStep:
             self.optimizer.release_captured_step()
             raise
         self.graphs = graphs
+        self._token = self.optimizer.capture_token()  # (close() releases THIS capture only: ADVICE r5)
         # what the capture baked in (see the class docstring)
         self._baked = [(tuple(g["betas"]), float(g["eps"])) for g in self.optimizer.param_groups]
         self._grads = [(p, p.grad) for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
@@ -393,7 +394,7 @@ class GraphedTrainStep:
         """Drop the captured step: the graphs go and the optimizer may capture again (another GraphedTrainStep, e.g. for a new batch shape)."""
         if self.graphs is not None:
             self.graphs = None
-            self.optimizer.release_captured_step()
+            self.optimizer.release_captured_step(getattr(self, "_token", None))
 
     def __del__(self):
         try:

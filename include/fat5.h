@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FAT5_VERSION 114 /* 0.1.4 (114: fat5_linear_fused removed, -inf-safe bias operands in the bodies that add the bias on the matrix pipe; 113: head_dim 16 native, FAT5_V_DBIAS_NOSPLIT; 112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
+#define FAT5_VERSION 114 /* 0.1.4 (114: FAT5_V_QDIAG_ON / _OFF, fat5_chip_cus, fat5_linear_fused removed, -inf-safe bias operands in the bodies that add the bias on the matrix pipe; 113: head_dim 16 native, FAT5_V_DBIAS_NOSPLIT; 112: FAT5_V_FUSED64_ON / _OFF); 0.1.1: per-call kernel-variant bits (no environment variables), fat5_rpe1d_from_table,
                             AdamWScale state dtype / flags; 111: fat5_fold_weights_bwd takes scratch, fat5_gated_act_*, fat5_adamw_scale_step_dev */
 
 enum fat5_status {
@@ -55,6 +55,7 @@ enum fat5_variant {
   FAT5_V_FWD64_MIX_ON = 524288, FAT5_V_FWD64_MIX_OFF = 1048576,  /* 64-row forward: 256-row and key-split 128-row workgroups in ONE launch wherever legal / never */
   FAT5_V_DBIAS_NOSPLIT = 262144,                                 /* batch-inner dbias kernel: the one-group form (one wave per SIMD) of rounds 2-3 */
   FAT5_V_QDB64_ON = 2097152, FAT5_V_QDB64_OFF = 4194304,        /* dense (1,H,M,N) bias, bf16, D = 64: dQ and the batch-reduced dbias in one kernel, four batch elements per workgroup (attn_bwd_qdb64.h) wherever legal / never */
+  FAT5_V_QDIAG_ON = 8388608, FAT5_V_QDIAG_OFF = 16777216,       /* T5 bias, one-launch 64-wide backward: the table gradient's per-diagonal sums formed by the dQ workgroups (attn_bwd_q64_body<QDG>) wherever that launch runs / never */
   FAT5_V_FUSED64_ON = 65536, FAT5_V_FUSED64_OFF = 131072         /* backward: the 64-wide dK/dV and dQ bodies in ONE launch (the dK/dV half forms its row statistics itself) wherever legal / never; dense (1,H,M,N) bias: the dense dK/dV body beside the dQ + dBias body in one launch behind a small row-statistics kernel */
 };
 
@@ -137,6 +138,9 @@ typedef struct fat5_attn_params {
 } fat5_attn_params;
 
 int fat5_version(void);
+/* compute units of the current device as the dispatch rules see them (their workgroup-count thresholds are rounds of the chip and scale with it);
+ * 256 -- the MI355X the rules were measured on -- when no device is present.  Host-only tests that pin dispatch choices check it. */
+int fat5_chip_cus(void);
 const char* fat5_last_error(void);
 /* sizeof(fat5_attn_params) as compiled into the library (bindings check their mirror against it). */
 size_t fat5_sizeof_attn_params(void);
@@ -147,9 +151,11 @@ int fat5_attn_fwd(const fat5_attn_params* p, void* hip_stream);
 size_t fat5_attn_bwd_workspace_bytes(const fat5_attn_params* p);
 /* backward: reads q,k,v,o,lse,dout(,bias|rpe1d); writes dq,dk,dv(,dbias|drpe1d). */
 int fat5_attn_bwd(const fat5_attn_params* p, void* hip_stream);
-/* number of main kernel launches fat5_attn_bwd uses for this problem: 1 = dQ and dK/dV halves side by side in one
+/* number of MAIN kernel launches fat5_attn_bwd uses for this problem: 1 = dQ and dK/dV halves side by side in one
  * launch (short sequences: both grids fit the chip together), 2 = dQ kernel then dK/dV kernel; 0 on invalid params.
- * (Profilers use it to name the dominant kernel; the reduction launch is not counted.) */
+ * Not counted: the reduction launch behind them (table gradient / staged dS / fp32 dbias slabs of B > 4) and, for the one-launch form of the
+ * dense (1,H,M,N) bias, the small row-statistics kernel ahead of it (bwd_stat2_kernel) -- `fat5_attn_describe` names the bodies, profilers use
+ * this number only to name the dominant kernel. */
 int fat5_attn_bwd_launches(const fat5_attn_params* p);
 /* Which kernel bodies this problem runs -- "fwd=64row-ksplit dq=32row dkdv=64key-mixed:4 fused=0 dbias=direct" -- written to `out`
  * (n bytes).  Host-only (no device, no pointer of `p` is followed): tests pin the dispatch rules with it. */

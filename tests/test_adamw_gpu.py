@@ -221,14 +221,22 @@ def test_captured_step_keeps_its_arena_and_refuses_a_second_capture():
     assert not torch.equal(before, p.detach())
     with pytest.raises(RuntimeError, match="already holds a captured step"):
         _capture_again(opt)
+    t1 = opt.capture_token()
+    assert t1 > 0
     opt.release_captured_step()
+    assert opt.capture_token() == 0
     g2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g2):
         opt.step()
+    # whoever held the FIRST capture (an old GraphedTrainStep collected late) must not release the second one's arena
+    t2 = opt.capture_token()
+    assert t2 > 0 and t2 != t1
+    assert opt.release_captured_step(t1) is False and opt.capture_token() == t2 and len(opt._graph_jobs) > 0
     opt.graph_advance()
     g2.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(p.detach().float()).all()
+    assert opt.release_captured_step(t2) is True and opt.capture_token() == 0
 
 
 def _capture_again(opt):

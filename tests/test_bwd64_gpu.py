@@ -303,8 +303,17 @@ def test_bwd64_fused_launch(B, H, M, N, causal, mode, md):
     for x, y in zip(a[1:3], b[1:3]):
         assert torch.isfinite(y.float()).all()
         assert maxdiff(x, y) <= 2.0 ** -7 * max(1e-6, float(x.float().abs().max()))
-    if mode == "rpe":
-        assert maxdiff(a[3], b[3]) <= 1e-3 * max(1.0, float(a[3].abs().max()))
     ref = oracle_all(q, k, v, bias, do, 0.125, causal)
     for key, got in zip(("dq", "dk", "dv"), b[:3]):
         assert maxdiff(got, ref[key]) <= gbound(ref[key], dtype), key
+    if mode == "rpe":
+        # Round 6: where the whole launch is resident at once the one-launch form has its dQ workgroups form the per-diagonal sums (tests/test_qdiag_gpu.py);
+        # both sides sum the same dS -- unrounded in band / general steps, rounded to the input dtype in far trips -- but which tiles are far trips follows the
+        # wave's 64 rows there and its 64 keys here: the two tables differ by the rounding noise of the far bins (inside twice the allowance of _table_truth),
+        # and each is checked against the oracle
+        want, allow = _table_truth(q, k, v, bias.float(), plan.o, ref["L"], do, 0.125, causal, table.cpu(), M, N, True, md)
+        for t in (a[3], b[3]):
+            err = (t.cpu() - want).abs()
+            assert bool((err <= allow + 2e-3 * max(1.0, want.abs().max().item()) + 1e-2).all()), (err.max().item(), allow.max().item())
+        diff = (a[3] - b[3]).abs().cpu()
+        assert bool((diff <= 2 * allow + 1e-3 * max(1.0, float(a[3].abs().max()))).all()), diff.max().item()

@@ -287,6 +287,8 @@ def test_dispatch_rules_are_pinned():
     (tools/dispatch_audit.py / tools/attn_time.py on MI355X): the test keeps a later threshold edit from silently
     moving a shape to a slower body."""
     from flasht5_amd import _lib as L
+    if L.load().fat5_chip_cus() != 256:  # (the thresholds are rounds of the chip: the pinned lines hold for the 256 CUs they were measured on -- ADVICE r5)
+        pytest.skip("dispatch rules are pinned for a 256-CU device (MI355X) or no device at all")
     rpe = dict(bias_mode=L.BIAS_RPE1D, radius=128, need_dbias=True)
     dense = dict(bias_mode=L.BIAS_DENSE, need_dbias=True)
     cases = [
