@@ -1320,6 +1320,12 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
     }
   };
   [[maybe_unused]] f32x4 facc4 = {0.f, 0.f, 0.f, 0.f};  // far-bin sums of the pipelined far steps on the matrix pipe (see the dK/dV body)
+  if constexpr (QDG) {
+    // the private arrays start at zero: 16-byte stores, issued here -- under the latency of the staging requests above -- and made visible by the prologue's
+    // barrier (the area lies behind the table copies: nothing else of the prologue touches it; the last store may run up to 12 bytes into the scratch words)
+    f32x4* z = reinterpret_cast<f32x4*>(sD0);
+    for (int i = tid; i < (n1 * 2 * Cfg::NW + 3) / 4; i += NT) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   f32x16 dq[2][DB];
 #pragma unroll
@@ -1361,8 +1367,6 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
   FAT5_STAMP(7);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
-  if constexpr (QDG)
-    for (int i = tid; i < n1 * 2 * Cfg::NW; i += NT) sD0[i] = 0.f;
   FAT5_STAMP(8);
   wait_dma_all();
   __syncthreads();

@@ -227,7 +227,69 @@ def rowwise_cases():
     return out
 
 
+# ---- the bodies of rounds 5 - 6, forced per call (per-tensor records, not only pass / fail) -----------------------------------
+def body_case(name, B, H, M, N, D, mode, bits, causal=False, scale=0.125, dt=torch.bfloat16, want=None, minus_inf=False):
+    """one problem through AttentionPlan with the variant bits `bits` against the fp32 oracle: o, lse, dq, dk, dv and the bias gradient (dense dbias / T5 table);
+    `want`: entries fat5_attn_describe must report (the body under test really ran)"""
+    from flasht5_amd.flash_attention_v2_bias import AttentionPlan
+    from flasht5_amd import positional_encoding as pe
+    q, k, v, _, do = make_inputs(B, H, M, N, D, dt, None, seed=B + M + 3 * N + D, strided=True)
+    table = _table(H, 3)
+    kw = {}
+    if mode == "dense":
+        g = torch.Generator().manual_seed(7)
+        bias = (torch.randn(1, H, M, N, generator=g) * 0.7).to(dt).cuda()
+        if minus_inf:  # an additive mask written as -inf: a band of keys for every row + scattered entries (every row keeps visible keys)
+            bias[..., N - 72:N - 8] = float("-inf")
+            bias = bias.masked_fill((torch.rand(1, H, M, N, generator=g) < 0.03).cuda() & (torch.arange(N).cuda() >= 32), float("-inf"))
+        kw = dict(bias=bias)
+        ref_bias = bias
+    elif mode == "rpe":
+        ref_bias = oracle.compute_bias(table, M, N, True, 32, 128).contiguous().cuda()
+        kw = dict(rpe1d=pe.rpe1d_from_table(table.cuda(), True, 32, 128), radius=128, rpe_bucket=pe.bucket_index32(128, True, 32, 128, "cuda"), num_buckets=32)
+    else:
+        ref_bias = None
+    plan = AttentionPlan(q, k, v, do, causal=causal, sm_scale=scale, variant=bits, **kw)
+    d = plan.describe()
+    for key, val in (want or {}).items():
+        assert d[key] == val, (name, key, d)
+    o = plan.forward().clone()
+    dq, dk, dv, db = plan.backward()
+    torch.cuda.synchronize()
+    ref = oracle_all(q, k, v, ref_bias, do, scale, causal)
+    out = [rec(name, "o", maxdiff(o, ref["o"]), bound(ref["o"], dt, ulps=2.0 if minus_inf else 1.0)), rec(name, "lse", maxdiff(plan.lse, ref["L"]), 10 * lse_bound(ref["L"]))]
+    out += [rec(name, key, maxdiff(g_, ref[key]), gbound(ref[key], dt)) for key, g_ in (("dq", dq), ("dk", dk), ("dv", dv))]
+    if mode == "dense":
+        out.append(rec(name, f"dbias(1,{H},{M},{N})", maxdiff(db, ref["db"]), gbound(ref["db"], dt) * (1 + B)))
+    elif mode == "rpe":
+        _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, ref_bias, o, ref["L"], do, scale, causal)
+        want_t = _table_grad_truth(table, M, N, db_alg)
+        out.append(rec(name, f"dtable(32,{H})", maxdiff(db.cpu(), want_t), 5e-3 * max(1.0, want_t.abs().max().item()) + 2e-2))
+    return out
+
+
+def round56_cases():
+    from flasht5_amd import _lib as L
+    two = L.V_QDB64_ON | L.V_KV64_ON | L.V_FUSED64_OFF
+    one = L.V_QDB64_ON | L.V_KV64_ON | L.V_FUSED64_ON
+    out = []
+    out += body_case("r5 dense: dQ + dBias kernel | dense 64-key dK/dV, two launches (4,12,1024,64)", 4, 12, 1024, 1024, 64, "dense", two, want={"dq": "64row-batch4", "dkdv": "64key", "fused": "0"})
+    out += body_case("r5 dense: both in ONE launch (4,12,512,64)", 4, 12, 512, 512, 64, "dense", one, want={"dq": "64row-batch4", "fused": "1"})
+    out += body_case("r5 dense: B = 6, fp32 slabs + partial reduction (6,4,512,64)", 6, 4, 512, 512, 64, "dense", two, want={"dbias": "dq-kernel+partials"})
+    out += body_case("r5 dense: reference benchmark's form, B = 16 causal sm_scale 1.3 (16,4,512,64)", 16, 4, 512, 512, 64, "dense", one, causal=True, scale=1.3, want={"dq": "64row-batch4"})
+    out += body_case("r5 dense: fp16 (4,4,512,64) 64-key dK/dV", 4, 4, 512, 512, 64, "dense", L.V_KV64_ON, dt=torch.float16, want={"dkdv": "64key"})
+    out += body_case("r6 dense with -inf mask entries, two launches (4,4,512,64)", 4, 4, 512, 512, 64, "dense", two, minus_inf=True, want={"dq": "64row-batch4", "dkdv": "64key"})
+    out += body_case("r6 dense with -inf mask entries, one launch, sm_scale 1.3 (4,4,512,64)", 4, 4, 512, 512, 64, "dense", one, scale=1.3, minus_inf=True, want={"fused": "1"})
+    out += body_case("r5 head_dim 128 pipelined forward, T5 table (2,4,1024,128)", 2, 4, 1024, 1024, 128, "rpe", L.V_FWD64_ON, scale=128 ** -0.5, want={"fwd": "64row"})
+    out += body_case("r5 head_dim 128 pipelined forward, dense bias (2,4,1024,128)", 2, 4, 1024, 1024, 128, "dense", L.V_FWD64_ON, scale=128 ** -0.5, want={"fwd": "64row"})
+    out += body_case("r5 head_dim 128 pipelined forward, causal none, sm_scale 1.3 (2,4,1024,128)", 2, 4, 1024, 1024, 128, "none", L.V_FWD64_ON, causal=True, scale=1.3, want={"fwd": "64row"})
+    out += body_case("r6 table gradient from the dQ workgroups (cfg2's form) (4,12,512,64)", 4, 12, 512, 512, 64, "rpe", L.V_FUSED64_ON | L.V_QDIAG_ON, want={"fused": "1", "qdiag": "1"})
+    out += body_case("r6 ... causal, ragged (2,4,1000,1100,64)", 2, 4, 1000, 1100, 64, "rpe", L.V_FUSED64_ON | L.V_QDIAG_ON, causal=True, want={"qdiag": "1"})
+    out += body_case("r4 table gradient from the dK/dV workgroups (4,12,512,64)", 4, 12, 512, 512, 64, "rpe", L.V_FUSED64_ON | L.V_QDIAG_OFF, want={"fused": "1", "qdiag": "0"})
+    return out
+
+
 ALL_CASES = ([("fixture:" + n, (lambda n=n: fixture_case(n))) for n in ATTN_CASES] +
              [("triton:" + n, (lambda n=n: triton_case(n))) for n in TRITON_CASES] +
              [("cfg1", cfg1_case), ("cfg2:rpe", lambda: cfg2_case("rpe")), ("cfg2:dense", lambda: cfg2_case("dense")),
-              ("cfg3", cfg3_case), ("cfg4", cfg4_case), ("rowwise", rowwise_cases)])
+              ("cfg3", cfg3_case), ("cfg4", cfg4_case), ("rowwise", rowwise_cases), ("rounds5-6", round56_cases)])

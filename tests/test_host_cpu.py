@@ -293,8 +293,11 @@ def test_dispatch_rules_are_pinned():
     dense = dict(bias_mode=L.BIAS_DENSE, need_dbias=True)
     cases = [
         # the three headline shapes (T5 bias): one launch of both 64-wide backward bodies at S = 512 (round 4); the same up to 1152 workgroups (S = 3072); mixed dK/dV launch above; 64-wide everywhere at 8192
-        (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
-        (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1")),
+        # (round 6: where the one launch is resident at once -- 96 + 96 workgroups on 256 CUs -- the dQ workgroups form the table gradient's diagonal sums: 24.1 vs 27.3 us)
+        (dict(B=4, H=12, M=512, N=512, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1", qdiag="1")),
+        (dict(B=2, H=12, M=512, N=512, **rpe), dict(fused="1", qdiag="1")),                                   # (25.9 vs 29.4 us)
+        (dict(B=8, H=12, M=512, N=512, **rpe), dict(fused="1", qdiag="0")),                                   # (384 workgroups, two rounds: 48.9 either way -> the dK/dV side keeps them)
+        (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1", qdiag="0")),       # (68.2 vs 68.9 us forced)
         (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
@@ -318,9 +321,9 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="64row", dkdv="64key")),            # T5 bias: band steps pipelined since round 4
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
-        (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key-mixed:20")),         # (round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
+        (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key")),         # (round 6: pure 256-key launch since causal launches go longest-first -- profiles/r06_audit_s4096.log; round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
         (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),   # (1536 workgroups: one launch 369.3 vs 387.8 us with the longest-first order, profiles/r05d_dispatch_audit_causal_bwd.log)
-        (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key-mixed:5")),
+        (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
         (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row-ksplit")),             # (round-4 audit: 51.1 vs 55.1 us -- the split form's Q / O travel as whole rows now)
