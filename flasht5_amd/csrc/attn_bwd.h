@@ -860,8 +860,14 @@ FAT5_DEV void attn_bwd_kv_body(const AttnArgs& a, const int bid) {
 #ifndef FAT5_BWDQ_MINW
 #define FAT5_BWDQ_MINW 2  // (3 fits at D <= 64 with a few spills but measured no faster: 82.7 vs 83.3 us at S=2048)
 #endif
+// head_dim 128 (round 6, profiles/r06_d128_dq_minw.log): the dense-bias instantiation needs ~100 bytes of scratch per lane at two waves per SIMD (bias tile reader, dS
+// staging) -- one wave per SIMD with the whole register file is faster there ((16,12,1024,128) causal dense: dQ stage 275 -> 222 us, backward 582 -> 526); the T5-table
+// and no-bias instantiations fit two waves with 0 / 32 bytes of scratch and lose at one ((4,12,1024,128) T5 table: 55 -> 71 us)
+#ifndef FAT5_BWDQ128_MINW
+#define FAT5_BWDQ128_MINW(BIAS) ((BIAS) == FAT5_BIAS_DENSE ? 1 : 2)
+#endif
 template <int D, bool BF16, int BIAS, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_BWDQ_MINW : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(D <= 64 ? FAT5_BWDQ_MINW : FAT5_BWDQ128_MINW(BIAS))))
 void attn_bwd_q_kernel(const AttnArgs a) {
   attn_bwd_q_body<D, BF16, BIAS, NW>(a, blockIdx.x);
 }

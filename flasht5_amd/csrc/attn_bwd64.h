@@ -1365,6 +1365,8 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
   for (int i = 0; i < 3; ++i)
     if (i < nt) dma_step(i, (uint32_t)(i * SLOT));
   for (int i = tid; i < SLOT / 16; i += NT) reinterpret_cast<u32x4*>(smem + 3 * SLOT)[i] = u32x4{0u, 0u, 0u, 0u};  // (see the dK/dV body)
+  // (round 6, measured and dropped -- profiles/r06_prologue_ab.log: the ring requests right behind the staging requests, the fragment reads + delta behind a counted
+  //  wait for the private staging images only, the lse loads youngest: cfg2 backward 27.9 vs 27.0 us on the same box, (2,12,1024) 38.5 vs 37.6 -- the order below stays)
   FAT5_STAMP(7);
   if constexpr (BIAS == FAT5_BIAS_RPE1D) rpe_table_fill_rest(sT - kRpePad, a.rpe1d + (int64_t)h * (2 * a.R + 1), a.R, tid, NT, tabr, ctab ? P : 0x7fffffff);
   FAT5_STAMP(8);
@@ -1797,6 +1799,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
     }
   }
+  FAT5_STAMP(12);
   if constexpr (QDG) {
     // ---- partial per-diagonal sums of this row block (after the dQ rows are on their way: the stores drain while the partial row is summed; the images and
     // the diagonal arrays are different LDS areas): row `mblk` of the a.part_stride partial rows of (b, h) ----
@@ -1810,6 +1813,7 @@ FAT5_DEV void attn_bwd_q64_body(const AttnArgs& a, const int bid) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: a __syncthreads here would also wait for the dQ stores)
       __builtin_amdgcn_s_barrier();
+      FAT5_STAMP(13);
       float* out = a.drpe_part + ((int64_t)(b * a.H + h) * a.part_stride + mblk) * n1;
       for (int i2 = tid; i2 < n1; i2 += NT) {
         float acc = 0.f;

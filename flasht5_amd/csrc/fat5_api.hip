@@ -277,8 +277,11 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     // 82 vs 91, (4,12,4096) 137-140 vs 147-149, (8,12,4096) 245 vs 250, equal from ~8000 waves on (tools/dispatch_audit.py).
     // (only where the mask actually shortens workgroups: with N >= 2 M every row sees most keys -- (16,12,1024x4096) causal 181 vs 196 us plain)
     // (round-4 audit: also between 512 and 1024 waves -- (4,12,1024) T5 bias 20.7 vs 22.6 us, none 19.4 vs 19.9; (8,12,512) 14.3 vs 16.1, 12.9 vs 13.5)
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && (waves64 < cu_scaled(2048) ||
-                                                        (p->causal && waves64 <= cu_scaled(8192) && p->N < 2 * p->M)));
+    // (round-6 audit, profiles/r06_dispatch_audit_H12.log: since round 5 -- causal launches longest-first, masked blocks inside the pipelined sweep -- the 256-row form
+    //  wins on causal problems from 3072 waves on: (8,12,2048) causal 66.3 split vs 64.7 us, T5 bias 66.7 vs 64.3; (4,12,4096) 114.2 vs 110.8 / 116.6 vs 108.4;
+    //  (16,12,2048) 136.6 vs 124.4 / 136.0 vs 122.8; (8,12,4096) 230.4 vs 207.7 / 226.6 vs 204.0; (4,12,8192) 406.5 vs 373.4; (16,12,1024) T5 bias 45.8 vs 43.2 --
+    //  the causal extension to 8192 waves of rounds 3-4 is gone; below 2048 waves the split form stays for every mask)
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && waves64 < cu_scaled(2048));
     // (round-4 audit: without bias as well -- (16,12,1024) causal 51.1 split vs 55.1 us, (16,12,2048) 138.7 vs 151.5: the split form's Q / O now travel as whole rows)
     // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
@@ -506,14 +509,19 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     // (round-4 audit: (2,12,2048) causal 80.9 vs 92.9 us -- the 384-workgroup exception holds at <= 1024 keys only; (8,12,2048) causal, 1536 workgroups: 269.8 vs 283.4)
     // (profiles/r05d_dispatch_audit_causal_bwd.log, longest-first order: causal (4,12,4096), 1536 workgroups, one launch 369.3 vs 387.8 us, T5 bias 382.6 vs 414.4;
     //  (2,32,4096), 2048 workgroups, T5 bias 506.1 vs 534.4, none 486.3 vs 493.5 -> causal problems up to 2048 workgroups)
-    const long max_wg = (ctab && p->N <= 2048) ? cu_scaled(1536) : ((p->causal && (ctab || p->bias_mode == FAT5_BIAS_NONE)) ? cu_scaled(2048) : FUSED64_MAX_WG);
+    // (round-6 audit, profiles/r06_dispatch_audit_H12.log -- after causal problems left the mixed dK/dV launch the separate launches caught up at 1536 workgroups:
+    //  (4,12,4096) causal 368.1 one launch vs 349.8 us, T5 bias 378.8 vs 377.2; (8,12,2048) 214.7 vs 206.1, T5 bias 226.8 vs 216.0; 768 workgroups stay:
+    //  (4,12,2048) 115.4 / 119.1 one launch, (8,12,1024) 79.2 / 77.7 -> causal problems up to 1280 workgroups)
+    const long max_wg = (p->causal && (ctab || p->bias_mode == FAT5_BIAS_NONE)) ? cu_scaled(1280) : FUSED64_MAX_WG;
     // (round 5, no bias: the dK/dV half's diagonal steps are pipelined (mask in the C operand) -- (16,12,512) causal 65.7 vs 72.1 us, (4,12,512) 21.7 vs 22.6;
     //  (4,12,1024) 45.9 either way -> up to 512 keys)
     // (closing audit of round 5, after causal launches went longest-first -- profiles/r05c_dispatch_audit_H12.log: T5 bias (4,12,1024), 384 workgroups, 44.6 one launch vs
     //  49.6 -> the 256 .. 512-workgroup exception holds below 1024 keys only; no bias (2,12,2048) 63.5 vs 70.3, (4,12,2048) 117.4 vs 127.7, (2,12,4096) 195.8 vs 198.7
     //  -> from 2048 keys on as well; (4,12,1024) 40.6 separate stays)
     const bool causal_ok = !p->causal || (ctab && squarish && (tot <= chip_cus() || tot >= cu_scaled(512) || p->N >= 1024)) ||
-                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (p->N <= 512 || tot <= chip_cus() || p->N >= 2048));  // ((3,5,2048) causal, 240 workgroups: 56.5 vs 70.9 us -- profiles/r05_dispatch_audit_H8_16_32.log)
+                           // ((3,5,2048) causal, 240 workgroups: 56.5 vs 70.9 us -- profiles/r05_dispatch_audit_H8_16_32.log; round-6 audit: (8,12,512) causal, 384 workgroups
+                           //  -- one and a half rounds of unequal workgroups -- 36.9 one launch vs 28.5 us: at <= 512 keys one round or from two rounds on, as with the T5 bias)
+                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (tot <= chip_cus() || (p->N <= 512 && tot >= cu_scaled(512)) || p->N >= 2048));
     const bool rule = causal_ok && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }

@@ -300,7 +300,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=1024, N=1024, **rpe), dict(dq="64row", dkdv="64key", fused="1", qdiag="0")),       # (68.2 vs 68.9 us forced)
         (dict(B=2, H=12, M=2048, N=2048), dict(dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=12, M=512, N=512, causal=True, **rpe), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),
-        (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row-ksplit")),                 # (forward: diagonal tiles are band tiles, the split form wins again)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
+        (dict(B=16, H=12, M=1024, N=1024, causal=True, **rpe), dict(fwd="64row")),                        # (forward, round-6 audit: 3072 waves -- the 256-row form, 43.2 vs 45.8 us split; rounds 4-5: the split form)   # causal + T5 bias: the table carries the mask, the 64-wide one-launch form (round 4)
         (dict(B=4, H=12, M=1024, N=1024, causal=True, **rpe), dict(dq="64row", dkdv="64key", fused="1")),  # (384 workgroups: an exception until causal launches went longest-first -- 44.6 vs 49.6 us, profiles/r05c_dispatch_audit_H12.log)
         (dict(B=2, H=12, M=1024, N=1024, causal=True), dict(fwd="32row-split")),                           # forward, causal, 384 waves of 64 rows at 1024 keys: the 32-row body (12.5 vs 15.5 us)
         (dict(B=4, H=12, M=1024, N=1024, causal=True), dict(fwd="64row-ksplit")),                          # ... 768 waves: the pipelined body
@@ -322,11 +322,14 @@ def test_dispatch_rules_are_pinned():
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="32key")),
         (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key")),         # (round 6: pure 256-key launch since causal launches go longest-first -- profiles/r06_audit_s4096.log; round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
-        (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),   # (1536 workgroups: one launch 369.3 vs 387.8 us with the longest-first order, profiles/r05d_dispatch_audit_causal_bwd.log)
+        (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row", dq="32row", dkdv="64key", fused="0")),   # (round-6 audit: 1536 workgroups, separate launches 349.8 vs 368.1 us; forward 110.8 vs 114.2 split)   # (1536 workgroups: one launch 369.3 vs 387.8 us with the longest-first order, profiles/r05d_dispatch_audit_causal_bwd.log)
         (dict(B=4, H=12, M=8192, N=8192, causal=True), dict(dq="32row", dkdv="64key")),
         (dict(B=4, H=12, M=512, N=512, causal=True), dict(fwd="32row-split")),
-        (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),
-        (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row-ksplit")),             # (round-4 audit: 51.1 vs 55.1 us -- the split form's Q / O travel as whole rows now)
+        (dict(B=8, H=12, M=2048, N=2048, causal=True), dict(fwd="64row", fused="0")),                   # (round-6 audit: 3072 waves, 64.7 vs 66.3 us split; backward 1536 workgroups: 206.1 separate vs 214.7)
+        (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(fwd="64row")),                    # (round-6 audit: 43.9-44.9 us either way -- one rule for causal and full: split below 2048 waves)
+        (dict(B=4, H=12, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit")),                  # ... 1536 waves
+        (dict(B=8, H=12, M=512, N=512, causal=True), dict(dq="32row", dkdv="32key", fused="1")),   # plain causal, 384 workgroups of the 64-wide form = one and a half rounds: the 32-wide one-launch form (28.5 vs 36.9 us, round-6 audit)
+        (dict(B=16, H=12, M=512, N=512, causal=True), dict(dq="64row", dkdv="64key", fused="1")),  # ... three rounds: 65.7 vs 72.1 (round 5)
         (dict(B=16, H=12, M=1024, N=4096, causal=True), dict(fwd="64row")),                    # N >= 2M: the mask shortens nothing
         # large batch, short keys: the uneven 1.5-waves-per-SIMD range keeps the 32-row forward; whole rounds do not
         (dict(B=16, H=12, M=512, N=512), dict(fwd="64row-ksplit")),                            # (round-4 audit: the 1.5-waves-per-SIMD exception at <= 512 keys is gone)
@@ -356,7 +359,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=8, M=512, N=512, **rpe), dict(fwd="32row-split", dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=16, M=2048, N=2048, **rpe), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),
         (dict(B=3, H=5, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),         # an under-filled chip (240 workgroups), causal without bias: the one-launch form (56.5 vs 70.9 us)
-        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit", dq="64row", dkdv="64key", fused="1")),   # (1024 workgroups, plain causal from 2048 keys: the one-launch form since the closing audit of round 5)
+        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),   # (1024 workgroups, plain causal from 2048 keys: the one-launch form since the closing audit of round 5)
         (dict(B=2, H=8, M=128, N=128), dict(fwd="32row", fused="1")),                                     # config 1's shape
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="64row", dq="32row", dkdv="32key")),            # head_dim 128 (round 5): the forward on the pipelined body, one wave per SIMD

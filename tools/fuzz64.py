@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from flasht5_amd import _lib
 if os.environ.get("FUZZ_FORCE64", "1") != "0":  # FUZZ_FORCE64=0: the default dispatch (32-row bodies at these sizes)
-    _lib.set_variant(_lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON)
+    # FUZZ_VARIANT: further fat5_variant bits, e.g. 8454144 = FUSED64_ON | QDIAG_ON (round 6: the one-launch backward with the table gradient's diagonal sums in the dQ workgroups)
+    _lib.set_variant(_lib.V_FWD64_ON | _lib.V_KV64_ON | _lib.V_Q64_ON | int(os.environ.get("FUZZ_VARIANT", "0")))
 import oracle
 from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
 from test_attention_gpu import bound, gbound, _rpe_case

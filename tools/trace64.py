@@ -45,6 +45,9 @@ def show(rows, title):
             if rows[:, k_].min() <= 0:
                 continue
             print(f"   prologue detail: entry -> {n_:18s} {np.median(rows[:, k_] - rows[:, 0]):8.0f}")
+    for n_, k_ in (("dQ rows on their way", 12), ("diagonal arrays complete (barrier)", 13)):
+        if rows[:, k_].min() > 0:
+            print(f"   epilogue detail: drain -> {n_:34s} {np.median(rows[:, k_] - rows[:, 4]):8.0f}")
     tot = (rows[:, 6] - rows[:, 0]).astype(np.float64)
     print(f"   workgroup duration: median {np.median(tot):.0f}  max {tot.max():.0f}")
 
