@@ -393,7 +393,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   //  (16,12,256) 39.6 vs 47.6; (8,12,256) 36.6 vs 28.9, (4,12,256) 29.8 vs 29.5 -> from 2^23 scores per call on; below that only inside the one-launch form, see dfused64)
   const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 23);
   const bool qdb_pick = qdb_legal && dense_kv_ok && qdb_env != 0 && qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL));
-  L.kv64_half = !dense && (kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full));
+  // (causal, closing audit of round 6 -- profiles/r06_audit_causal_kv.log: with longest-first launches the pure 256-key form beats the half-length and the mixed one on every
+  //  causal problem measured, (8,12,1024) 41.7 vs 47.4 / 52.7 us, (5,12,1536) 48.1 vs 57.4 / 57.4, (16,12,1536) 141.3 vs 168.0 / 155.2 -> causal: only when a call forces them)
+  L.kv64_half = !dense && (kvh_env == 1 || (kvh_env != 0 && p->bias_mode == FAT5_BIAS_NONE && r_half < 0.9 * r_full && !p->causal));
   // Both variants in one launch (attn_bwd_kv64_mixed_kernel): the first `pf` (b, h) pairs of every XCD as 256-key workgroups, the
   // others half-length.  pf by a list-scheduling model of one XCD (32 CUs, one workgroup per CU, launch order; a half-length
   // workgroup costs 0.65 of a full one without bias, 0.73 with the T5 bias: measured round times 56 / 36 us and 70 / 51 us at
@@ -434,7 +436,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
       // (round 6, after causal launches went longest-first in round 5 -- profiles/r06_audit_s4096.log: the pure 256-key launch now wins on causal problems,
       //  (8,12,3072) causal 236.0 vs 255.4 us mixed, T5 bias 260.4 vs 280.2; (8,12,4096) 395.6 vs 425.2 / 433.4 vs 460.2; (4,12,6144) 426.9 vs 446.0 / 463.5 vs 481.7:
       //  the mixed launch deals pair-major -> a causal problem takes it only where the model asks for it, like every other)
-      if (best_pf > 0 && (mix_env == 1 || best < 0.95 * pure)) {
+      // (closing audit: where the model did ask -- (8,12,1024) causal, 384 workgroups -- the pure 256-key launch was the fastest forced form (41.3 us): the model
+      //  assumes workgroups of equal length -> causal problems take the mixed launch when a call forces it, never by the model)
+      if (best_pf > 0 && (mix_env == 1 || (best < 0.95 * pure && !p->causal))) {
         L.kv64_mix_pf = best_pf;
         mix_gain = best / makespan(per);
       }
@@ -454,13 +458,15 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
   const bool ctab_kv = p->causal && p->bias_mode == FAT5_BIAS_RPE1D && p->N - p->M < p->rpe_radius && p->N - p->M >= -p->rpe_radius;
   // (round 5: without bias the mask rides in the score MFMAs' C operand -- (4,12,2048) causal 73.7 (half-length) vs 82.7 us, (16,12,2048) 261 vs 269;
   //  (16,12,1024) 102 vs 95 -> from 2048 keys on as well; dense: see dense_rule)
-  const bool kv64_causal_ok = !p->causal || p->N >= ((ctab_kv || p->bias_mode == FAT5_BIAS_NONE) ? 2048 : 4096);
+  // (round-6 audit at B = 16, profiles/r06_dispatch_audit_16x12.log -- with causal launches longest-first: (16,12,1024) causal 74.4 vs 80.2 us for the 32-key body,
+  //  T5 bias 84.9 vs 97.7; (8,12,1024) 41.3 vs 43.8 -> from 1024 keys on)
+  const bool kv64_causal_ok = !p->causal || p->N >= ((ctab_kv || p->bias_mode == FAT5_BIAS_NONE) ? 1024 : 4096);
   // (dense, round 5 -- bias on the matrix pipe, causal mask in the C operand; 64-key vs 32-key body, us: (4,12,2048) 137 vs 164, (4,12,8192) 1700 vs 2208;
   //  causal (16,12,512) 52.5 vs 54.1, (16,12,1024) 121 vs 133, (16,12,2048) 344 vs 392 -> from 192 workgroups on)
   //  (with the dQ + dBias body taken -- qdb_pick above -- the 64-key body follows it down to 2^23 scores)
   const bool dense_rule = dense && ((wg256 >= cu_scaled(192) && (int64_t)bh * p->M * p->N >= (int64_t(1) << 25)) || qdb_pick);
   L.kv64 = p->D == 64 && (!dense || dense_kv_ok) && !p->cu_seqlens_q && b64_env != 0 &&
-           (b64_env == 1 || dense_rule || ((wg256 >= cu_scaled(fills ? 320 : 512) ||
+           (b64_env == 1 || dense_rule || ((wg256 >= cu_scaled(p->causal ? 256 : (fills ? 320 : 512)) ||  // (causal: unequal workgroups fill the last round by themselves -- (8,12,1024) causal, 384 workgroups, 41.7 vs 43.7 us for the 32-key body; (5,12,1536), 360: 48.1 vs 53.0; (6,12,1024), 288: 33.4 vs 34.1)
                               // (long query streams pay even with the chip under-filled: 192 workgroups at (4,12,4096x1024) 99.5 vs 121.7 us,
                               //  (4,12,8192x1024) 190 vs 234; with the T5 bias 117 vs 146 and 213 vs 274)
                               (wg256 >= cu_scaled(160) && p->M >= 4096 && !p->causal)) && kv64_causal_ok)) && kv64_lds <= 160 * 1024;

@@ -17,6 +17,7 @@ ap.add_argument("--bh", default="4x12,8x12,16x12"); ap.add_argument("--S", defau
 ap.add_argument("--max-work", type=float, default=48 * 8192.0 ** 2 * 1.01)
 ap.add_argument("--D", type=int, default=64); ap.add_argument("--scale", type=float, default=0.125)
 ap.add_argument("--stages", default="fwd,dq,dkdv,bwd")  # (head_dim 128: --stages fwd -- only the forward has more than one body there)
+ap.add_argument("--all", action="store_true")  # print every forced body's time, not only the best
 ap.add_argument("--MN", default="")  # rectangular problems instead of --S: "512x1024,2048x512" (M x N)
 a = ap.parse_args()
 
@@ -86,6 +87,8 @@ for bh in a.bh.split(","):
                     best = min((t, n) for n, t in res.items() if n != "default")
                     bad = res["default"] > 1.05 * best[0]
                     line += f" | {stage}: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
+                    if a.all:
+                        line += " [" + " ".join(f"{n_}={t_:.1f}" for n_, t_ in res.items() if n_ != "default") + "]"
                     if bad:
                         flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
                 res = {}

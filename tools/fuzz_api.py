@@ -8,107 +8,13 @@ usage: python tools/fuzz_api.py [n_cases] [seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch
-import oracle
-from flasht5_amd import flash_attention_v2_bias, flash_attention_v2_rpe, _lib
-from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
-from test_attention_gpu import bound, gbound
+from api_fuzz import run_case
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for i in range(n):
-    D = rng.choice([16, 32, 64, 64, 64, 128])
-    B, H = rng.randint(1, 5), rng.randint(1, 4)
-    big = rng.random() < 0.6
-    M = rng.randint(1, 700) if big else rng.randint(1, 70)
-    N = rng.randint(1, 700) if big else rng.randint(1, 70)
-    if rng.random() < 0.3:
-        N = M
-    causal = rng.random() < 0.4
-    dtype = torch.bfloat16 if rng.random() < 0.7 else torch.float16
-    scale = rng.choice([None, 0.125, 0.25, 1.0 / 3, 1.0, 1.3])
-    kind = rng.choice(["none", "1h", "1h", "bh", "11", "b1", "rpe", "rpe"])
-    strided = rng.random() < 0.5
-    q, k, v, b, do = make_inputs(B, H, M, N, D, dtype, kind if kind not in ("none", "rpe") else None, seed=3000 + i, strided=strided)
-    sc = scale if scale is not None else D ** -0.5
-    if sc > 0.5:
-        q = (q.float() * 0.35).to(dtype)
-    mask = ""
-    md = 128
-    table = None
-    if kind == "rpe":
-        md = rng.choice([32, 64, 128, 128, 256])
-        bidir = rng.random() < 0.7
-        table = torch.randn(32, H, generator=torch.Generator().manual_seed(i)) * 0.5
-        b = oracle.compute_bias(table, M, N, bidir, 32, md).contiguous().cuda()  # (fp32: the table mode never rounds the bias)
-    elif b is not None and rng.random() < 0.35 and N > 1:
-        # padded keys: the last `pad` keys of some batch elements (or of all, with a shared bias) masked the way the model does it
-        neg = rng.choice([float("-inf"), torch.finfo(dtype).min])
-        pad = rng.randint(1, max(1, N // 2))
-        b = b.clone()
-        if b.shape[0] > 1:
-            b[rng.randrange(b.shape[0]), :, :, N - pad:] = neg
-        else:
-            b[:, :, :, N - pad:] = neg
-        mask = f" mask={neg:.3g}x{pad}"
-    ref = oracle_all(q, k, v, b, do, sc, causal)
-    leaves = [t.detach().clone().requires_grad_() for t in (q, k, v)]
-    try:
-        if kind == "rpe":
-            tb = table.cuda().requires_grad_()
-            o = flash_attention_v2_rpe(leaves[0], leaves[1], leaves[2], tb, bidir, 32, md, causal, scale)
-            dq, dk, dv, dt = torch.autograd.grad(o, leaves + [tb], do)
-        elif b is not None:
-            bb = b.detach().clone().requires_grad_()
-            o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], bb, causal, scale)
-            dq, dk, dv, db = torch.autograd.grad(o, leaves + [bb], do)
-        else:
-            o = flash_attention_v2_bias(leaves[0], leaves[1], leaves[2], None, causal, scale)
-            dq, dk, dv = torch.autograd.grad(o, leaves, do)
-        torch.cuda.synchronize()
-    except Exception as e:  # noqa: BLE001
-        print(f"BAD case {i}: D={D} B={B} H={H} M={M} N={N} causal={int(causal)} {kind} raised {type(e).__name__}: {e}", flush=True)
-        bad += 1
-        continue
-    got = {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv}
-    msgs = []
-    lp = None
-    for key in ("o", "dq", "dk", "dv") + (("db",) if kind not in ("none", "rpe") else ()):
-        g = db if key == "db" else got[key]
-        r = ref[key]
-        if key == "db":
-            r = r.to(torch.float32)
-            if tuple(r.shape) != tuple(g.shape):  # (the oracle returns dS summed to the bias shape already; guard all the same)
-                msgs.append(f"db shape {tuple(g.shape)} vs {tuple(r.shape)}")
-                continue
-        # a sum over b batch elements / h heads of rounded dS: one output rounding of a value up to (b h) times larger, b h times the roundings inside
-        nsum = 1
-        if key == "db":
-            nsum = (B if b.shape[0] == 1 else 1) * (H if b.shape[1] == 1 else 1)
-        lim = bound(r, dtype) if key == "o" else gbound(r, dtype) * (1 + (nsum if nsum > 1 else 0))
-        # masked entries: finite-or-identical is all that can be asked of a gradient at a -inf bias (maxdiff treats equal infinities / exact zeros as 0)
-        e = maxdiff(g, r)
-        fin = torch.isfinite(g.float()).all()
-        if fin and e <= lim:
-            continue
-        if lp is None:
-            bl = b.to(dtype) if b is not None else None
-            lp = eager_lowprec_errors(q, k, v, bl, do, sc, causal, ref)
-        if not fin or e > 2 * lp.get(key, 0.0) * (nsum if key == "db" else 1) + 1e-5:
-            msgs.append(f"{key} {e:.3e} > {lim:.3e} and > 2 x eager {lp.get(key, float('nan')):.3e}" + ("" if fin else " (non-finite)"))
-    if kind == "rpe":
-        _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, b, o.detach(), ref["L"], do, sc, causal)
-        tl = table.clone().requires_grad_()
-        oracle.compute_bias(tl, M, N, bidir, 32, md).backward(db_alg.cpu())
-        want = tl.grad
-        # (truth as in tests/test_attention_gpu.py::test_rpe_mode_matches_dense_oracle: the oracle's dS with delta formed from the STORED o, pushed through compute_bias)
-        err = (dt.detach().cpu() - want).abs().max().item()
-        lim = 2e-2 * max(1.0, want.abs().max().item())
-        if not torch.isfinite(dt).all() or err > lim:
-            msgs.append(f"dtable {err:.3e} > {lim:.3e}")
-    tag = "OK " if not msgs else "BAD"
+    desc, msgs = run_case(i, rng)
     bad += bool(msgs)
-    print(f"{tag} case {i}: D={D} B={B} H={H} M={M} N={N} causal={int(causal)} {kind}{' md=%d' % md if kind == 'rpe' else ''} {str(dtype)[6:]} scale={sc:.3f} "
-          f"strided={int(strided)}{mask} {'; '.join(msgs)}", flush=True)
+    print(f"{'OK ' if not msgs else 'BAD'} case {i}: {desc} {'; '.join(msgs)}", flush=True)
 print(f"FUZZ_API: {bad} bad of {n}")
