@@ -281,7 +281,9 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
     //  wins on causal problems from 3072 waves on: (8,12,2048) causal 66.3 split vs 64.7 us, T5 bias 66.7 vs 64.3; (4,12,4096) 114.2 vs 110.8 / 116.6 vs 108.4;
     //  (16,12,2048) 136.6 vs 124.4 / 136.0 vs 122.8; (8,12,4096) 230.4 vs 207.7 / 226.6 vs 204.0; (4,12,8192) 406.5 vs 373.4; (16,12,1024) T5 bias 45.8 vs 43.2 --
     //  the causal extension to 8192 waves of rounds 3-4 is gone; below 2048 waves the split form stays for every mask)
-    const bool ksplit = ks_env == 1 || (ks_env != 0 && waves64 < cu_scaled(2048));
+    //  (B H = 64 audit, profiles/r06_dispatch_audit_other_H.log: at exactly 2048 waves the split form still wins on causal problems -- (2,32,2048) causal 46.2 vs 49.0 us,
+    //   (4,16,2048) 46.6 vs 48.5, (8,8,2048) 46.2 vs 48.4 -- and ties on full ones (69.5 either way) -> causal: below 2560 waves)
+    const bool ksplit = ks_env == 1 || (ks_env != 0 && waves64 < cu_scaled(p->causal ? 2560 : 2048));
     // (round-4 audit: without bias as well -- (16,12,1024) causal 51.1 split vs 55.1 us, (16,12,2048) 138.7 vs 151.5: the split form's Q / O now travel as whole rows)
     // (ctab: (16,12,1024) causal 50.6 split vs 53.4, (16,12,2048) 140 vs 147 -- the diagonal tiles no longer cost the split form an exact tile each)
     // (... and only while a wave still has keys to split: (16,12,1024) causal, 3072 waves of 16 tiles, 55.4 us plain vs 57.6 split;
@@ -517,8 +519,9 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     //  (2,32,4096), 2048 workgroups, T5 bias 506.1 vs 534.4, none 486.3 vs 493.5 -> causal problems up to 2048 workgroups)
     // (round-6 audit, profiles/r06_dispatch_audit_H12.log -- after causal problems left the mixed dK/dV launch the separate launches caught up at 1536 workgroups:
     //  (4,12,4096) causal 368.1 one launch vs 349.8 us, T5 bias 378.8 vs 377.2; (8,12,2048) 214.7 vs 206.1, T5 bias 226.8 vs 216.0; 768 workgroups stay:
-    //  (4,12,2048) 115.4 / 119.1 one launch, (8,12,1024) 79.2 / 77.7 -> causal problems up to 1280 workgroups)
-    const long max_wg = (p->causal && (ctab || p->bias_mode == FAT5_BIAS_NONE)) ? cu_scaled(1280) : FUSED64_MAX_WG;
+    //  (4,12,2048) 115.4 / 119.1 one launch, (8,12,1024) 79.2 / 77.7; B H = 64 audit, 1024 workgroups: (2,32,2048) causal 146.1 one launch vs 139.3, T5 bias 152.3 vs 149.5,
+    //  the same at (4,16,2048) / (8,8,2048) -> causal problems up to 896 workgroups)
+    const long max_wg = (p->causal && (ctab || p->bias_mode == FAT5_BIAS_NONE)) ? cu_scaled(896) : FUSED64_MAX_WG;
     // (round 5, no bias: the dK/dV half's diagonal steps are pipelined (mask in the C operand) -- (16,12,512) causal 65.7 vs 72.1 us, (4,12,512) 21.7 vs 22.6;
     //  (4,12,1024) 45.9 either way -> up to 512 keys)
     // (closing audit of round 5, after causal launches went longest-first -- profiles/r05c_dispatch_audit_H12.log: T5 bias (4,12,1024), 384 workgroups, 44.6 one launch vs

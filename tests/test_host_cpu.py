@@ -361,7 +361,7 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=8, M=512, N=512, **rpe), dict(fwd="32row-split", dq="64row", dkdv="64key", fused="1")),
         (dict(B=4, H=16, M=2048, N=2048, **rpe), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),
         (dict(B=3, H=5, M=2048, N=2048, causal=True), dict(dq="64row", dkdv="64key", fused="1")),         # an under-filled chip (240 workgroups), causal without bias: the one-launch form (56.5 vs 70.9 us)
-        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row", dq="64row", dkdv="64key", fused="1")),   # (1024 workgroups, plain causal from 2048 keys: the one-launch form since the closing audit of round 5)
+        (dict(B=2, H=32, M=2048, N=2048, causal=True), dict(fwd="64row-ksplit", dkdv="64key", fused="0")),   # (B H = 64 audit of round 6: 2048 waves, causal -- split form 46.2 vs 49.0 us; 1024 workgroups -- separate launches 139.3 vs 146.1)
         (dict(B=2, H=8, M=128, N=128), dict(fwd="32row", fused="1")),                                     # config 1's shape
         # head dims other than 64: the 32-wide bodies
         (dict(B=4, H=6, M=8192, N=8192, D=128), dict(fwd="64row", dq="32row", dkdv="32key")),            # head_dim 128 (round 5): the forward on the pipelined body, one wave per SIMD
