@@ -530,7 +530,10 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
     const bool causal_ok = !p->causal || (ctab && squarish && (tot <= chip_cus() || tot >= cu_scaled(512) || p->N >= 1024)) ||
                            // ((3,5,2048) causal, 240 workgroups: 56.5 vs 70.9 us -- profiles/r05_dispatch_audit_H8_16_32.log; round-6 audit: (8,12,512) causal, 384 workgroups
                            //  -- one and a half rounds of unequal workgroups -- 36.9 one launch vs 28.5 us: at <= 512 keys one round or from two rounds on, as with the T5 bias)
-                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (tot <= chip_cus() || (p->N <= 512 && tot >= cu_scaled(512)) || p->N >= 2048));
+                           // (B H = 64 audit: 1024 keys at exactly two rounds of workgroups -- (2,32,1024) / (4,16,1024) / (8,8,1024) causal 49.9-50.8 one launch vs 54.5-54.8 us; (8,12,1024), three rounds,
+                           //  77.0 vs 79.2; at 384 / 480 workgroups the 32-wide one-launch form holds -> whole rounds of the chip, up to four)
+                           (p->bias_mode == FAT5_BIAS_NONE && squarish && (tot <= chip_cus() || (p->N <= 512 && tot >= cu_scaled(512)) || p->N >= 2048 ||
+                                                                           (p->N <= 1024 && tot % chip_cus() == 0 && tot <= 4L * chip_cus())));  // ((4,16,1536), 768 workgroups: 96.3 one launch vs 90.6 -> up to 1024 keys)
     const bool rule = causal_ok && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }

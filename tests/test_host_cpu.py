@@ -321,7 +321,9 @@ def test_dispatch_rules_are_pinned():
         (dict(B=4, H=12, M=4096, N=4096, **rpe), dict(dq="64row", dkdv="64key")),            # T5 bias: band steps pipelined since round 4
         # causal: diagonal steps are unpipelined in the 64-wide backward bodies
         (dict(B=16, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="64key")),          # (round-6 audit at B = 16: 74.4 vs 80.2 us for the 32-key body; rounds 2-5: "32key")
-        (dict(B=8, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="64key", fused="0")),  # ... and the PURE 256-key launch on causal problems: 41.7 vs 47.4 half-length / 52.7 mixed (profiles/r06_audit_causal_kv.log)
+        (dict(B=6, H=12, M=1024, N=1024, causal=True), dict(dq="32row", dkdv="64key", fused="0")),  # ... and the PURE 256-key launch on causal problems: (8,12,1024) 41.7 vs 47.4 half-length / 52.7 mixed (profiles/r06_audit_causal_kv.log)
+        (dict(B=8, H=12, M=1024, N=1024, causal=True), dict(dq="64row", dkdv="64key", fused="1")),  # plain causal, 1024 keys, whole rounds of workgroups (768; B H = 64: 512 -- 49.9 vs 54.5 us): the one-launch 64-wide form
+        (dict(B=4, H=16, M=1536, N=1536, causal=True), dict(fused="0")),                            # ... not beyond 1024 keys (96.3 vs 90.6)
         (dict(B=5, H=12, M=1536, N=1536, causal=True), dict(dkdv="64key")),                         # ... 360 workgroups: 48.1 vs 53.0 (32-key) / 57.4
         (dict(B=16, H=12, M=2048, N=2048, causal=True), dict(dq="32row", dkdv="64key")),         # (round 6: pure 256-key launch since causal launches go longest-first -- profiles/r06_audit_s4096.log; round 5: diagonal steps pipelined without bias too -- 261 vs 269 us; (4,12,2048): 73.7 vs 82.7)
         (dict(B=4, H=12, M=4096, N=4096, causal=True), dict(fwd="64row", dq="32row", dkdv="64key", fused="0")),   # (round-6 audit: 1536 workgroups, separate launches 349.8 vs 368.1 us; forward 110.8 vs 114.2 split)   # (1536 workgroups: one launch 369.3 vs 387.8 us with the longest-first order, profiles/r05d_dispatch_audit_causal_bwd.log)
