@@ -13,15 +13,24 @@ from attn_helpers import make_inputs, oracle_all, maxdiff, eager_lowprec_errors
 from test_attention_gpu import bound, gbound
 
 
-def run_case(i, rng):
-    """case i drawn from `rng` (random.Random): returns (description, list of failures -- empty = passed)"""
-    D = rng.choice([16, 32, 64, 64, 64, 128])
-    B, H = rng.randint(1, 5), rng.randint(1, 4)
-    big = rng.random() < 0.6
-    M = rng.randint(1, 700) if big else rng.randint(1, 70)
-    N = rng.randint(1, 700) if big else rng.randint(1, 70)
-    if rng.random() < 0.3:
-        N = M
+def run_case(i, rng, large=False):
+    """case i drawn from `rng` (random.Random): returns (description, list of failures -- empty = passed).  large: production-sized problems (4 .. 96 (batch, head)
+    pairs, 256 .. 2304 rows / keys, mostly head_dim 64) -- the sizes at which the library's own dispatch reaches the 64-wide pipelined bodies and their launch forms"""
+    if large:
+        D = rng.choice([64, 64, 64, 128])
+        B, H = rng.randint(1, 8), rng.choice([4, 8, 12, 12, 16])
+        M = rng.randint(256, 2304)
+        N = rng.randint(256, 2304) if rng.random() < 0.5 else M
+        if rng.random() < 0.5:
+            M, N = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    else:
+        D = rng.choice([16, 32, 64, 64, 64, 128])
+        B, H = rng.randint(1, 5), rng.randint(1, 4)
+        big = rng.random() < 0.6
+        M = rng.randint(1, 700) if big else rng.randint(1, 70)
+        N = rng.randint(1, 700) if big else rng.randint(1, 70)
+        if rng.random() < 0.3:
+            N = M
     causal = rng.random() < 0.4
     dtype = torch.bfloat16 if rng.random() < 0.7 else torch.float16
     scale = rng.choice([None, 0.125, 0.25, 1.0 / 3, 1.0, 1.3])
