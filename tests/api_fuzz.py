@@ -114,3 +114,82 @@ def run_case(i, rng, large=False):
     desc = (f"D={D} B={B} H={H} M={M} N={N} causal={int(causal)} {kind}{' md=%d' % md if kind == 'rpe' else ''} {str(dtype)[6:]} scale={sc:.3f} "
             f"strided={int(strided)}{mask}")
     return desc, msgs
+
+
+def run_varlen_case(i, rng):
+    """Packed batches (`flash_attn_varlen_func`, SURVEY 8(f) n2 -- the reference pads instead, data_collator_ul2.py:49-87): 1 .. 7 sequences of 0 .. 400 tokens (empty and
+    one-token sequences included), cross-attention (independent key lengths) without bias or self-attention with the in-kernel T5 bias (positions local to each
+    sequence), head_dim 16 / 32 / 64 / 128, causal or not; o, dq, dk, dv (and the generator gradient) against the per-sequence fp32 oracle."""
+    from flasht5_amd import flash_attn_varlen_func
+    D = rng.choice([16, 32, 64, 64, 128])
+    H = rng.randint(1, 6)
+    nseq = rng.randint(1, 7)
+    causal = rng.random() < 0.4
+    with_rpe = rng.random() < 0.4
+    scale = rng.choice([0.125, 0.25, D ** -0.5])
+    lens_q = [rng.choice([0, 1, rng.randint(2, 60), rng.randint(61, 400)]) for _ in range(nseq)]
+    lens_k = list(lens_q) if with_rpe else [rng.choice([0, 1, rng.randint(2, 60), rng.randint(61, 400)]) for _ in range(nseq)]
+    if causal:  # (bottom-right aligned mask: more rows than keys would leave rows without a visible key -- NaN in the eager reference)
+        lens_q, lens_k = [min(a_, b_) if b_ > 0 else a_ for a_, b_ in zip(lens_q, lens_k)], lens_k
+    if sum(lens_q) == 0:
+        lens_q[0] = 17
+        if with_rpe:
+            lens_k[0] = 17
+    if sum(lens_k) == 0:
+        lens_k[0] = 23
+    cu_q, cu_k = [0], [0]
+    for a_, b_ in zip(lens_q, lens_k):
+        cu_q.append(cu_q[-1] + a_)
+        cu_k.append(cu_k[-1] + b_)
+    g = torch.Generator().manual_seed(5000 + i)
+    dtype = torch.bfloat16
+    q = torch.randn(cu_q[-1], H, D, generator=g).to(dtype).cuda()
+    k = torch.randn(cu_k[-1], H, D, generator=g).to(dtype).cuda()
+    v = torch.randn(cu_k[-1], H, D, generator=g).to(dtype).cuda()
+    do = torch.randn(cu_q[-1], H, D, generator=g).to(dtype).cuda()
+    R = rng.choice([8, 32, 128])
+    r1 = (torch.randn(H, 2 * R + 1, generator=g) * 0.5).cuda()
+    desc = f"varlen D={D} H={H} lens_q={lens_q} lens_k={lens_k} causal={int(causal)} {'rpe R=%d' % R if with_rpe else 'none'} scale={scale:.3f}"
+    leaves = [t.clone().requires_grad_() for t in (q, k, v)] + ([r1.clone().requires_grad_()] if with_rpe else [])
+    cq, ck = torch.tensor(cu_q, dtype=torch.int32).cuda(), torch.tensor(cu_k, dtype=torch.int32).cuda()
+    try:
+        if with_rpe:
+            o = flash_attn_varlen_func(leaves[0], leaves[1], leaves[2], cq, ck, max(lens_q), max(lens_k), causal, scale, leaves[3], R)
+        else:
+            o = flash_attn_varlen_func(leaves[0], leaves[1], leaves[2], cq, ck, max(lens_q), max(lens_k), causal, scale)
+        grads = torch.autograd.grad(o, leaves, do)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        return desc, [f"raised {type(e).__name__}: {e}"]
+    # per-sequence fp32 truth through autograd of the eager restatement (bias gathered from the same generator)
+    ref_leaves = [t.float().clone().requires_grad_() for t in (q, k, v)] + ([r1.clone().requires_grad_()] if with_rpe else [])
+    ref_o = torch.zeros(cu_q[-1], H, D, device="cuda")
+    total = None
+    for s in range(nseq):
+        qs, qe, ks, ke = cu_q[s], cu_q[s + 1], cu_k[s], cu_k[s + 1]
+        if qe == qs or ke == ks:
+            continue
+        qi, ki, vi = ref_leaves[0][qs:qe].permute(1, 0, 2).unsqueeze(0), ref_leaves[1][ks:ke].permute(1, 0, 2).unsqueeze(0), ref_leaves[2][ks:ke].permute(1, 0, 2).unsqueeze(0)
+        bias = None
+        if with_rpe:
+            idx = torch.clamp(torch.arange(ke - ks)[None, :] - torch.arange(qe - qs)[:, None], -R, R).cuda() + R
+            bias = ref_leaves[3][:, idx].unsqueeze(0)
+        oi = oracle.attn_ref(qi, ki, vi, bias, scale, causal=causal, upcast=True)[0].permute(1, 0, 2)
+        ref_o[qs:qe] = oi.detach()
+        t_ = (oi * do[qs:qe].float()).sum()
+        total = t_ if total is None else total + t_
+    if total is None:
+        ref_grads = [torch.zeros_like(t) for t in ref_leaves]
+    else:
+        ref_grads = [g_ if g_ is not None else torch.zeros_like(t) for g_, t in zip(torch.autograd.grad(total, ref_leaves, allow_unused=True), ref_leaves)]
+    msgs = []
+    if not torch.isfinite(o.float()).all() or maxdiff(o, ref_o) > bound(ref_o, dtype):
+        msgs.append(f"o {maxdiff(o, ref_o):.3e} > {bound(ref_o, dtype):.3e}")
+    for got, ref, key in zip(grads[:3], ref_grads[:3], ("dq", "dk", "dv")):
+        if not torch.isfinite(got.float()).all() or maxdiff(got, ref) > gbound(ref, dtype):
+            msgs.append(f"{key} {maxdiff(got, ref):.3e} > {gbound(ref, dtype):.3e}")
+    if with_rpe:
+        lim = 1e-2 * max(1.0, ref_grads[3].abs().max().item()) + 3e-2
+        if not torch.isfinite(grads[3]).all() or maxdiff(grads[3], ref_grads[3]) > lim:
+            msgs.append(f"drpe1d {maxdiff(grads[3], ref_grads[3]):.3e} > {lim:.3e}")
+    return desc, msgs

@@ -19,3 +19,15 @@ def test_public_operators_on_random_problems(block):
         if msgs:
             failures.append(f"{desc}: {'; '.join(msgs)}")
     assert not failures, failures
+
+
+def test_packed_batches_on_random_problems():
+    """flash_attn_varlen_func: random packed batches incl. empty and one-token sequences, cross-attention or the in-kernel T5 bias"""
+    from api_fuzz import run_varlen_case
+    rng = random.Random(300)
+    failures = []
+    for i in range(12):
+        desc, msgs = run_varlen_case(i, rng)
+        if msgs:
+            failures.append(f"{desc}: {'; '.join(msgs)}")
+    assert not failures, failures
