@@ -193,3 +193,63 @@ def run_varlen_case(i, rng):
         if not torch.isfinite(grads[3]).all() or maxdiff(grads[3], ref_grads[3]) > lim:
             msgs.append(f"drpe1d {maxdiff(grads[3], ref_grads[3]):.3e} > {lim:.3e}")
     return desc, msgs
+
+
+def run_rowwise_case(i, rng):
+    """The two bandwidth-bound operators around the attention path: `fast_rms_layernorm(X, W, eps)` (reference rms_norm.py:250-287) and `cross_entropy_loss(...)`
+    with label smoothing / z-loss / logit scale / ignored and out-of-range labels (cross_entropy_loss.py:280-426) on random shapes -- 1 .. 3000 rows, any width --
+    against the CPU restatement of their kernels, with the reference tests' tolerance (atol 1e-2, tests/test_rms_norm.py / test_cross_entropy.py)."""
+    from flasht5_amd import fast_rms_layernorm, cross_entropy_loss
+    msgs = []
+    dtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
+    g = torch.Generator().manual_seed(7000 + i)
+    if rng.random() < 0.5:
+        rows, n = rng.randint(1, 3000), rng.choice([rng.randint(1, 300), rng.randint(301, 4100), 512, 768, 1024, 2048])
+        lead = rng.random() < 0.5 and rows % 2 == 0
+        x = torch.randn(rows, n, generator=g).to(dtype)
+        w = (1.0 + 0.1 * torch.randn(n, generator=g)).to(dtype if rng.random() < 0.7 else torch.float32)
+        dy = torch.randn(rows, n, generator=g).to(dtype)
+        eps = rng.choice([1e-6, 1e-5])
+        desc = f"rmsnorm rows={rows} n={n} {str(dtype)[6:]} w={str(w.dtype)[6:]} eps={eps:g} 3d={int(lead)}"
+        y_ref, rstd = oracle.rmsnorm_fwd_oracle(x, w, eps)
+        dx_ref, dw_ref = oracle.rmsnorm_bwd_oracle(dy, x, w, rstd)
+        xs = x.cuda().view(2, rows // 2, n) if lead else x.cuda()
+        xg, wg = xs.clone().requires_grad_(), w.cuda().clone().requires_grad_()
+        try:
+            y = fast_rms_layernorm(xg, wg, eps)
+            dx, dw = torch.autograd.grad(y, [xg, wg], dy.cuda().view_as(y))
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            return desc, [f"raised {type(e).__name__}: {e}"]
+        for got, ref, key, tol in ((y.reshape(rows, n), y_ref, "y", 1e-2), (dx.reshape(rows, n), dx_ref, "dx", 1e-2), (dw, dw_ref, "dw", 1e-2 * max(1.0, rows ** 0.5))):
+            lim = tol * max(1.0, ref.float().abs().max().item())
+            if not torch.isfinite(got.float()).all() or maxdiff(got.cpu(), ref) > lim:
+                msgs.append(f"{key} {maxdiff(got.cpu(), ref):.3e} > {lim:.3e}")
+        return desc, msgs
+    rows, V = rng.randint(1, 600), rng.choice([rng.randint(2, 500), rng.randint(501, 40000), 32128, 32768])
+    smooth, zl, scale = rng.choice([0.0, 0.0, 0.1]), rng.choice([0.0, 1e-4, 1.0]), rng.choice([1.0, 1.0, 0.5])
+    logits = (torch.randn(rows, V, generator=g) * rng.choice([1.0, 4.0])).to(dtype)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    for r in range(rows):  # ignored rows and labels outside the vocabulary (the reference's vocab-parallel convention: no picked logit)
+        u = rng.random()
+        if u < 0.1:
+            labels[r] = -100
+        elif u < 0.13:
+            labels[r] = V + 5
+    inplace = rng.random() < 0.3
+    desc = f"ce rows={rows} V={V} {str(dtype)[6:]} smoothing={smooth} z={zl:g} logit_scale={scale} inplace={int(inplace)}"
+    l_ref, z_ref, lse = oracle.ce_fwd_oracle(logits, labels, smooth, scale, zl, -100)
+    dl = torch.randn(rows, generator=g)
+    d_ref = oracle.ce_bwd_oracle(dl, logits, lse, labels, smooth, scale, zl, -100)
+    lg = logits.cuda().clone().requires_grad_()
+    try:
+        losses, zz = cross_entropy_loss(lg, labels.cuda(), label_smoothing=smooth, logit_scale=scale, lse_square_scale=zl, inplace_backward=inplace)
+        (dlg,) = torch.autograd.grad(losses, [lg], dl.cuda())
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        return desc, [f"raised {type(e).__name__}: {e}"]
+    for got, ref, key in ((losses, l_ref, "loss"), (zz, z_ref, "z_loss"), (dlg, d_ref, "dlogits")):
+        lim = 1e-2 * max(1.0, ref.float().abs().max().item())
+        if not torch.isfinite(got.float()).all() or maxdiff(got.cpu(), ref) > lim:
+            msgs.append(f"{key} {maxdiff(got.cpu(), ref):.3e} > {lim:.3e}")
+    return desc, msgs

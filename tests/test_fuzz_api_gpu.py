@@ -31,3 +31,15 @@ def test_packed_batches_on_random_problems():
         if msgs:
             failures.append(f"{desc}: {'; '.join(msgs)}")
     assert not failures, failures
+
+
+def test_rowwise_operators_on_random_problems():
+    """fast_rms_layernorm and cross_entropy_loss (label smoothing, z-loss, logit scale, ignored / out-of-range labels, in-place backward) on random shapes"""
+    from api_fuzz import run_rowwise_case
+    rng = random.Random(400)
+    failures = []
+    for i in range(24):
+        desc, msgs = run_rowwise_case(i, rng)
+        if msgs:
+            failures.append(f"{desc}: {'; '.join(msgs)}")
+    assert not failures, failures
