@@ -768,12 +768,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # developer check of the N > 1 launch form on a one-GPU box with the REAL backend: FAT5_BENCH_FORCE_REDUCE=1 (N = 1 only) opens a one-rank "nccl" (= RCCL) group
+    # and runs the line exactly as N > 1 does -- U steps per replay, every step's all-reduce captured inside the graph, the capture validated against the eager
+    # collective.  The collective itself is trivial with one rank; ProcessGroupNCCL under stream capture and the RCCL launch as a graph node are the real ones.
+    # Never set by the driver (profiles/r06_bench_force_reduce_1rank.log).
+    force_reduce = world == 1 and os.environ.get("FAT5_BENCH_FORCE_REDUCE") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    elif force_reduce:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29618")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     import flasht5_amd  # noqa: F401  raises if libfat5.so is missing
     S, mode = args.seq, args.mode
@@ -805,12 +814,12 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
     from flasht5_amd.sharding import OverlappedGradReduce
-    want_reduce = world > 1 and mode != "none"
+    want_reduce = (world > 1 or force_reduce) and mode != "none"
     # ONE launch rule for every N (launch_plan): U steps per replay -- the same launches in the same order, one host call per U steps -- and with more
     # than one rank the all-reduce of every step's bias(-table) gradient INSIDE the captured graph (RCCL collectives are stream operations: U of them per
     # replay, each between its step's backward and the next step's forward, in place on the gradient).  --bucket-allreduce: the U gradients are kept (one
     # stream-ordered copy per step inside the graph) and travel in ONE all-reduce per replay instead.
-    lp = launch_plan(world, args.graph_steps, args.bucket_allreduce, graph is None, args.steps, want_reduce)
+    lp = launch_plan(2 if force_reduce else world, args.graph_steps, args.bucket_allreduce, graph is None, args.steps, want_reduce)
     U = lp["steps_per_replay"]
     graph_u, stash, ar_fallback = None, None, None
 
@@ -1029,6 +1038,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # (rank 0 may still have been busy with its extras: everyone leaves together)
+        dist.destroy_process_group()
+    elif force_reduce:
         dist.destroy_process_group()
 
 
