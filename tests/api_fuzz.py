@@ -78,6 +78,7 @@ def run_case(i, rng, large=False):
     got = {"o": o.detach(), "dq": dq, "dk": dk, "dv": dv}
     msgs = []
     lp = None
+    fa2 = None
     for key in ("o", "dq", "dk", "dv") + (("db",) if kind not in ("none", "rpe") else ()):
         g = db if key == "db" else got[key]
         r = ref[key]
@@ -100,6 +101,16 @@ def run_case(i, rng, large=False):
             bl = b.to(dtype) if b is not None else None
             lp = eager_lowprec_errors(q, k, v, bl, do, sc, causal, ref)
         if not fin or e > 2 * lp.get(key, 0.0) * (nsum if key == "db" else 1) + 1e-5:
+            # third yardstick, gradients only: the FA2 backward DEFINES delta = rowsum(o * do) on the STORED (rounded) o (reference _bwd_preprocess reads the 16-bit o,
+            # flash_attention_v2_bias.py:516-556) -- on peaked rows (dP' ~ delta) that differs from the fp32-o gradient by ~2^-9 |o| |do| sqrt(D) per dS element, which
+            # neither bound above models.  The same formulas fed with the kernel's own o are the reference kernel's arithmetic in fp32:
+            if fin and key != "o":
+                if fa2 is None:
+                    dq2, dk2, dv2, _, db2 = oracle.attn_bwd_oracle(q, k, v, b, got["o"], ref["L"], do, sc, causal)
+                    fa2 = {"dq": dq2, "dk": dk2, "dv": dv2, "db": db2}
+                e2 = maxdiff(g, fa2[key].to(torch.float32))
+                if e2 <= lim:
+                    continue
             msgs.append(f"{key} {e:.3e} > {lim:.3e} and > 2 x eager {lp.get(key, float('nan')):.3e}" + ("" if fin else " (non-finite)"))
     if kind == "rpe":
         _, _, _, _, db_alg = oracle.attn_bwd_oracle(q, k, v, b, o.detach(), ref["L"], do, sc, causal)
@@ -129,14 +140,16 @@ def run_varlen_case(i, rng):
     scale = rng.choice([0.125, 0.25, D ** -0.5])
     lens_q = [rng.choice([0, 1, rng.randint(2, 60), rng.randint(61, 400)]) for _ in range(nseq)]
     lens_k = list(lens_q) if with_rpe else [rng.choice([0, 1, rng.randint(2, 60), rng.randint(61, 400)]) for _ in range(nseq)]
-    if causal:  # (bottom-right aligned mask: more rows than keys would leave rows without a visible key -- NaN in the eager reference)
-        lens_q, lens_k = [min(a_, b_) if b_ > 0 else a_ for a_, b_ in zip(lens_q, lens_k)], lens_k
     if sum(lens_q) == 0:
         lens_q[0] = 17
         if with_rpe:
             lens_k[0] = 17
     if sum(lens_k) == 0:
         lens_k[0] = 23
+    if causal:  # (bottom-right aligned mask: more rows than keys would leave rows without a visible key -- NaN in the eager reference)
+        lens_q = [min(a_, b_) if b_ > 0 else a_ for a_, b_ in zip(lens_q, lens_k)]
+        if sum(lens_q) == 0:
+            lens_q[0] = lens_k[0] = 9
     cu_q, cu_k = [0], [0]
     for a_, b_ in zip(lens_q, lens_k):
         cu_q.append(cu_q[-1] + a_)
@@ -183,15 +196,57 @@ def run_varlen_case(i, rng):
     else:
         ref_grads = [g_ if g_ is not None else torch.zeros_like(t) for g_, t in zip(torch.autograd.grad(total, ref_leaves, allow_unused=True), ref_leaves)]
     msgs = []
-    if not torch.isfinite(o.float()).all() or maxdiff(o, ref_o) > bound(ref_o, dtype):
-        msgs.append(f"o {maxdiff(o, ref_o):.3e} > {bound(ref_o, dtype):.3e}")
-    for got, ref, key in zip(grads[:3], ref_grads[:3], ("dq", "dk", "dv")):
-        if not torch.isfinite(got.float()).all() or maxdiff(got, ref) > gbound(ref, dtype):
-            msgs.append(f"{key} {maxdiff(got, ref):.3e} > {gbound(ref, dtype):.3e}")
+    lowp = None
+
+    def lowp_errors():
+        """the reference tests' yardstick (tests/fa2_triton/test_fa2_bias.py:64-67): the error of eager attention in the input dtype, per sequence"""
+        lv = [t.clone().requires_grad_() for t in (q, k, v)]
+        lo = torch.zeros(cu_q[-1], H, D, device="cuda")
+        tot = None
+        for s_ in range(nseq):
+            qs, qe, ks, ke = cu_q[s_], cu_q[s_ + 1], cu_k[s_], cu_k[s_ + 1]
+            if qe == qs or ke == ks:
+                continue
+            bias = None
+            if with_rpe:
+                idx = torch.clamp(torch.arange(ke - ks)[None, :] - torch.arange(qe - qs)[:, None], -R, R).cuda() + R
+                bias = r1[:, idx].unsqueeze(0).to(dtype)
+            oi = oracle.attn_ref(lv[0][qs:qe].permute(1, 0, 2).unsqueeze(0), lv[1][ks:ke].permute(1, 0, 2).unsqueeze(0), lv[2][ks:ke].permute(1, 0, 2).unsqueeze(0),
+                                 bias, scale, causal=causal, upcast=False)[0].permute(1, 0, 2)
+            lo[qs:qe] = oi.detach().float()
+            t_ = (oi.float() * do[qs:qe].float()).sum()
+            tot = t_ if tot is None else tot + t_
+        gl = torch.autograd.grad(tot, lv) if tot is not None else [torch.zeros_like(t) for t in lv]
+        return {"o": maxdiff(lo, ref_o), "dq": maxdiff(gl[0], ref_grads[0]), "dk": maxdiff(gl[1], ref_grads[1]), "dv": maxdiff(gl[2], ref_grads[2])}
+
+    for got, ref, key, lim in [(o, ref_o, "o", bound(ref_o, dtype))] + [(g_, r_, k_, gbound(r_, dtype)) for g_, r_, k_ in zip(grads[:3], ref_grads[:3], ("dq", "dk", "dv"))]:
+        e = maxdiff(got, ref)
+        if torch.isfinite(got.float()).all() and e <= lim:
+            continue
+        if lowp is None and torch.isfinite(got.float()).all():
+            lowp = lowp_errors()
+        if not torch.isfinite(got.float()).all() or e > 2 * lowp[key] + 1e-5:
+            msgs.append(f"{key} {e:.3e} > {lim:.3e}" + (f" and > 2 x eager {lowp[key]:.3e}" if lowp is not None else " (non-finite)"))
     if with_rpe:
         lim = 1e-2 * max(1.0, ref_grads[3].abs().max().item()) + 3e-2
-        if not torch.isfinite(grads[3]).all() or maxdiff(grads[3], ref_grads[3]) > lim:
-            msgs.append(f"drpe1d {maxdiff(grads[3], ref_grads[3]):.3e} > {lim:.3e}")
+        e = maxdiff(grads[3], ref_grads[3])
+        if torch.isfinite(grads[3]).all() and e > lim:
+            # the FA2 definition (see run_case): dS with delta = rowsum(o * do) on the STORED o, summed along its diagonals -- far bins of a small radius collect
+            # thousands of dS elements whose per-row delta offsets do not cancel
+            alt = torch.zeros_like(ref_grads[3])
+            for s_ in range(nseq):
+                qs, qe, ks, ke = cu_q[s_], cu_q[s_ + 1], cu_k[s_], cu_k[s_ + 1]
+                if qe == qs or ke == ks:
+                    continue
+                idx = torch.clamp(torch.arange(ke - ks)[None, :] - torch.arange(qe - qs)[:, None], -R, R).cuda() + R
+                bias = r1[:, idx].unsqueeze(0)
+                qi, ki, vi = q[qs:qe].permute(1, 0, 2).unsqueeze(0), k[ks:ke].permute(1, 0, 2).unsqueeze(0), v[ks:ke].permute(1, 0, 2).unsqueeze(0)
+                oi, Li = oracle.attn_fwd_oracle(qi, ki, vi, bias, scale, causal)
+                _, _, _, ds, _ = oracle.attn_bwd_oracle(qi, ki, vi, bias, o[qs:qe].detach().permute(1, 0, 2).unsqueeze(0), Li, do[qs:qe].permute(1, 0, 2).unsqueeze(0), scale, causal)
+                alt.index_add_(1, idx.reshape(-1), ds[0].reshape(H, -1).float())
+            e = maxdiff(grads[3], alt)
+        if not torch.isfinite(grads[3]).all() or e > lim:
+            msgs.append(f"drpe1d {e:.3e} > {lim:.3e}")
     return desc, msgs
 
 
