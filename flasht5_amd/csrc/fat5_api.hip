@@ -393,7 +393,15 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
                          ((int64_t)(p->M - 1) * p->bias_stride[2] + p->N) * 2 < (int64_t(1) << 31);
   // (measured, whole dense backward, both 64-wide bodies against both older ones, us -- profiles/r05_dfused_time2.log: (4,12,768) 60.5 vs 78.5, (8,12,512) 55.1 vs 72.8, (2,12,1024) 71.9 vs 83.5,
   //  (16,12,256) 39.6 vs 47.6; (8,12,256) 36.6 vs 28.9, (4,12,256) 29.8 vs 29.5 -> from 2^23 scores per call on; below that only inside the one-launch form, see dfused64)
-  const bool qdb_rule = p->B >= 2 && (int64_t)p->B * p->H * p->M * p->N >= (int64_t(1) << 23);
+  // (closing audit of round 6, the one dense row above 5 %: (8,12,512) CAUSAL -- 192 + 192 workgroups of unequal length, one and a half rounds of the chip whether as one launch
+  //  or two -- 58.9 us against 51.1 for the 32-wide one-launch body + staged dS; one round ((4,12,512): 31.9 vs 41.8) and two rounds ((16,12,512): 81.7 vs 92.6) stay)
+  const long qdb_nq = (long)p->H * qdb_ngrp * ((p->M + 63) / 64);
+  const bool dense_causal_odd_round = dense && p->causal && p->N <= 512 && wg256 + qdb_nq > chip_cus() && wg256 + qdb_nq < 2L * chip_cus();
+  // (the same audit off the power-of-two grid, profiles/r06_audit_dense_small.log, whole dense backward, us: (6,12,384) 54.1 vs 37.2 for the 32-wide one-launch body + staged dS,
+  //  (5,12,384) 53.8 vs 37.7, (7,12,384) 53.4 vs 42.4, (8,12,384) 54.5 vs 49.6, (5,12,512) 54.7 vs 48.8; (6,12,512) 55.3 vs 59.7, (7,12,512) 55.6 vs 62.7, (8,12,512) 56.4 vs 69.0:
+  //  the two 64-wide launches cost ~54 us whatever the size down there -> from 2^24 scores on; 2^23 .. 2^24 only for the many short workgroups of B >= 16 ((16,12,256) 39.6 vs 47.6))
+  const int64_t dense_scores = (int64_t)p->B * p->H * p->M * p->N;
+  const bool qdb_rule = p->B >= 2 && (dense_scores >= (int64_t(1) << 24) || (dense_scores >= (int64_t(1) << 23) && p->B >= 16)) && !dense_causal_odd_round;
   const bool qdb_pick = qdb_legal && dense_kv_ok && qdb_env != 0 && qdb_rule && !(p->variant & (FAT5_V_DBIAS_STAGED | FAT5_V_DBIAS_INKERNEL));
   // (causal, closing audit of round 6 -- profiles/r06_audit_causal_kv.log: with longest-first launches the pure 256-key form beats the half-length and the mixed one on every
   //  causal problem measured, (8,12,1024) 41.7 vs 47.4 / 52.7 us, (5,12,1536) 48.1 vs 57.4 / 57.4, (16,12,1536) 141.3 vs 168.0 / 155.2 -> causal: only when a call forces them)

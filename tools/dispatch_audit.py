@@ -92,7 +92,7 @@ for bh in a.bh.split(","):
                     if bad:
                         flags.append((B, H, M, S, causal, mode, stage, round(res["default"], 1), best[1], round(best[0], 1)))
                 res = {}
-                for name, bits in () if "bwd" not in stages else (BWD.items() if not dense else {"default": 0, "round4": L.V_QDB64_OFF | L.V_KV64_OFF}.items()):
+                for name, bits in () if "bwd" not in stages else (BWD.items() if not dense else {"default": 0, "round4": L.V_QDB64_OFF | L.V_KV64_OFF, "64wide": L.V_QDB64_ON | L.V_KV64_ON | L.V_FUSED64_OFF, "64wide-one-launch": L.V_QDB64_ON | L.V_KV64_ON | L.V_FUSED64_ON}.items()):
                     plan.set_variant(bits)
                     res[name] = gpu_time(lambda: plan.backward(7 if dense else 3), it)
                 plan.set_variant(0)
@@ -103,6 +103,8 @@ for bh in a.bh.split(","):
                 best = min((t, n) for n, t in res.items() if n != "default")
                 bad = res["default"] > 1.05 * best[0]
                 line += f" | bwd: {res['default']:8.1f} us, best {best[1]} {best[0]:8.1f}" + (" <-- MISS" if bad else "")
+                if a.all:
+                    line += " [" + " ".join(f"{n_}={t_:.1f}" for n_, t_ in res.items() if n_ != "default") + "]"
                 if bad:
                     flags.append((B, H, M, S, causal, mode, "bwd", round(res["default"], 1), best[1], round(best[0], 1)))
                 print(line, flush=True)
