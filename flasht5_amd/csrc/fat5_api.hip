@@ -263,7 +263,8 @@ static FwdChoice fwd_choice(const fat5_attn_params* p) {
                         !(p->N <= 512 && p->causal && !ctab) &&
                         // (closing audit of round 5, profiles/r05c_dispatch_audit_H12.log: (2,12,1024) causal, 384 waves -- 15.5 vs 12.5 us for the 32-row body, T5 bias 14.8 vs 13.4;
                         //  (4,12,1024) causal, 768 waves, 15.6 either way -> causal problems of 513 .. 2047 keys from 768 waves on)
-                        !(p->causal && p->N > 512 && p->N < 2048 && waves64 < cu_scaled(768)) &&
+                        // (off-grid audit of round 6: (5,12,768) causal, 720 waves -- 13.9 vs 16.5 us for the 32-row body, T5 bias 13.4 vs 19.5 -> from 512 waves on)
+                        !(p->causal && p->N > 512 && p->N < 2048 && waves64 < cu_scaled(512)) &&
                         // (its two waves per SIMD need two workgroups per CU: a radius beyond ~500 takes the table past 80 KB of LDS)
                         smem_fwd64_d64(p->rpe_radius, p->bias_mode) <= 80 * 1024))) {
     c.fwd64 = true;
@@ -542,7 +543,14 @@ static int bwd_layout_compute(const fat5_attn_params* p, BwdLayout& L) {
                            //  77.0 vs 79.2; at 384 / 480 workgroups the 32-wide one-launch form holds -> whole rounds of the chip, up to four)
                            (p->bias_mode == FAT5_BIAS_NONE && squarish && (tot <= chip_cus() || (p->N <= 512 && tot >= cu_scaled(512)) || p->N >= 2048 ||
                                                                            (p->N <= 1024 && tot % chip_cus() == 0 && tot <= 4L * chip_cus())));  // ((4,16,1536), 768 workgroups: 96.3 one launch vs 90.6 -> up to 1024 keys)
-    const bool rule = causal_ok && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
+    // (off-grid audit of round 6, profiles/r06_audit_offgrid.log: the 64-wide bodies work in 256-key / 256-row workgroups -- 384 = 1.5 x 256 wastes a quarter of both halves:
+    //  (6,12,384) 26.3 one launch vs 18.8 us on the 32-wide bodies, T5 bias 36.0 vs 27.3; (7,12,384) 37.4 vs 24.7 / 42.0 vs 31.6; (5,12,384) 26.1 vs 21.7 -> non-causal problems
+    //  whose padding to 256 exceeds 20 % stay on the 32-wide bodies; causal (6,12,384) / (7,12,384) tie either way)
+    const long padM = ((p->M + 255) / 256) * 256, padN = ((p->N + 255) / 256) * 256;
+    //  (second pass, profiles/r06_audit_offgrid_after.log: only where the launch does not fit one round -- (4,12,384), 192 workgroups, 28.2 one launch vs 38.9; (5,12,384), 240: 28.4 vs
+    //   30.5 -- and from 20 % on: (4,12,640), 288 workgroups, 38.9 one launch vs 26.9, T5 bias 53.1 vs 36.3; (5,12,640) T5 54.6 vs 46.3; (7,12,640) 56.9 vs 51.5; (6,12,640) ties)
+    const bool padded = !p->causal && tot > chip_cus() && ((p->M > 256 && padM * 5 >= (long)p->M * 6) || (p->N > 256 && padN * 5 >= (long)p->N * 6));
+    const bool rule = causal_ok && !padded && (tot <= cu_scaled(384) || (tot <= max_wg && squarish)) && b64_env != 0 && q64_env != 0 && kvh_env != 1 && mix_env != 1;
     L.fused64 = f64_env == 1 || rule;
   }
   if (L.fused64) {
